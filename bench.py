@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: jacobi3d 512^3 float32, 1000-operator chain (BASELINE.json
+configs[2]) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one execution of the whole 1000-operator chain on a synthetic
+grid resident in HBM.  N > 1 (launched by torch.distributed.run, one rank per
+GPU) runs the slab-decomposed configuration configs[3]: (512*N) x 512 x 512,
+split along the outermost axis, halos exchanged over RCCL -- per-GPU work is
+fixed, so scaling is weak.  Rank 0 prints ONE JSON line (contract: task
+description; fields `roofline` and `cpu_baseline` are added at N = 1).
+"""
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(shape, block=8, budget_s=12.0):
+    """The oracle's C/OpenMP restatement timed on the host cores, on a bounded
+    sample: the same operator on the same grid, applied `block` operators at a
+    time (output fed back as input) until about `budget_s` seconds have passed."""
+    from oracle import c_oracle
+    from stencilflow_amd import programs
+    cores = os.cpu_count() or 1
+    ref = c_oracle.CompiledReference(programs.jacobi3d(shape, block),
+                                     threads=cores)
+    out_name = "b{}".format(block - 1)
+    x = ref.run({"a": np.ones(shape, np.float32)})[out_name]  # untimed warm-up
+    applied, t0 = 0, time.perf_counter()
+    while True:
+        x = ref.run({"a": x})[out_name]
+        applied += block
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or applied >= 1000:
+            break
+    cells = float(np.prod(shape)) * applied
+    return {
+        "value": cells / dt / 1e6,
+        "unit": "Mcells/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "{} operators of the chain on the full {}x{}x{} grid, "
+                  "{:.1f} s, gcc -O3 -fopenmp, {} threads".format(
+                      applied, shape[0], shape[1], shape[2], dt, cores),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--stages", type=int, default=1000)
+    ap.add_argument("--options", type=str, default="")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import stencilflow_amd as sf
+    from stencilflow_amd import programs
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    n = args.size
+    shape = (n * world, n, n)
+    prog = programs.jacobi3d(shape, args.stages)
+    options = {k: v for k, v in (kv.split("=") for kv in args.options.split(";") if kv)}
+
+    with tempfile.TemporaryDirectory() as tmp:
+        path = programs.write_program(prog, os.path.join(tmp, "bench.json"))
+        chain = sf.KernelChainGraph(path)
+        sfir = lower(chain)
+
+    if world > 1:
+        from stencilflow_amd.distributed import SlabRunner
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        runner = SlabRunner(sfir, shape, rank, world, device=local_rank,
+                            options=options)
+        local = np.ones(runner.local_shape, np.float32)
+        runner.upload([local])
+
+        def step():
+            runner.execute()
+
+        def sync():
+            runner.synchronize()
+            dist.barrier()
+    else:
+        plan = Plan(sfir, device=local_rank, options=options)
+        plan.upload([np.ones(shape, np.float32)])
+
+        def step():
+            plan.execute(1)
+
+        def sync():
+            plan.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        step()
+        if world == 1:
+            # HIP events bracket the launches of this step on the plan's stream
+            plan.synchronize()
+            kernel_ms += plan.elapsed_ms()
+    sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cells = float(np.prod(shape)) * args.stages * args.steps
+    result = {
+        "metric": "Mcells/s (updates) and achieved HBM GB/s vs roofline, "
+                  "jacobi3d 512^3 f32",
+        "value": cells / elapsed / 1e6,
+        "unit": "Mcells/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "jacobi3d {}x{}x{} float32, {}-operator chain, "
+                        "constant BC 0.0, coefficient 0.16666666".format(
+                            shape[0], shape[1], shape[2], args.stages),
+            "decomposition": "slab{}".format(world) if world > 1 else "single",
+        },
+    }
+    if world == 1:
+        stats = plan.kernel_stats()
+        launches = plan.num_launches * args.steps
+        name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"])
+        alg = cells * 8.0 / launches  # 2 * sizeof(f32) per cell update
+        avg_s = kernel_ms * 1e-3 / launches
+        achieved = alg / avg_s
+        result["roofline"] = {
+            "bound": "hbm",
+            "kernel": name,
+            "achieved": achieved / 1e9,
+            "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg,
+            "avg_launch_us": avg_s * 1e6,
+            "launches": launches,
+        }
+        result["config"]["schedule"] = plan.describe().splitlines()[1].strip()
+        if not args.no_cpu_baseline and rank == 0:
+            result["cpu_baseline"] = cpu_baseline(shape, budget_s=args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

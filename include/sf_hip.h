@@ -1,0 +1,139 @@
+/* sf_hip.h — C ABI of libsf_hip.so, the MI355X (gfx950) execution backend for
+ * StencilFlow stencil-chain programs.
+ *
+ * Boundary being replaced (paths relative to the reference tree):
+ *   The reference's driver obtains a compiled program from DaCe and calls it
+ *   through ctypes:  `program = sdfg.compile()`            stencilflow/run_program.py:120-123
+ *                    `program(**dace_args)` x repetitions   stencilflow/run_program.py:164-178
+ *   i.e. an init / call / exit triple over caller-owned, C-contiguous NumPy
+ *   buffers (arrays keyed `<name>_host`, 0-D inputs passed by value).
+ *   `sf_plan_create / sf_plan_run / sf_plan_destroy` are that triple; the
+ *   record DaCe receives (`generate_sdfg`, stencilflow/sdfg_generator.py:219-577,
+ *   per operator `_generate_stencil`, :68-176) is passed here as SFIR text
+ *   (grammar: stencilflow_amd/lowering.py).
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a
+ * negative sf_status on failure, with a thread-local message available from
+ * sf_last_error(); nothing throws across the boundary.  Host buffers belong
+ * to the caller (inputs are only read, outputs only written, during the call);
+ * all device memory, streams and code objects belong to the plan.  A plan is
+ * not re-entrant; distinct plans may be used from distinct threads.
+ */
+#ifndef SF_HIP_H
+#define SF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sf_plan sf_plan;
+
+enum sf_status {
+  SF_OK = 0,
+  SF_ERR_INVALID = -1,     /* bad argument / malformed SFIR  (Python: ValueError)   */
+  SF_ERR_UNSUPPORTED = -2, /* valid program the backend cannot run (ValueError)    */
+  SF_ERR_COMPILE = -3,     /* hipRTC rejected generated code       (RuntimeError)  */
+  SF_ERR_DEVICE = -4,      /* HIP runtime error / no GPU           (RuntimeError)  */
+  SF_ERR_STATE = -5        /* call order violated                  (RuntimeError)  */
+};
+
+/* ABI version of this header (major*1000 + minor). */
+int sf_version(void);
+
+/* Message of the last failure on the calling thread ("" if none). */
+const char* sf_last_error(void);
+
+/* Number of visible HIP devices, or a negative status. */
+int sf_device_count(void);
+
+/* Build a plan from SFIR text: analysis, kernel generation and hipRTC
+ * compilation for gfx950.  No GPU is touched until the first run/upload, so
+ * this succeeds on a machine without a device (used by the build check).
+ * `options` is a ';'-separated list of key=value tuning overrides or NULL
+ * (keys: see DESIGN.md §Options).                     replaces: sdfg.compile(),
+ * stencilflow/run_program.py:118-128 */
+int sf_plan_create(const char* sfir_text, int device, const char* options,
+                   sf_plan** out_plan);
+
+int sf_plan_destroy(sf_plan* plan);
+
+/* Introspection: the argument lists `sf_plan_run` expects, in order.
+ * Arrays first (program order), then nothing else: 0-D inputs are scalars. */
+int sf_plan_num_inputs(const sf_plan* plan);   /* array inputs   */
+int sf_plan_num_scalars(const sf_plan* plan);  /* 0-D inputs     */
+int sf_plan_num_outputs(const sf_plan* plan);
+const char* sf_plan_input_name(const sf_plan* plan, int index);
+const char* sf_plan_scalar_name(const sf_plan* plan, int index);
+const char* sf_plan_output_name(const sf_plan* plan, int index);
+/* bytes of input/output array `index` (full array, C order) */
+size_t sf_plan_input_bytes(const sf_plan* plan, int index);
+size_t sf_plan_output_bytes(const sf_plan* plan, int index);
+
+/* Run-time values of the 0-D inputs, as doubles (converted to each scalar's
+ * declared type).  Must be set before the first run if the program has any. */
+int sf_plan_set_scalars(sf_plan* plan, const double* values, int count);
+
+/* The drop-in call: copy inputs host->device, execute the whole chain
+ * `repetitions` times, copy outputs device->host, synchronously.
+ *                                replaces: program(**dace_args),
+ *                                stencilflow/run_program.py:170-178 */
+int sf_plan_run(sf_plan* plan, const void* const* host_inputs,
+                void* const* host_outputs, int repetitions);
+
+/* Device-resident variant used for measurement and by the multi-GPU driver:
+ * inputs stay in HBM between executions. */
+int sf_plan_upload(sf_plan* plan, const void* const* host_inputs);
+int sf_plan_execute(sf_plan* plan, int repetitions); /* asynchronous */
+int sf_plan_synchronize(sf_plan* plan);
+int sf_plan_download(sf_plan* plan, void* const* host_outputs);
+
+/* HIP-event time of the last sf_plan_execute (whole chain, all repetitions),
+ * in milliseconds; valid after sf_plan_synchronize. */
+int sf_plan_elapsed_ms(sf_plan* plan, double* ms);
+
+/* Launch schedule of one execution of the chain. */
+int sf_plan_num_launches(const sf_plan* plan);
+/* Distinct generated kernels. */
+int sf_plan_num_kernels(const sf_plan* plan);
+/* Name of generated kernel `index` as it appears in rocprofv3 traces. */
+const char* sf_plan_kernel_name(const sf_plan* plan, int index);
+/* Generated HIP source of kernel `index` (for inspection / offline hipcc). */
+const char* sf_plan_kernel_source(const sf_plan* plan, int index);
+/* Per-kernel timing of the last execution when the option "profile=1" is set:
+ * number of launches of kernel `index`, their summed HIP-event duration (ms),
+ * cell updates and algorithmic bytes (2*sizeof(dtype) per update) per launch. */
+int sf_plan_kernel_stats(sf_plan* plan, int index, int* launches,
+                         double* total_ms, double* updates_per_launch,
+                         double* algorithmic_bytes_per_launch);
+/* Human-readable description of the schedule (groups, tiles, buffers). */
+const char* sf_plan_describe(const sf_plan* plan);
+
+/* ---- slab decomposition (multi-GPU; one plan per rank) --------------------
+ * The outermost dimension is split into contiguous slabs.  A rank's plan is
+ * created with the option "slab=<lo>:<hi>:<halo>" and works on local arrays of
+ * (hi-lo+2*halo) planes.  One chain execution is a sequence of steps; before
+ * step s the planes listed by sf_plan_step_halo must have been exchanged with
+ * the neighbouring ranks for the buffer it names. */
+int sf_plan_num_steps(const sf_plan* plan);
+/* depth (planes) and device buffer id of the field step `step` reads across
+ * slab boundaries; depth 0 if the step needs no exchange. */
+int sf_plan_step_halo(const sf_plan* plan, int step, int* buffer_id,
+                      int* depth);
+/* Execute one step on `stream` (a hipStream_t, or NULL for the plan's own).
+ * part: 0 = whole slab, 1 = planes adjacent to the lower slab boundary,
+ *       2 = planes adjacent to the upper boundary, 3 = interior only. */
+int sf_plan_execute_step(sf_plan* plan, int step, int part, void* stream);
+/* Device address, plane size in bytes and plane count of device buffer `id`. */
+int sf_plan_buffer_info(const sf_plan* plan, int buffer_id, void** device_ptr,
+                        size_t* plane_bytes, int* planes);
+/* Buffer ids holding input `index` / output `index` at start / end of a chain. */
+int sf_plan_input_buffer(const sf_plan* plan, int index);
+int sf_plan_output_buffer(const sf_plan* plan, int index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SF_HIP_H */

@@ -1,0 +1,844 @@
+// sf_hip.cpp — libsf_hip.so: planner, hipRTC driver and runtime behind the C ABI
+// of include/sf_hip.h.  Host code only; every device kernel is generated per
+// program (codegen.hpp, kernels/star3d.h) and compiled for gfx950 at plan
+// creation, the way the reference compiles each program's SDFG before calling
+// it (stencilflow/run_program.py:118-128).
+#include "../../include/sf_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+#include "codegen.hpp"
+
+namespace sf {
+
+static thread_local std::string g_last_error;
+
+#define SF_HIP_CHECK(expr)                                                            \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      throw Error(SF_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// ---------------------------------------------------------------- options
+struct Options {
+  std::map<std::string, std::string> kv;
+  explicit Options(const char* text) {
+    if (!text) return;
+    std::string s(text), item;
+    std::istringstream is(s);
+    while (std::getline(is, item, ';')) {
+      if (item.empty()) continue;
+      size_t eq = item.find('=');
+      if (eq == std::string::npos) throw Error(SF_ERR_INVALID, "option without '=': " + item);
+      kv[item.substr(0, eq)] = item.substr(eq + 1);
+    }
+  }
+  long long get(const std::string& k, long long dflt) const {
+    auto it = kv.find(k);
+    return it == kv.end() ? dflt : std::stoll(it->second);
+  }
+  std::string gets(const std::string& k, const std::string& dflt) const {
+    auto it = kv.find(k);
+    return it == kv.end() ? dflt : it->second;
+  }
+};
+
+// ---------------------------------------------------------------- plan pieces
+struct CompiledKernel {
+  std::string name, source;
+  std::vector<char> code;
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  int launches = 0;
+  double total_ms = 0;
+  double updates_per_launch = 0, alg_bytes_per_launch = 0;
+};
+
+struct Buffer {
+  DT dt = DT::F32;
+  bool slabbed = true;     // has the stream dimension (I0)
+  size_t plane_bytes = 0;  // bytes of one I0 plane (whole array if !slabbed)
+  int planes = 1;          // local planes incl. halos
+  void* d = nullptr;
+  size_t bytes() const { return plane_bytes * (size_t)planes; }
+};
+
+struct Step {
+  bool star = false;
+  std::vector<int> kernels;    // program kernel indices fused in this launch
+  int ck = -1;                 // compiled kernel
+  std::vector<int> in_bufs;    // argument order
+  int out_buf = -1;
+  std::vector<int> scalars;    // run-time scalars, argument / struct order
+  std::vector<size_t> scalar_offsets;
+  size_t scalars_bytes = 4;
+  StarCfg cfg;
+  int halo_buf = -1, halo_depth = 0;  // what must be exchanged before the step
+  std::string note;
+};
+
+}  // namespace sf
+
+using namespace sf;
+
+struct sf_plan {
+  Program P;
+  Options opt{nullptr};
+  int device = 0;
+  bool device_ready = false;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  bool timed = false, profile = false;
+  std::vector<CompiledKernel> kernels;
+  std::map<std::string, int> kernel_by_source;
+  std::vector<Buffer> buffers;
+  std::vector<Step> steps;
+  std::vector<int> input_buf, output_buf;  // by io_index
+  std::vector<double> scalar_values;       // by Scalar::input_index
+  bool scalars_set = false;
+  // slab decomposition of I0
+  long long n_local = 0, goff = 0;
+  int halo = 0;
+  std::string description;
+  // per-launch profiling events
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  std::vector<int> prof_kernel;
+};
+
+namespace sf {
+
+// ---------------------------------------------------------------- hipRTC
+static void compile_kernel(CompiledKernel& k) {
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, k.source.c_str(), (k.name + ".hip").c_str(), 0, nullptr, nullptr) !=
+      HIPRTC_SUCCESS)
+    throw Error(SF_ERR_COMPILE, "hiprtcCreateProgram failed");
+  const std::string def = "-DSF_KERNEL_NAME=" + k.name;
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                        def.c_str()};
+  hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+  if (r != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    throw Error(SF_ERR_COMPILE, "hipRTC failed for " + k.name + ":\n" + log);
+  }
+  size_t n = 0;
+  hiprtcGetCodeSize(prog, &n);
+  k.code.resize(n);
+  hiprtcGetCode(prog, k.code.data());
+  hiprtcDestroyProgram(&prog);
+}
+
+static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& source) {
+  auto it = pl.kernel_by_source.find(source);
+  if (it != pl.kernel_by_source.end()) return it->second;
+  CompiledKernel k;
+  k.name = prefix + "_" + hex8(fnv1a(source));
+  k.source = source;
+  compile_kernel(k);
+  pl.kernels.push_back(std::move(k));
+  pl.kernel_by_source[source] = (int)pl.kernels.size() - 1;
+  return (int)pl.kernels.size() - 1;
+}
+
+// ---------------------------------------------------------------- planner
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static size_t star_lds_bytes(const StarCfg& c, DT dt);
+
+static StarCfg choose_star_cfg(const sf_plan& pl, int T, DT dt) {
+  const Program& P = pl.P;
+  StarCfg c;
+  c.T = T;
+  c.VK = 4;
+  c.n0g = P.n[0];
+  c.n1 = P.n[1];
+  c.n2 = P.n[2];
+  c.noj = (P.n[1] == 1);
+  c.row_fence = (int)pl.opt.get("k1.fence", 1);
+  const int hk = round_up(T, c.VK);
+  if (c.noj) {
+    c.RJ = 1;
+    c.BY = 1;
+    c.BX = (int)pl.opt.get("k2.bx", 64);
+  } else {
+    c.RJ = (int)pl.opt.get("k1.rj", 4);
+    long long bx = pl.opt.get("k1.bx", 0);
+    if (bx == 0) {
+      // widest tile that wastes the fewest lanes on k halo / padding
+      double best = -1;
+      for (int cand : {64, 128}) {
+        const long long tkh = (long long)cand * c.VK;
+        double eff;
+        if (tkh == P.n[2]) {
+          eff = 1.0;
+        } else {
+          const long long tki = tkh - 2 * hk;
+          const long long nkt = (P.n[2] + tki - 1) / tki;
+          eff = (double)P.n[2] / (double)(nkt * tkh);
+        }
+        if (eff > best + 1e-9) {
+          best = eff;
+          bx = cand;
+        }
+      }
+    }
+    c.BX = (int)bx;
+    long long by = pl.opt.get("k1.by", 0);
+    if (by == 0) {
+      const int max_by = 1024 / c.BX;
+      // enough rows for the whole column, but no more than the block limit
+      const long long want = (P.n[1] + 2 * T + c.RJ - 1) / c.RJ;
+      by = std::max<long long>(2, std::min<long long>(max_by, want));
+      // keep the exchange image within LDS (and leave room for a second block)
+      c.BY = (int)by;
+      while (c.BY > 2 && star_lds_bytes(c, dt) > 96 * 1024 && (c.BY - 1) * c.RJ - 2 * T >= 1) --c.BY;
+      by = c.BY;
+    }
+    c.BY = (int)by;
+  }
+  if (c.BX % 64 != 0 || c.BX * c.BY > 1024 || c.BX < 64)
+    throw Error(SF_ERR_INVALID, "star kernel: block shape must be a multiple of 64 lanes and <= 1024 threads");
+  const long long tkh = (long long)c.BX * c.VK;
+  c.ktiled = (tkh != P.n[2]);
+  c.HK = c.ktiled ? hk : 0;
+  c.NKT = c.ktiled ? (int)((P.n[2] + (tkh - 2 * c.HK) - 1) / (tkh - 2 * c.HK)) : 1;
+  if (c.noj) {
+    c.NJT = 1;
+  } else {
+    const int tji = c.BY * c.RJ - 2 * T;
+    if (tji < 1) throw Error(SF_ERR_INVALID, "star kernel: tile has no interior rows (raise k1.by / k1.rj)");
+    c.NJT = (int)((P.n[1] + tji - 1) / tji);
+  }
+  return c;
+}
+
+static size_t star_lds_bytes(const StarCfg& c, DT dt) {
+  const size_t rows = c.noj ? 0 : (size_t)c.T * c.BY * 2 * c.BX * c.VK;
+  const size_t edge = (size_t)c.T * c.BY * c.RJ * (c.BX / 64) * 2;
+  return (rows + edge) * size_of(dt);
+}
+
+static void build_plan(sf_plan& pl) {
+  const Program& P = pl.P;
+  const int K = (int)P.kernels.size();
+  pl.profile = pl.opt.get("profile", 0) != 0;
+
+  // slab of the stream dimension owned by this plan
+  pl.n_local = P.n[0];
+  pl.goff = 0;
+  pl.halo = 0;
+  {
+    const std::string slab = pl.opt.gets("slab", "");
+    if (!slab.empty()) {
+      long long lo, hi;
+      int h;
+      if (std::sscanf(slab.c_str(), "%lld:%lld:%d", &lo, &hi, &h) != 3 || lo < 0 || hi > P.n[0] ||
+          lo >= hi || h < 0)
+        throw Error(SF_ERR_INVALID, "option slab=<lo>:<hi>:<halo> out of range");
+      pl.n_local = hi - lo;
+      pl.goff = lo;
+      pl.halo = h;
+    }
+  }
+
+  // consumers per field
+  std::map<std::string, int> consumers;
+  for (auto& k : P.kernels) {
+    std::set<std::string> seen;
+    for (auto& a : k.acc)
+      if (seen.insert(a.field).second) consumers[a.field]++;
+  }
+
+  const int fuse = (int)std::max<long long>(1, pl.opt.get("fuse", 2));
+  const bool generic_only = pl.opt.get("generic_only", 0) != 0;
+  const bool star_ok_dims = (P.nd >= 2) && (P.n[2] % 4 == 0) && P.n[0] > 1;
+
+  // ---- group kernels into launches
+  for (int k = 0; k < K;) {
+    Step st;
+    std::string src;
+    bool star = !generic_only && star_ok_dims && star_eligible(P, P.kernels[k], &src);
+    if (star && P.n[1] == 1) {
+      for (auto& a : P.kernels[k].acc)
+        if (a.off[1] != 0) star = false;
+    }
+    if (star) {
+      st.star = true;
+      st.kernels.push_back(k);
+      while ((int)st.kernels.size() < fuse && k + (int)st.kernels.size() < K) {
+        const int cur = st.kernels.back(), nxt = cur + 1;
+        const Kernel& kc = P.kernels[cur];
+        std::string nsrc;
+        if (!star_eligible(P, P.kernels[nxt], &nsrc)) break;
+        if (nsrc != kc.name) break;
+        if (P.field(kc.name).role != Role::Temp) break;
+        if (consumers[kc.name] != 1) break;
+        if (P.kernels[nxt].dt != kc.dt) break;
+        st.kernels.push_back(nxt);
+      }
+    } else {
+      st.kernels.push_back(k);
+    }
+    k += (int)st.kernels.size();
+    pl.steps.push_back(st);
+  }
+
+  // ---- buffers with liveness-based reuse (the reference keeps one full-size
+  // transient per intermediate, sdfg_generator.py:626-630; a 1000-stage chain
+  // needs two)
+  auto make_buffer = [&](const Field& f) {
+    Buffer b;
+    b.dt = f.dt;
+    b.slabbed = f.has[0] && P.n[0] > 1;
+    size_t plane = size_of(f.dt);
+    if (f.has[1]) plane *= (size_t)P.n[1];
+    if (f.has[2]) plane *= (size_t)P.n[2];
+    if (b.slabbed) {
+      b.plane_bytes = plane;
+      b.planes = (int)(pl.n_local + 2 * pl.halo);
+    } else {
+      b.plane_bytes = plane * (f.has[0] ? (size_t)P.n[0] : 1);
+      b.planes = 1;
+    }
+    pl.buffers.push_back(b);
+    return (int)pl.buffers.size() - 1;
+  };
+  std::map<std::string, int> buf_of;   // live field -> buffer
+  std::map<std::string, int> last_use; // field -> last step reading it
+  auto step_reads = [&](const Step& st) {
+    std::vector<std::string> r;
+    if (st.star) {
+      r.push_back(P.kernels[st.kernels[0]].acc[0].field);
+    } else {
+      for (auto& a : P.kernels[st.kernels[0]].acc)
+        if (std::find(r.begin(), r.end(), a.field) == r.end()) r.push_back(a.field);
+    }
+    return r;
+  };
+  for (size_t s = 0; s < pl.steps.size(); ++s)
+    for (auto& f : step_reads(pl.steps[s])) last_use[f] = (int)s;
+
+  pl.input_buf.assign(P.num_inputs, -1);
+  pl.output_buf.assign(P.num_outputs, -1);
+  for (auto& f : P.fields)
+    if (f.role == Role::Input) {
+      const int b = make_buffer(f);
+      buf_of[f.name] = b;
+      pl.input_buf[f.io_index] = b;
+    }
+  std::multimap<std::pair<size_t, int>, int> free_pool;  // (bytes, dt) -> buffer
+  for (size_t s = 0; s < pl.steps.size(); ++s) {
+    Step& st = pl.steps[s];
+    for (auto& f : step_reads(st)) {
+      auto it = buf_of.find(f);
+      if (it == buf_of.end()) throw Error(SF_ERR_INVALID, "field '" + f + "' is read before it is produced");
+      st.in_bufs.push_back(it->second);
+    }
+    const Field& of = P.field(P.kernels[st.kernels.back()].name);
+    int ob = -1;
+    if (of.role == Role::Output) {
+      ob = make_buffer(of);
+      pl.output_buf[of.io_index] = ob;
+    } else {
+      Buffer probe;
+      {
+        // size the candidate without registering it
+        const size_t before = pl.buffers.size();
+        const int tmp = make_buffer(of);
+        probe = pl.buffers[tmp];
+        pl.buffers.resize(before);
+      }
+      auto key = std::make_pair(probe.bytes(), (int)probe.dt);
+      auto it = free_pool.find(key);
+      if (it != free_pool.end()) {
+        ob = it->second;
+        free_pool.erase(it);
+      } else {
+        ob = make_buffer(of);
+      }
+    }
+    st.out_buf = ob;
+    buf_of[of.name] = ob;
+    // release temporaries whose last reader was this step
+    for (auto& f : step_reads(st)) {
+      const Field& rf = P.field(f);
+      if (rf.role == Role::Temp && last_use[f] == (int)s) {
+        const int b = buf_of[f];
+        free_pool.insert({{pl.buffers[b].bytes(), (int)pl.buffers[b].dt}, b});
+        buf_of.erase(f);
+      }
+    }
+  }
+
+  // ---- generate + compile kernels
+  const double cells = (double)pl.n_local * (double)P.n[1] * (double)P.n[2];
+  std::ostringstream desc;
+  desc << "program " << P.name << ": dims " << P.n[0] << "x" << P.n[1] << "x" << P.n[2] << ", "
+       << K << " operators, " << pl.steps.size() << " launches, " << pl.buffers.size()
+       << " device buffers\n";
+  for (auto& st : pl.steps) {
+    const DT dt = P.kernels[st.kernels[0]].dt;
+    if (st.star) {
+      st.cfg = choose_star_cfg(pl, (int)st.kernels.size(), dt);
+      if (star_lds_bytes(st.cfg, dt) > 160 * 1024)
+        throw Error(SF_ERR_INVALID, "star kernel: tile needs more than 160 KiB of LDS");
+      StarKernelSource g = gen_star(P, st.kernels, st.cfg);
+      st.scalars = g.scalars;
+      st.scalar_offsets = g.scalar_offsets;
+      st.scalars_bytes = g.scalars_bytes;
+      std::string prefix = std::string("sf_star") + (st.cfg.noj ? "2d_" : "3d_") + short_of(dt) + "_t" +
+                           std::to_string(st.cfg.T);
+      st.ck = intern_kernel(pl, prefix, g.source);
+      st.halo_depth = st.cfg.T;
+      st.halo_buf = st.in_bufs[0];
+    } else {
+      GenericKernelSource g = gen_generic(P, st.kernels[0]);
+      st.scalars = g.scalars;
+      st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
+      int depth = 0, hb = -1;
+      for (size_t ai = 0; ai < P.kernels[st.kernels[0]].acc.size(); ++ai) {
+        const Access& a = P.kernels[st.kernels[0]].acc[ai];
+        if (std::abs(a.off[0]) > depth) {
+          depth = std::abs(a.off[0]);
+        }
+      }
+      // exchange descriptor names the first slab-split field read across planes
+      for (size_t r = 0; r < g.reads.size(); ++r)
+        for (auto& a : P.kernels[st.kernels[0]].acc)
+          if (a.field == g.reads[r] && a.off[0] != 0 && hb < 0) hb = st.in_bufs[r];
+      st.halo_depth = depth;
+      st.halo_buf = hb;
+    }
+    if (pl.halo > 0 && st.halo_depth > pl.halo)
+      throw Error(SF_ERR_INVALID, "slab halo is shallower than a launch's reach; raise the halo");
+    CompiledKernel& ck = pl.kernels[st.ck];
+    ck.updates_per_launch = cells * (double)st.kernels.size();
+    ck.alg_bytes_per_launch = 0;
+    for (int k : st.kernels) ck.alg_bytes_per_launch += cells * 2.0 * (double)size_of(P.kernels[k].dt);
+    desc << "  launch " << ck.name << ": ";
+    for (int k : st.kernels) desc << P.kernels[k].name << " ";
+    if (st.star)
+      desc << "[star T=" << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
+           << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " lds "
+           << star_lds_bytes(st.cfg, dt) << " B]";
+    else
+      desc << "[point]";
+    desc << " in";
+    for (int b : st.in_bufs) desc << " b" << b;
+    desc << " out b" << st.out_buf << "\n";
+    if (desc.tellp() > 16384) break;
+  }
+  pl.description = desc.str();
+  pl.scalar_values.assign(P.num_scalar_inputs, 0.0);
+}
+
+// ---------------------------------------------------------------- runtime
+static void ensure_device(sf_plan& pl) {
+  if (pl.device_ready) return;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    throw Error(SF_ERR_DEVICE, "no HIP device available: the HIP backend cannot run without a GPU");
+  if (pl.device < 0 || pl.device >= count) throw Error(SF_ERR_DEVICE, "device index out of range");
+  SF_HIP_CHECK(hipSetDevice(pl.device));
+  SF_HIP_CHECK(hipStreamCreateWithFlags(&pl.stream, hipStreamNonBlocking));
+  SF_HIP_CHECK(hipEventCreate(&pl.ev_begin));
+  SF_HIP_CHECK(hipEventCreate(&pl.ev_end));
+  for (auto& k : pl.kernels) {
+    SF_HIP_CHECK(hipModuleLoadData(&k.mod, k.code.data()));
+    SF_HIP_CHECK(hipModuleGetFunction(&k.fn, k.mod, k.name.c_str()));
+  }
+  for (auto& b : pl.buffers) {
+    SF_HIP_CHECK(hipMalloc(&b.d, b.bytes()));
+    SF_HIP_CHECK(hipMemsetAsync(b.d, 0, b.bytes(), pl.stream));
+  }
+  SF_HIP_CHECK(hipStreamSynchronize(pl.stream));
+  pl.device_ready = true;
+}
+
+static void store_scalar(char* dst, DT dt, double v) {
+  switch (dt) {
+    case DT::F32: { float x = (float)v; std::memcpy(dst, &x, 4); break; }
+    case DT::F64: { std::memcpy(dst, &v, 8); break; }
+    case DT::I32: { int x = (int)v; std::memcpy(dst, &x, 4); break; }
+    default: { long long x = (long long)v; std::memcpy(dst, &x, 8); break; }
+  }
+}
+
+static void launch_step(sf_plan& pl, const Step& st, int part, hipStream_t stream) {
+  const Program& P = pl.P;
+  int i_begin = 0, i_end = (int)pl.n_local;
+  if (part != 0) {
+    const int h = std::max(pl.halo, 1);
+    if (2 * h > pl.n_local) throw Error(SF_ERR_STATE, "slab too thin to split into boundary and interior");
+    if (part == 1) i_end = h;
+    else if (part == 2) i_begin = (int)pl.n_local - h;
+    else { i_begin = h; i_end = (int)pl.n_local - h; }
+  }
+  if (i_begin >= i_end) return;
+  if (P.num_scalar_inputs > 0 && !pl.scalars_set)
+    throw Error(SF_ERR_STATE, "the program has 0-D inputs: call sf_plan_set_scalars first");
+  CompiledKernel& ck = pl.kernels[st.ck];
+  int halo = pl.halo, goff = (int)pl.goff, n_local = (int)pl.n_local;
+  std::vector<void*> args;
+  std::vector<void*> ptrs;
+  ptrs.reserve(st.in_bufs.size() + 1);
+  alignas(16) char scalar_store[512];
+  if (st.scalars_bytes > sizeof scalar_store || st.scalars.size() * 8 > sizeof scalar_store)
+    throw Error(SF_ERR_UNSUPPORTED, "too many scalar inputs for one launch");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (pl.profile) {
+    SF_HIP_CHECK(hipEventCreate(&e0));
+    SF_HIP_CHECK(hipEventCreate(&e1));
+    SF_HIP_CHECK(hipEventRecord(e0, stream));
+  }
+  if (st.star) {
+    const StarCfg& c = st.cfg;
+    ptrs.push_back(pl.buffers[st.in_bufs[0]].d);
+    ptrs.push_back(pl.buffers[st.out_buf].d);
+    std::memset(scalar_store, 0, sizeof scalar_store);
+    for (size_t s = 0; s < st.scalars.size(); ++s) {
+      const Scalar& sc = P.scalars[st.scalars[s]];
+      store_scalar(scalar_store + st.scalar_offsets[s], sc.dt, pl.scalar_values[sc.input_index]);
+    }
+    // chunking of the stream axis: aim at a whole number of block waves
+    const int range = i_end - i_begin;
+    const int tiles = c.NJT * c.NKT;
+    int occ = std::max(1, std::min(8, 2048 / (c.BX * c.BY)));
+    const size_t lds = star_lds_bytes(c, P.kernels[st.kernels[0]].dt);
+    if (lds > 0) occ = std::max(1, std::min<int>(occ, (int)(160 * 1024 / std::max<size_t>(lds, 1))));
+    long long li = pl.opt.get(c.noj ? "k2.li" : "k1.li", 0);
+    if (li <= 0) {
+      const int target = 256 * occ;
+      int nch = std::max(1, (target + tiles / 2) / tiles);
+      li = (range + nch - 1) / nch;
+      const int min_li = std::min(range, 8 * c.T);
+      if (li < min_li) li = min_li;
+    }
+    if (li > range) li = range;
+    const int nch = (int)((range + li - 1) / li);
+    int li_i = (int)li;
+    args = {&ptrs[0], &ptrs[1], scalar_store, &halo, &goff, &i_begin, &i_end, &li_i};
+    SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(tiles * nch), 1, 1, c.BX, c.BY, 1, 0, stream,
+                                       args.data(), nullptr));
+  } else {
+    for (int b : st.in_bufs) ptrs.push_back(pl.buffers[b].d);
+    ptrs.push_back(pl.buffers[st.out_buf].d);
+    for (auto& p : ptrs) args.push_back(&p);
+    size_t off = 0;
+    for (size_t s = 0; s < st.scalars.size(); ++s) {
+      const Scalar& sc = P.scalars[st.scalars[s]];
+      store_scalar(scalar_store + off, sc.dt, pl.scalar_values[sc.input_index]);
+      args.push_back(scalar_store + off);
+      off += 8;
+    }
+    args.push_back(&n_local);
+    args.push_back(&halo);
+    args.push_back(&goff);
+    args.push_back(&i_begin);
+    args.push_back(&i_end);
+    const long long plane = P.n[1] * P.n[2];
+    const unsigned gx = (unsigned)((plane + 255) / 256);
+    int done = i_begin;
+    while (done < i_end) {  // gridDim.y is limited to 65535
+      int chunk_end = std::min(i_end, done + 65535);
+      int cb = done, ce = chunk_end;
+      args[args.size() - 2] = &cb;
+      args[args.size() - 1] = &ce;
+      SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, gx, (unsigned)(ce - cb), 1, 256, 1, 1, 0, stream,
+                                         args.data(), nullptr));
+      done = chunk_end;
+    }
+  }
+  if (pl.profile) {
+    SF_HIP_CHECK(hipEventRecord(e1, stream));
+    pl.prof_events.push_back({e0, e1});
+    pl.prof_kernel.push_back(st.ck);
+  }
+}
+
+static void collect_profile(sf_plan& pl) {
+  for (size_t i = 0; i < pl.prof_events.size(); ++i) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, pl.prof_events[i].first, pl.prof_events[i].second);
+    pl.kernels[pl.prof_kernel[i]].launches += 1;
+    pl.kernels[pl.prof_kernel[i]].total_ms += ms;
+    (void)hipEventDestroy(pl.prof_events[i].first);
+    (void)hipEventDestroy(pl.prof_events[i].second);
+  }
+  pl.prof_events.clear();
+  pl.prof_kernel.clear();
+}
+
+static void upload(sf_plan& pl, const void* const* host_inputs) {
+  ensure_device(pl);
+  for (int i = 0; i < pl.P.num_inputs; ++i) {
+    if (!host_inputs || !host_inputs[i]) throw Error(SF_ERR_INVALID, "null input array");
+    Buffer& b = pl.buffers[pl.input_buf[i]];
+    if (b.slabbed) {
+      SF_HIP_CHECK(hipMemcpyAsync((char*)b.d + (size_t)pl.halo * b.plane_bytes, host_inputs[i],
+                                  b.plane_bytes * (size_t)pl.n_local, hipMemcpyHostToDevice, pl.stream));
+    } else {
+      SF_HIP_CHECK(hipMemcpyAsync(b.d, host_inputs[i], b.bytes(), hipMemcpyHostToDevice, pl.stream));
+    }
+  }
+  SF_HIP_CHECK(hipStreamSynchronize(pl.stream));
+}
+
+static void download(sf_plan& pl, void* const* host_outputs) {
+  ensure_device(pl);
+  for (int i = 0; i < pl.P.num_outputs; ++i) {
+    if (!host_outputs || !host_outputs[i]) throw Error(SF_ERR_INVALID, "null output array");
+    Buffer& b = pl.buffers[pl.output_buf[i]];
+    if (b.slabbed) {
+      SF_HIP_CHECK(hipMemcpyAsync(host_outputs[i], (char*)b.d + (size_t)pl.halo * b.plane_bytes,
+                                  b.plane_bytes * (size_t)pl.n_local, hipMemcpyDeviceToHost, pl.stream));
+    } else {
+      SF_HIP_CHECK(hipMemcpyAsync(host_outputs[i], b.d, b.bytes(), hipMemcpyDeviceToHost, pl.stream));
+    }
+  }
+  SF_HIP_CHECK(hipStreamSynchronize(pl.stream));
+}
+
+static void execute(sf_plan& pl, int repetitions) {
+  ensure_device(pl);
+  if (repetitions < 0) throw Error(SF_ERR_INVALID, "negative repetition count");
+  for (auto& k : pl.kernels) {
+    k.launches = 0;
+    k.total_ms = 0;
+  }
+  SF_HIP_CHECK(hipEventRecord(pl.ev_begin, pl.stream));
+  for (int r = 0; r < repetitions; ++r)
+    for (auto& st : pl.steps) launch_step(pl, st, 0, pl.stream);
+  SF_HIP_CHECK(hipEventRecord(pl.ev_end, pl.stream));
+  pl.timed = true;
+}
+
+}  // namespace sf
+
+// ---------------------------------------------------------------- C ABI
+#define SF_API_BEGIN try {
+#define SF_API_END                                       \
+  }                                                      \
+  catch (const sf::Error& e) {                           \
+    sf::g_last_error = e.what();                         \
+    return e.status;                                     \
+  }                                                      \
+  catch (const std::exception& e) {                      \
+    sf::g_last_error = e.what();                         \
+    return SF_ERR_INVALID;                               \
+  }                                                      \
+  catch (...) {                                          \
+    sf::g_last_error = "unknown failure";                \
+    return SF_ERR_INVALID;                               \
+  }
+
+extern "C" {
+
+int sf_version(void) { return 1000; }
+
+const char* sf_last_error(void) { return sf::g_last_error.c_str(); }
+
+int sf_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    sf::g_last_error = hipGetErrorString(e);
+    return SF_ERR_DEVICE;
+  }
+  return n;
+}
+
+int sf_plan_create(const char* sfir_text, int device, const char* options, sf_plan** out_plan) {
+  SF_API_BEGIN
+  if (!sfir_text || !out_plan) throw Error(SF_ERR_INVALID, "null argument");
+  std::unique_ptr<sf_plan> pl(new sf_plan);
+  pl->P = parse_sfir(sfir_text);
+  pl->opt = Options(options);
+  pl->device = device;
+  build_plan(*pl);
+  *out_plan = pl.release();
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_plan_destroy(sf_plan* plan) {
+  SF_API_BEGIN
+  if (!plan) return SF_OK;
+  if (plan->device_ready) {
+    (void)hipSetDevice(plan->device);
+    (void)hipStreamSynchronize(plan->stream);
+    collect_profile(*plan);
+    for (auto& b : plan->buffers)
+      if (b.d) (void)hipFree(b.d);
+    for (auto& k : plan->kernels)
+      if (k.mod) (void)hipModuleUnload(k.mod);
+    (void)hipEventDestroy(plan->ev_begin);
+    (void)hipEventDestroy(plan->ev_end);
+    (void)hipStreamDestroy(plan->stream);
+  }
+  delete plan;
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_plan_num_inputs(const sf_plan* p) { return p ? p->P.num_inputs : SF_ERR_INVALID; }
+int sf_plan_num_scalars(const sf_plan* p) { return p ? p->P.num_scalar_inputs : SF_ERR_INVALID; }
+int sf_plan_num_outputs(const sf_plan* p) { return p ? p->P.num_outputs : SF_ERR_INVALID; }
+
+static const char* field_name_by_io(const sf_plan* p, Role role, int index) {
+  if (!p) return nullptr;
+  for (auto& f : p->P.fields)
+    if (f.role == role && f.io_index == index) return f.name.c_str();
+  return nullptr;
+}
+const char* sf_plan_input_name(const sf_plan* p, int i) { return field_name_by_io(p, Role::Input, i); }
+const char* sf_plan_output_name(const sf_plan* p, int i) { return field_name_by_io(p, Role::Output, i); }
+const char* sf_plan_scalar_name(const sf_plan* p, int index) {
+  if (!p) return nullptr;
+  for (auto& s : p->P.scalars)
+    if (!s.is_const && s.input_index == index) return s.name.c_str();
+  return nullptr;
+}
+size_t sf_plan_input_bytes(const sf_plan* p, int i) {
+  if (!p || i < 0 || i >= p->P.num_inputs) return 0;
+  const Buffer& b = p->buffers[p->input_buf[i]];
+  return b.slabbed ? b.plane_bytes * (size_t)p->n_local : b.bytes();
+}
+size_t sf_plan_output_bytes(const sf_plan* p, int i) {
+  if (!p || i < 0 || i >= p->P.num_outputs) return 0;
+  const Buffer& b = p->buffers[p->output_buf[i]];
+  return b.slabbed ? b.plane_bytes * (size_t)p->n_local : b.bytes();
+}
+
+int sf_plan_set_scalars(sf_plan* plan, const double* values, int count) {
+  SF_API_BEGIN
+  if (!plan) throw Error(SF_ERR_INVALID, "null plan");
+  if (count != plan->P.num_scalar_inputs) throw Error(SF_ERR_INVALID, "wrong number of scalar values");
+  for (int i = 0; i < count; ++i) plan->scalar_values[i] = values[i];
+  plan->scalars_set = true;
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_plan_run(sf_plan* plan, const void* const* host_inputs, void* const* host_outputs, int repetitions) {
+  SF_API_BEGIN
+  if (!plan) throw Error(SF_ERR_INVALID, "null plan");
+  upload(*plan, host_inputs);
+  execute(*plan, repetitions);
+  SF_HIP_CHECK(hipStreamSynchronize(plan->stream));
+  collect_profile(*plan);
+  download(*plan, host_outputs);
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_plan_upload(sf_plan* plan, const void* const* host_inputs) {
+  SF_API_BEGIN
+  if (!plan) throw Error(SF_ERR_INVALID, "null plan");
+  upload(*plan, host_inputs);
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_plan_execute(sf_plan* plan, int repetitions) {
+  SF_API_BEGIN
+  if (!plan) throw Error(SF_ERR_INVALID, "null plan");
+  execute(*plan, repetitions);
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_plan_synchronize(sf_plan* plan) {
+  SF_API_BEGIN
+  if (!plan) throw Error(SF_ERR_INVALID, "null plan");
+  ensure_device(*plan);
+  SF_HIP_CHECK(hipStreamSynchronize(plan->stream));
+  collect_profile(*plan);
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_plan_download(sf_plan* plan, void* const* host_outputs) {
+  SF_API_BEGIN
+  if (!plan) throw Error(SF_ERR_INVALID, "null plan");
+  download(*plan, host_outputs);
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_plan_elapsed_ms(sf_plan* plan, double* ms) {
+  SF_API_BEGIN
+  if (!plan || !ms) throw Error(SF_ERR_INVALID, "null argument");
+  if (!plan->timed) throw Error(SF_ERR_STATE, "nothing has been executed yet");
+  float f = 0;
+  SF_HIP_CHECK(hipEventElapsedTime(&f, plan->ev_begin, plan->ev_end));
+  *ms = f;
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_plan_num_launches(const sf_plan* p) { return p ? (int)p->steps.size() : SF_ERR_INVALID; }
+int sf_plan_num_kernels(const sf_plan* p) { return p ? (int)p->kernels.size() : SF_ERR_INVALID; }
+const char* sf_plan_kernel_name(const sf_plan* p, int i) {
+  return (p && i >= 0 && i < (int)p->kernels.size()) ? p->kernels[i].name.c_str() : nullptr;
+}
+const char* sf_plan_kernel_source(const sf_plan* p, int i) {
+  return (p && i >= 0 && i < (int)p->kernels.size()) ? p->kernels[i].source.c_str() : nullptr;
+}
+int sf_plan_kernel_stats(sf_plan* p, int i, int* launches, double* total_ms, double* updates,
+                         double* alg_bytes) {
+  if (!p || i < 0 || i >= (int)p->kernels.size()) return SF_ERR_INVALID;
+  const CompiledKernel& k = p->kernels[i];
+  if (launches) *launches = k.launches;
+  if (total_ms) *total_ms = k.total_ms;
+  if (updates) *updates = k.updates_per_launch;
+  if (alg_bytes) *alg_bytes = k.alg_bytes_per_launch;
+  return SF_OK;
+}
+const char* sf_plan_describe(const sf_plan* p) { return p ? p->description.c_str() : nullptr; }
+
+int sf_plan_num_steps(const sf_plan* p) { return p ? (int)p->steps.size() : SF_ERR_INVALID; }
+int sf_plan_step_halo(const sf_plan* p, int step, int* buffer_id, int* depth) {
+  if (!p || step < 0 || step >= (int)p->steps.size()) return SF_ERR_INVALID;
+  if (buffer_id) *buffer_id = p->steps[step].halo_buf;
+  if (depth) *depth = p->steps[step].halo_buf >= 0 ? p->steps[step].halo_depth : 0;
+  return SF_OK;
+}
+int sf_plan_execute_step(sf_plan* plan, int step, int part, void* stream) {
+  SF_API_BEGIN
+  if (!plan || step < 0 || step >= (int)plan->steps.size() || part < 0 || part > 3)
+    throw Error(SF_ERR_INVALID, "bad step or part");
+  ensure_device(*plan);
+  launch_step(*plan, plan->steps[step], part, stream ? (hipStream_t)stream : plan->stream);
+  return SF_OK;
+  SF_API_END
+}
+int sf_plan_buffer_info(const sf_plan* p, int id, void** device_ptr, size_t* plane_bytes, int* planes) {
+  SF_API_BEGIN
+  if (!p || id < 0 || id >= (int)p->buffers.size()) throw Error(SF_ERR_INVALID, "bad buffer id");
+  ensure_device(*const_cast<sf_plan*>(p));
+  if (device_ptr) *device_ptr = p->buffers[id].d;
+  if (plane_bytes) *plane_bytes = p->buffers[id].plane_bytes;
+  if (planes) *planes = p->buffers[id].planes;
+  return SF_OK;
+  SF_API_END
+}
+int sf_plan_input_buffer(const sf_plan* p, int i) {
+  return (p && i >= 0 && i < p->P.num_inputs) ? p->input_buf[i] : SF_ERR_INVALID;
+}
+int sf_plan_output_buffer(const sf_plan* p, int i) {
+  return (p && i >= 0 && i < p->P.num_outputs) ? p->output_buf[i] : SF_ERR_INVALID;
+}
+
+}  // extern "C"

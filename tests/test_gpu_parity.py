@@ -1,0 +1,272 @@
+"""Parity of the HIP backend against the oracle (-m gpu; calls go through the
+C ABI of libsf_hip.so).  Floating point contract: results are produced by the
+same typed expression in the same order as the oracle, so they are required to
+be bit-identical for + - * / programs, and within 1e-6 relative (BASELINE.json)
+where device math functions are involved."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import stencilflow_amd as sf
+from stencilflow_amd import programs
+from stencilflow_amd.backend import CompiledProgram
+from oracle import numpy_oracle as npo
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20261003
+
+
+def _write(tmp_path, prog, name="prog"):
+    return programs.write_program(prog, str(tmp_path / (name + ".json")))
+
+
+def _run_gpu(path, inputs, options=None):
+    chain = sf.KernelChainGraph(path)
+    prog = CompiledProgram(chain, options=options)
+    outs = {
+        name: np.zeros(chain.dimensions[3 - chain.kernel_dimensions:],
+                       dtype=chain.program[name]["data_type"].type)
+        for name in chain.outputs
+    }
+    kwargs = {}
+    for name, desc in chain.inputs.items():
+        val = inputs[name]
+        if len(desc["input_dims"]) == 0:
+            kwargs[name] = val
+        else:
+            kwargs[name + "_host"] = np.ascontiguousarray(val)
+    for name, arr in outs.items():
+        kwargs[name + "_host"] = arr
+    prog(**kwargs)
+    desc = prog.plan.describe()
+    prog.close()
+    return outs, desc
+
+
+def _inputs_of(path, programs_dir=None, rng=None):
+    prog = npo.load_program(path)
+    vals = {}
+    for name in prog["inputs"]:
+        override = None
+        dims = npo._input_dims(prog, name)
+        if rng is not None and dims:
+            shape = npo._dims_shape(prog, dims)
+            override = rng.uniform(-1, 1, shape).astype(
+                npo._NP[prog["inputs"][name]["data_type"]])
+        vals[name] = npo.materialise_input(prog, name, programs_dir, override)
+    return vals
+
+
+FIXTURES = [
+    "jacobi2d_128x128", "jacobi2d_128x128_8vec", "jacobi3d_32x32x32",
+    "jacobi3d_32x32x32_8itr", "jacobi3d_32x32x32_8itr_4vec",
+    "jacobi3d_32x32x32_8itr_8vec", "simulator", "simulator2", "simulator3",
+    "simulator4", "simulator5", "simulator6", "simulator7", "simulator8",
+    "simulator9", "simulator10", "simulator11", "simulator12",
+    "varying_dimensionality"
+]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_reference_test_programs(programs_dir, name):
+    """Every program of the reference's own test-suite
+    (test/test_stencilflow.py:188-224), inputs as the files specify."""
+    path = os.path.join(programs_dir, name + ".json")
+    ins = _inputs_of(path, programs_dir)
+    want = npo.run_reference(path, inputs=ins)
+    got, _ = _run_gpu(path, ins)
+    for k in want:
+        assert got[k].dtype == want[k].dtype
+        assert np.array_equal(got[k], want[k]), (name, k,
+                                                 npo.max_rel_err(want[k], got[k]))
+
+
+@pytest.mark.parametrize("name", [
+    "jacobi2d_128x128", "jacobi3d_32x32x32_8itr_8vec", "simulator7",
+    "simulator10", "varying_dimensionality"
+])
+def test_reference_test_programs_random_inputs(programs_dir, name):
+    path = os.path.join(programs_dir, name + ".json")
+    ins = _inputs_of(path, programs_dir, np.random.default_rng(SEED))
+    want = npo.run_reference(path, inputs=ins)
+    got, _ = _run_gpu(path, ins)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), (name, k)
+
+
+def test_run_program_driver_compare_to_reference(programs_dir, tmp_path,
+                                                 monkeypatch):
+    """The README call: run_program(<json>, mode, compare_to_reference=True)
+    returns 0 and writes results/<name>/[reference/]<out>.dat."""
+    from stencilflow_amd.run_program import run_program
+    monkeypatch.chdir(tmp_path)
+    path = os.path.join(programs_dir, "jacobi3d_32x32x32_8itr_8vec.json")
+    ret = run_program(path, "emulation", compare_to_reference=True,
+                      input_directory=programs_dir,
+                      log_level=sf.LogLevel.NO_LOG)
+    assert ret == 0
+    out = np.fromfile(tmp_path / "results" / "jacobi3d_32x32x32_8itr_8vec" /
+                      "b7.dat", np.float32)
+    ref = np.fromfile(tmp_path / "results" / "jacobi3d_32x32x32_8itr_8vec" /
+                      "reference" / "b7.dat", np.float32)
+    assert out.size == 32**3 and np.array_equal(out, ref)
+
+
+SHAPES_3D = [(32, 32, 32), (20, 44, 64), (17, 9, 12), (40, 70, 260),
+             (9, 30, 512), (6, 5, 520)]
+
+
+@pytest.mark.parametrize("shape", SHAPES_3D)
+@pytest.mark.parametrize("fuse", [1, 2, 3])
+def test_jacobi3d_chain_random(tmp_path, shape, fuse):
+    """Fused star kernel vs oracle: ragged sizes (tiles wider than the domain,
+    k-tiled rows, partial j tiles, chunked i) and every fusion depth."""
+    stages = 5
+    rng = np.random.default_rng(SEED)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    prog = programs.jacobi3d(shape, stages, bc_value=0.25)
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, {"a": x})["b%d" % (stages - 1)]
+    got, desc = _run_gpu(path, {"a": x}, options={"fuse": fuse})
+    assert "star" in desc
+    assert np.array_equal(got["b%d" % (stages - 1)], want), npo.max_rel_err(
+        want, got["b%d" % (stages - 1)])
+
+
+@pytest.mark.parametrize("options", [
+    {"fuse": 2, "k1.rj": 2, "k1.by": 4},
+    {"fuse": 2, "k1.rj": 3, "k1.by": 8},
+    {"fuse": 2, "k1.bx": 64, "k1.by": 4, "k1.rj": 4},
+    {"fuse": 2, "k1.li": 7},
+    {"fuse": 4, "k1.rj": 2, "k1.by": 8},
+    {"generic_only": 1},
+])
+def test_jacobi3d_tile_shapes(tmp_path, options):
+    shape, stages = (37, 50, 136), 4
+    rng = np.random.default_rng(SEED + 1)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    prog = programs.jacobi3d(shape, stages)
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, {"a": x})["b3"]
+    got, _ = _run_gpu(path, {"a": x}, options=options)
+    assert np.array_equal(got["b3"], want)
+
+
+def test_integer_bc_literal_f32_accumulation(tmp_path):
+    shape = (16, 24, 64)
+    rng = np.random.default_rng(SEED + 2)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    prog = programs.jacobi3d(shape, 3, bc_value=0,
+                             coefficient="0.16666666666666666")
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, {"a": x})["b2"]
+    got, _ = _run_gpu(path, {"a": x})
+    assert np.array_equal(got["b2"], want)
+
+
+@pytest.mark.parametrize("shape", [(128, 128), (40, 264), (333, 36), (64, 1024)])
+@pytest.mark.parametrize("fuse", [1, 2, 4])
+def test_jacobi2d_chain_random(tmp_path, shape, fuse):
+    stages = 6
+    rng = np.random.default_rng(SEED + 3)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    prog = programs.jacobi2d(shape, stages, bc_value=1.0)
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, {"a": x})["b5"]
+    got, desc = _run_gpu(path, {"a": x}, options={"fuse": fuse})
+    assert "star" in desc
+    assert np.array_equal(got["b5"], want)
+
+
+@pytest.mark.parametrize("fuse", [1, 3])
+def test_three_operator_chain_f64(tmp_path, fuse):
+    """C5 at a size the oracle finishes quickly: diffusion -> advection ->
+    laplacian, float64, scalar coefficient inputs."""
+    shape = (24, 40, 136)
+    rng = np.random.default_rng(SEED + 4)
+    prog = programs.diffusion_advection_laplacian(shape)
+    x = rng.uniform(-1, 1, shape)
+    ins = _inputs_of(prog)
+    ins["a"] = x
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, inputs=ins)["lap"]
+    got, desc = _run_gpu(path, ins, options={"fuse": fuse})
+    assert np.array_equal(got["lap"], want)
+    if fuse == 3:
+        assert desc.count("launch") == 1 and "T=3" in desc
+
+
+def test_shrink_boundary(tmp_path):
+    shape = (12, 16, 32)
+    rng = np.random.default_rng(SEED + 5)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    prog = programs.jacobi3d(shape, 2)
+    for k in prog["program"].values():
+        for bc in k["boundary_conditions"].values():
+            bc["type"] = "shrink"
+            del bc["value"]
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, {"a": x})["b1"]
+    got, _ = _run_gpu(path, {"a": x})
+    assert np.array_equal(got["b1"], want)
+    h = 2  # outside the shrink halo the junk never arrives
+    inner = tuple(slice(h, -h) for _ in shape)
+    assert np.abs(got["b1"][inner]).max() <= 1.0
+
+
+def test_math_calls_within_tolerance(tmp_path):
+    prog = {
+        "inputs": {"a": {"data": "constant:1.0", "data_type": "float32"}},
+        "outputs": ["c"],
+        "dimensions": [8, 16, 32],
+        "program": {
+            "b": {
+                "computation_string":
+                "b = sin(a[i,j,k]) * cos(a[i,j,k+1]) + sqrt(fabs(a[i-1,j,k]))",
+                "boundary_conditions": {"a": {"type": "constant", "value": 0.5}},
+                "data_type": "float32"
+            },
+            "c": {
+                "computation_string":
+                "t = max(b[i,j,k], b[i,j-1,k]); c = t if t > 0.3 else min(t, 0.1) - exp(b[i,j,k])",
+                "boundary_conditions": {"b": {"type": "constant", "value": 0.0}},
+                "data_type": "float32"
+            }
+        }
+    }
+    rng = np.random.default_rng(SEED + 6)
+    x = rng.uniform(-1, 1, (8, 16, 32)).astype(np.float32)
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, {"a": x})["c"]
+    got, _ = _run_gpu(path, {"a": x})
+    assert npo.arrays_match(want, got["c"], 1e-6)  # tolerance: BASELINE.json
+
+
+def test_full_size_properties():
+    """BASELINE size (512^3, f32): properties that do not need the oracle to run
+    the whole chain -- fused == unfused bit for bit, 8-fold symmetry, range --
+    plus a direct oracle check of the first two stages."""
+    n, stages = 512, 6
+    prog = programs.jacobi3d((n, n, n), stages)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = programs.write_program(prog, os.path.join(tmp, "big.json"))
+        x = np.ones((n, n, n), np.float32)
+        fused, _ = _run_gpu(path, {"a": x}, options={"fuse": 2})
+        unfused, _ = _run_gpu(path, {"a": x}, options={"fuse": 1})
+    out = fused["b5"]
+    assert np.array_equal(out, unfused["b5"])
+    assert np.array_equal(out, out[::-1]) and np.array_equal(out, out[:, ::-1])
+    assert np.array_equal(out, out[:, :, ::-1])
+    assert np.array_equal(out, out.transpose(1, 0, 2))
+    assert 0.0 <= out.min() and out.max() <= 1.0
+    # corner block against the oracle on a sub-domain whose far faces are
+    # > `stages` cells away from the compared region
+    m = 40
+    small = programs.jacobi3d((m, m, m), stages)
+    ref = npo.run_reference(small, {"a": np.ones((m, m, m), np.float32)})["b5"]
+    c = m - stages - 1
+    assert np.array_equal(out[:c, :c, :c], ref[:c, :c, :c])
