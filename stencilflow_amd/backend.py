@@ -84,6 +84,16 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 /
+    # libhiprtc (same sonames as /opt/rocm's).  If torch is going to be used in
+    # this process (device streams, torch.distributed), its copy must be the one
+    # that is loaded first, otherwise two runtimes coexist and the second sees
+    # no GPU.  libsf_hip.so binds by soname and so shares whichever is resident.
+    if os.environ.get("SF_HIP_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.isfile(_LIB_PATH):
         raise RuntimeError(
             "{} is missing: build it with `python -m stencilflow_amd.csrc.build`"

@@ -154,7 +154,8 @@ __device__ __forceinline__ void sf_later_stages(
 extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc,
                    int halo, int goff, int i_begin, int i_end, int li) {
-  __shared__ sf_t lds[SF_ROWS_ELEMS + SF_EDGE_ELEMS];
+  // SF_LDS_DB: two exchange images used alternately -> one barrier per step
+  __shared__ sf_t lds_all[(SF_LDS_DB ? 2 : 1) * (SF_ROWS_ELEMS + SF_EDGE_ELEMS)];
 
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int lane = tx & 63, wave = tx >> 6;
@@ -219,7 +220,10 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   sf_vec pre[SF_RJ];
   load_plane(cb - SF_T, pre);
 
+  int parity = 0;
   for (int p = cb - SF_T; p < ce + SF_T; ++p) {
+    sf_t* lds = lds_all + (SF_LDS_DB ? parity * (SF_ROWS_ELEMS + SF_EDGE_ELEMS) : 0);
+    parity ^= 1;
     // publish the rows / columns other threads need of every stage's current plane
 #pragma unroll
     for (int s = 0; s < SF_T; ++s) {
@@ -250,6 +254,6 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     if (p + 1 < ce + SF_T) load_plane(p + 1, pre);
     sf_later_stages<2>(st, fresh, lds, sc, out, tx, ty, lane, wave, jmask, kmask, store_mask, p,
                        goff, halo, cb, ce, j0, k0);
-    if (SF_USE_LDS) __syncthreads();
+    if (SF_USE_LDS && !SF_LDS_DB) __syncthreads();
   }
 }

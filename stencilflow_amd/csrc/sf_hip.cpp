@@ -153,62 +153,42 @@ static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::stri
 // ---------------------------------------------------------------- planner
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-static size_t star_lds_bytes(const StarCfg& c, DT dt);
+static size_t star_lds_bytes(const StarCfg& c, DT dt) {
+  const size_t rows = c.noj ? 0 : (size_t)c.T * c.BY * 2 * c.BX * c.VK;
+  const size_t edge = (size_t)c.T * c.BY * c.RJ * (c.BX / 64) * 2;
+  return (rows + edge) * size_of(dt) * (c.lds_db ? 2 : 1);
+}
 
-static StarCfg choose_star_cfg(const sf_plan& pl, int T, DT dt) {
-  const Program& P = pl.P;
-  StarCfg c;
-  c.T = T;
-  c.VK = 4;
-  c.n0g = P.n[0];
-  c.n1 = P.n[1];
-  c.n2 = P.n[2];
-  c.noj = (P.n[1] == 1);
-  c.row_fence = (int)pl.opt.get("k1.fence", 1);
-  const int hk = round_up(T, c.VK);
-  if (c.noj) {
-    c.RJ = 1;
-    c.BY = 1;
-    c.BX = (int)pl.opt.get("k2.bx", 64);
-  } else {
-    c.RJ = (int)pl.opt.get("k1.rj", 4);
-    long long bx = pl.opt.get("k1.bx", 0);
-    if (bx == 0) {
-      // widest tile that wastes the fewest lanes on k halo / padding
-      double best = -1;
-      for (int cand : {64, 128}) {
-        const long long tkh = (long long)cand * c.VK;
-        double eff;
-        if (tkh == P.n[2]) {
-          eff = 1.0;
-        } else {
-          const long long tki = tkh - 2 * hk;
-          const long long nkt = (P.n[2] + tki - 1) / tki;
-          eff = (double)P.n[2] / (double)(nkt * tkh);
-        }
-        if (eff > best + 1e-9) {
-          best = eff;
-          bx = cand;
-        }
-      }
-    }
-    c.BX = (int)bx;
-    long long by = pl.opt.get("k1.by", 0);
-    if (by == 0) {
-      const int max_by = 1024 / c.BX;
-      // enough rows for the whole column, but no more than the block limit
-      const long long want = (P.n[1] + 2 * T + c.RJ - 1) / c.RJ;
-      by = std::max<long long>(2, std::min<long long>(max_by, want));
-      // keep the exchange image within LDS (and leave room for a second block)
-      c.BY = (int)by;
-      while (c.BY > 2 && star_lds_bytes(c, dt) > 96 * 1024 && (c.BY - 1) * c.RJ - 2 * T >= 1) --c.BY;
-      by = c.BY;
-    }
-    c.BY = (int)by;
-  }
-  if (c.BX % 64 != 0 || c.BX * c.BY > 1024 || c.BX < 64)
-    throw Error(SF_ERR_INVALID, "star kernel: block shape must be a multiple of 64 lanes and <= 1024 threads");
+// ---- launch-geometry model ------------------------------------------------------
+// Measured on MI355X (profiles/r01_sweep_*.log): for a given fused depth the raw
+// update rate of the star kernel is nearly independent of the tile shape; what
+// separates configurations is (a) redundant halo work in j / k / along the
+// stream axis and (b) how evenly the blocks fill the 256 CUs.  The planner
+// therefore minimises
+//   cost = (tile rows / interior rows) * (tile cols / interior cols)
+//          * (chunk planes + 2T) / chunk planes * (block slots used / blocks)
+// over the tile shapes whose register footprint fits without spilling.
+static int star_regs_estimate(const StarCfg& c, DT dt) {
+  const int words = (dt == DT::F64) ? 2 : 1;
+  const int P = c.RJ * c.VK;
+  return 3 * c.T * P * words + 60 + (words - 1) * 20;
+}
+
+static int star_blocks_per_cu(const StarCfg& c, DT dt) {
+  const int threads = c.BX * c.BY;
+  const int waves_per_simd = (threads + 255) / 256;  // a block's waves on one SIMD
+  const int regs = star_regs_estimate(c, dt);
+  const int alloc = (regs + 7) / 8 * 8;
+  const int by_regs = (512 / alloc) / waves_per_simd;
+  const size_t lds = std::max<size_t>(star_lds_bytes(c, dt), 1);
+  const int by_lds = (int)(160 * 1024 / lds);
+  const int by_waves = 32 / ((threads + 63) / 64);
+  return std::max(0, std::min(std::min(by_regs, by_lds), std::min(by_waves, 8)));
+}
+
+static void star_finish_cfg(StarCfg& c, const Program& P, int T) {
   const long long tkh = (long long)c.BX * c.VK;
+  const int hk = round_up(T, c.VK);
   c.ktiled = (tkh != P.n[2]);
   c.HK = c.ktiled ? hk : 0;
   c.NKT = c.ktiled ? (int)((P.n[2] + (tkh - 2 * c.HK) - 1) / (tkh - 2 * c.HK)) : 1;
@@ -219,13 +199,86 @@ static StarCfg choose_star_cfg(const sf_plan& pl, int T, DT dt) {
     if (tji < 1) throw Error(SF_ERR_INVALID, "star kernel: tile has no interior rows (raise k1.by / k1.rj)");
     c.NJT = (int)((P.n[1] + tji - 1) / tji);
   }
-  return c;
 }
 
-static size_t star_lds_bytes(const StarCfg& c, DT dt) {
-  const size_t rows = c.noj ? 0 : (size_t)c.T * c.BY * 2 * c.BX * c.VK;
-  const size_t edge = (size_t)c.T * c.BY * c.RJ * (c.BX / 64) * 2;
-  return (rows + edge) * size_of(dt);
+// chunk length along the stream axis for `range` planes: whole block waves
+static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_out = nullptr) {
+  const int tiles = c.NJT * c.NKT;
+  const int slots = 256 * std::max(1, star_blocks_per_cu(c, dt));
+  double best = 1e30;
+  int best_li = range;
+  const int max_nch = std::max(1, range / std::max(1, 2 * c.T));
+  for (int nch = 1; nch <= std::min(max_nch, 4096); ++nch) {
+    const int li = (range + nch - 1) / nch;
+    const int real_nch = (range + li - 1) / li;
+    const long long blocks = (long long)tiles * real_nch;
+    const long long rounds = (blocks + slots - 1) / slots;
+    const double quant = (double)(rounds * slots) / (double)blocks;
+    const double warm = (double)(li + 2 * c.T) / (double)li;
+    // more rounds amortise the tail when block times differ
+    const double cost = warm * quant * (1.0 + 0.02 / (double)rounds);
+    if (cost < best - 1e-12) {
+      best = cost;
+      best_li = li;
+    }
+    if (blocks > 64LL * slots) break;
+  }
+  if (cost_out) *cost_out = best;
+  return best_li;
+}
+
+static StarCfg choose_star_cfg(const sf_plan& pl, int T, DT dt) {
+  const Program& P = pl.P;
+  StarCfg base;
+  base.T = T;
+  base.VK = 4;
+  base.n0g = P.n[0];
+  base.n1 = P.n[1];
+  base.n2 = P.n[2];
+  base.noj = (P.n[1] == 1);
+  base.row_fence = (int)pl.opt.get("k1.fence", 1);
+  base.lds_db = (int)pl.opt.get("k1.db", 1);
+  const std::string pfx = base.noj ? "k2." : "k1.";
+  const long long pin_bx = pl.opt.get(pfx + "bx", 0);
+  const long long pin_by = base.noj ? 1 : pl.opt.get("k1.by", 0);
+  const long long pin_rj = base.noj ? 1 : pl.opt.get("k1.rj", 0);
+  const int range = (int)pl.n_local;
+
+  double best_cost = 1e30;
+  StarCfg best = base;
+  bool found = false;
+  for (int bx : {64, 128, 256}) {
+    if (pin_bx && bx != pin_bx) continue;
+    for (int rj = 1; rj <= 8; ++rj) {
+      if (pin_rj && rj != pin_rj) continue;
+      for (int by = 1; by <= 16; ++by) {
+        if (pin_by && by != pin_by) continue;
+        if (bx * by > 1024) continue;
+        StarCfg c = base;
+        c.BX = bx;
+        c.RJ = rj;
+        c.BY = by;
+        if (!c.noj && by * rj - 2 * T < 1) continue;
+        star_finish_cfg(c, P, T);
+        if (star_lds_bytes(c, dt) > 160 * 1024) continue;
+        const bool pinned = pin_bx && pin_by && pin_rj;
+        if (!pinned && star_blocks_per_cu(c, dt) < 1) continue;  // would spill
+        double chunk_cost = 1.0;
+        star_chunk_planes(c, dt, range, &chunk_cost);
+        const double jcost = c.noj ? 1.0 : (double)c.NJT * c.BY * c.RJ / (double)P.n[1];
+        const double kcost = (double)c.NKT * c.BX * c.VK / (double)P.n[2];
+        // ties go to the larger block (fewer barriers per point)
+        const double cost = jcost * kcost * chunk_cost * (1.0 + 1e-4 / (double)(c.BX * c.BY * c.RJ));
+        if (cost < best_cost - 1e-12) {
+          best_cost = cost;
+          best = c;
+          found = true;
+        }
+      }
+    }
+  }
+  if (!found) throw Error(SF_ERR_INVALID, "star kernel: no tile shape satisfies the given k1.* options");
+  return best;
 }
 
 static void build_plan(sf_plan& pl) {
@@ -425,6 +478,7 @@ static void build_plan(sf_plan& pl) {
     ck.updates_per_launch = cells * (double)st.kernels.size();
     ck.alg_bytes_per_launch = 0;
     for (int k : st.kernels) ck.alg_bytes_per_launch += cells * 2.0 * (double)size_of(P.kernels[k].dt);
+    if (desc.tellp() > 16384) continue;  // long chains: describe the first launches only
     desc << "  launch " << ck.name << ": ";
     for (int k : st.kernels) desc << P.kernels[k].name << " ";
     if (st.star)
@@ -436,7 +490,6 @@ static void build_plan(sf_plan& pl) {
     desc << " in";
     for (int b : st.in_bufs) desc << " b" << b;
     desc << " out b" << st.out_buf << "\n";
-    if (desc.tellp() > 16384) break;
   }
   pl.description = desc.str();
   pl.scalar_values.assign(P.num_scalar_inputs, 0.0);
@@ -511,20 +564,11 @@ static void launch_step(sf_plan& pl, const Step& st, int part, hipStream_t strea
       const Scalar& sc = P.scalars[st.scalars[s]];
       store_scalar(scalar_store + st.scalar_offsets[s], sc.dt, pl.scalar_values[sc.input_index]);
     }
-    // chunking of the stream axis: aim at a whole number of block waves
+    // chunking of the stream axis: whole block waves (star_chunk_planes)
     const int range = i_end - i_begin;
     const int tiles = c.NJT * c.NKT;
-    int occ = std::max(1, std::min(8, 2048 / (c.BX * c.BY)));
-    const size_t lds = star_lds_bytes(c, P.kernels[st.kernels[0]].dt);
-    if (lds > 0) occ = std::max(1, std::min<int>(occ, (int)(160 * 1024 / std::max<size_t>(lds, 1))));
     long long li = pl.opt.get(c.noj ? "k2.li" : "k1.li", 0);
-    if (li <= 0) {
-      const int target = 256 * occ;
-      int nch = std::max(1, (target + tiles / 2) / tiles);
-      li = (range + nch - 1) / nch;
-      const int min_li = std::min(range, 8 * c.T);
-      if (li < min_li) li = min_li;
-    }
+    if (li <= 0) li = star_chunk_planes(c, P.kernels[st.kernels[0]].dt, range);
     if (li > range) li = range;
     const int nch = (int)((range + li - 1) / li);
     int li_i = (int)li;

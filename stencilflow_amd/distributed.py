@@ -1,0 +1,275 @@
+"""Slab decomposition of a stencil chain over the GPUs of one node.
+
+The reference has no domain decomposition (it splits the *operator chain*
+across FPGAs, stencilflow/sdfg_generator.py:782-1000, with SMI streams and MPI
+barriers, bin/run_distributed_program.py:98-100,283-299).  On MI355X the grid
+itself is split: rank ``p`` owns planes ``[lo, hi)`` of the outermost dimension
+plus ``halo`` ghost planes on each side (contiguous ``N_j x N_k`` blocks in C
+order).  Before a launch that reads ``d`` planes across the slab boundary, the
+``d`` owned planes next to each boundary are sent to the neighbour
+(``isend``/``irecv`` pairs = RCCL ``ncclSend``/``ncclRecv`` over one xGMI link per
+direction) while the launch's interior planes are already being computed; the
+boundary planes follow once the halos have landed.  Ranks at the global
+boundary receive nothing there: the kernels apply the boundary constant by
+*global* coordinate.  No collective is needed on the data path.
+
+``SlabRunner`` drives one rank's ``sf_plan`` (created with the option
+``slab=<lo>:<hi>:<halo>``) step by step through the C ABI; the exchange itself
+is delegated to an *exchanger*:
+
+* ``TorchDistExchanger(staging="device")`` -- ``torch.distributed`` P2P on
+  tensors aliasing the plan's device buffers (backend ``nccl`` = RCCL);
+* ``TorchDistExchanger(staging="host")``   -- the same protocol staged through
+  host memory (works with ``gloo``; used to test the multi-rank path on a
+  single GPU and on CPU tensors);
+* ``LocalExchanger`` -- ranks living in one process (tests).
+"""
+
+import numpy as np
+
+from .backend import Plan
+
+
+def slab_bounds(n0, rank, world):
+    """Planes ``[lo, hi)`` of the outermost dimension owned by ``rank``."""
+    return (n0 * rank) // world, (n0 * (rank + 1)) // world
+
+
+class _DeviceMemory:
+    """Exposes a raw device allocation through ``__cuda_array_interface__`` so
+    torch can alias it (no copy, no ownership)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {
+            "shape": (int(nbytes), ),
+            "typestr": "|u1",
+            "data": (int(ptr), False),
+            "version": 2,
+        }
+
+
+def alias_device_buffer(ptr, nbytes, device):
+    import torch
+    return torch.as_tensor(_DeviceMemory(ptr, nbytes),
+                           device=torch.device("cuda", device))
+
+
+def halo_regions(n_local, halo, depth, plane_bytes):
+    """Byte ranges (offset, size) inside a slab buffer of
+    ``n_local + 2*halo`` planes:
+    send_down / send_up = owned planes adjacent to the lower / upper boundary,
+    recv_down / recv_up = ghost planes filled by the lower / upper neighbour."""
+    d = depth * plane_bytes
+    return {
+        "send_down": (halo * plane_bytes, d),
+        "send_up": ((halo + n_local - depth) * plane_bytes, d),
+        "recv_down": ((halo - depth) * plane_bytes, d),
+        "recv_up": ((halo + n_local) * plane_bytes, d),
+    }
+
+
+class TorchDistExchanger:
+    """Neighbour exchange over ``torch.distributed`` point-to-point ops."""
+
+    def __init__(self, rank, world, group=None, staging="device"):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world, self.group = rank, world, group
+        self.staging = staging
+        self._host = {}
+
+    def _ops(self, buf, regions, as_tensor):
+        dist = self.dist
+        ops = []
+        lo_peer, hi_peer = self.rank - 1, self.rank + 1
+        # post receives first, then sends; one pair per neighbour
+        if lo_peer >= 0:
+            ops.append(dist.P2POp(dist.irecv, as_tensor("recv_down"), lo_peer,
+                                  self.group))
+        if hi_peer < self.world:
+            ops.append(dist.P2POp(dist.irecv, as_tensor("recv_up"), hi_peer,
+                                  self.group))
+        if lo_peer >= 0:
+            ops.append(dist.P2POp(dist.isend, as_tensor("send_down"), lo_peer,
+                                  self.group))
+        if hi_peer < self.world:
+            ops.append(dist.P2POp(dist.isend, as_tensor("send_up"), hi_peer,
+                                  self.group))
+        return ops
+
+    def start(self, tensor, regions, key=None):
+        """Begin exchanging the halo regions of the flat byte tensor ``tensor``
+        (device tensor aliasing a plan buffer, or a CPU tensor).  Returns a
+        handle for ``finish``."""
+        import torch
+        if self.world == 1:
+            return None
+        if self.staging == "device" or not tensor.is_cuda:
+            def view(name):
+                off, size = regions[name]
+                return tensor[off:off + size]
+            works = self.dist.batch_isend_irecv(self._ops(tensor, regions, view))
+            return ("direct", works, None)
+        # host staging: device -> pinned host -> gloo -> device
+        stage = {}
+        for name, (off, size) in regions.items():
+            k = (key, name, size)
+            if k not in self._host:
+                self._host[k] = torch.empty(size, dtype=torch.uint8).pin_memory()
+            stage[name] = self._host[k]
+        torch.cuda.current_stream().synchronize()
+        for name in ("send_down", "send_up"):
+            off, size = regions[name]
+            stage[name].copy_(tensor[off:off + size])
+        works = self.dist.batch_isend_irecv(
+            self._ops(tensor, regions, lambda name: stage[name]))
+        return ("host", works, (tensor, regions, stage))
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        kind, works, extra = handle
+        for w in works:
+            w.wait()
+        if kind == "host":
+            tensor, regions, stage = extra
+            if self.rank - 1 >= 0:
+                off, size = regions["recv_down"]
+                tensor[off:off + size].copy_(stage["recv_down"])
+            if self.rank + 1 < self.world:
+                off, size = regions["recv_up"]
+                tensor[off:off + size].copy_(stage["recv_up"])
+
+
+class LocalExchanger:
+    """All ranks in one process: ``finish`` of the last rank to arrive performs
+    the copies for everyone (tests; ranks must be stepped in lockstep)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.pending = {}
+
+    def for_rank(self, rank):
+        parent = self
+
+        class _View:
+            def start(self, tensor, regions, key=None):
+                parent.pending[rank] = (tensor, regions)
+                return rank
+
+            def finish(self, handle):
+                if len(parent.pending) < parent.world:
+                    return
+                import torch
+                torch.cuda.synchronize()
+                p = parent.pending
+                for r in range(parent.world - 1):
+                    lo_t, lo_r = p[r]
+                    hi_t, hi_r = p[r + 1]
+                    so, ss = lo_r["send_up"]
+                    ro, rs = hi_r["recv_down"]
+                    hi_t[ro:ro + rs].copy_(lo_t[so:so + ss])
+                    so, ss = hi_r["send_down"]
+                    ro, rs = lo_r["recv_up"]
+                    lo_t[ro:ro + rs].copy_(hi_t[so:so + ss])
+                torch.cuda.synchronize()
+                parent.pending = {}
+
+        return _View()
+
+
+def run_lockstep(runners):
+    """Execute one chain on several in-process ranks (``LocalExchanger``)."""
+    for s in range(len(runners[0].steps)):
+        handles = [r.step_begin(s) for r in runners]
+        for r, h in zip(runners, handles):
+            r.step_end(s, h)
+    for r in runners:
+        r.synchronize()
+
+
+class SlabRunner:
+    """One rank of a slab-decomposed chain execution."""
+
+    def __init__(self, sfir_text, global_shape, rank, world, device=0,
+                 options=None, exchanger=None, halo=None, overlap=True):
+        import torch
+        self.torch = torch
+        self.rank, self.world, self.device = rank, world, device
+        options = dict(options or {})
+        fuse = int(options.get("fuse", 2))
+        self.halo = int(halo if halo is not None else max(1, fuse))
+        self.lo, self.hi = slab_bounds(global_shape[0], rank, world)
+        self.n_local = self.hi - self.lo
+        if world > 1 and self.n_local < 2 * self.halo:
+            raise ValueError("slab of {} planes is thinner than two halos".
+                             format(self.n_local))
+        self.local_shape = (self.n_local, ) + tuple(global_shape[1:])
+        if world > 1:
+            options["slab"] = "{}:{}:{}".format(self.lo, self.hi, self.halo)
+        self.plan = Plan(sfir_text, device=device, options=options)
+        self.exchanger = exchanger
+        if self.exchanger is None and world > 1:
+            self.exchanger = TorchDistExchanger(rank, world)
+        self.overlap = overlap
+        self.stream = torch.cuda.Stream(device=device)
+        self._tensors = {}
+        self.steps = [self.plan.step_halo(s) for s in range(self.plan.num_steps)]
+
+    def _buffer_tensor(self, buf):
+        if buf not in self._tensors:
+            ptr, plane_bytes, planes = self.plan.buffer_info(buf)
+            t = alias_device_buffer(ptr, plane_bytes * planes, self.device)
+            self._tensors[buf] = (t, plane_bytes, planes)
+        return self._tensors[buf]
+
+    def upload(self, local_inputs):
+        self.plan.upload([np.ascontiguousarray(a) for a in local_inputs])
+
+    def download(self, local_outputs):
+        self.plan.download(local_outputs)
+
+    def step_begin(self, s):
+        """Start the halo exchange step ``s`` needs (if any) and launch the part
+        of the step that does not depend on it."""
+        torch = self.torch
+        raw = self.stream.cuda_stream
+        buf, depth = self.steps[s]
+        with torch.cuda.stream(self.stream):
+            if self.world == 1 or depth == 0 or buf < 0:
+                self.plan.execute_step(s, 0, raw)
+                return None
+            tensor, plane_bytes, _ = self._buffer_tensor(buf)
+            regions = halo_regions(self.n_local, self.halo, depth, plane_bytes)
+            # the transfer waits for everything queued so far (the planes it
+            # sends were produced by the previous launch) ...
+            handle = self.exchanger.start(tensor, regions, key=buf)
+            if self.overlap:
+                # ... and runs beside the interior of this launch
+                self.plan.execute_step(s, 3, raw)
+            return handle
+
+    def step_end(self, s, handle):
+        torch = self.torch
+        raw = self.stream.cuda_stream
+        buf, depth = self.steps[s]
+        if self.world == 1 or depth == 0 or buf < 0:
+            return
+        with torch.cuda.stream(self.stream):
+            self.exchanger.finish(handle)
+            if self.overlap:
+                self.plan.execute_step(s, 1, raw)
+                self.plan.execute_step(s, 2, raw)
+            else:
+                self.plan.execute_step(s, 0, raw)
+
+    def execute(self):
+        """One execution of the whole chain (asynchronous on ``self.stream``)."""
+        for s in range(len(self.steps)):
+            self.step_end(s, self.step_begin(s))
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def close(self):
+        self.plan.close()
