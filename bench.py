@@ -26,6 +26,27 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
+SEED = 20261003
+
+
+def synthetic(shape, rank=0):
+    """Uniform random grid (timing on constant data flatters the clock:
+    cdna_hip_programming.md §5.4 rule 25)."""
+    rng = np.random.default_rng(SEED + rank)
+    return rng.random(shape, dtype=np.float32)
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/hbm_traffic.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE,
+    collected in their own --pmc runs of this command), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        return float(table[kernel.rsplit("_", 1)[0]]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(shape, block=8, budget_s=12.0):
@@ -38,7 +59,7 @@ def cpu_baseline(shape, block=8, budget_s=12.0):
     ref = c_oracle.CompiledReference(programs.jacobi3d(shape, block),
                                      threads=cores)
     out_name = "b{}".format(block - 1)
-    x = ref.run({"a": np.ones(shape, np.float32)})[out_name]  # untimed warm-up
+    x = ref.run({"a": synthetic(shape)})[out_name]  # untimed warm-up
     applied, t0 = 0, time.perf_counter()
     while True:
         x = ref.run({"a": x})[out_name]
@@ -101,8 +122,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         runner = SlabRunner(sfir, shape, rank, world, device=local_rank,
                             options=options)
-        local = np.ones(runner.local_shape, np.float32)
-        runner.upload([local])
+        runner.upload([synthetic(runner.local_shape, rank)])
 
         def step():
             runner.execute()
@@ -112,7 +132,7 @@ def main():
             dist.barrier()
     else:
         plan = Plan(sfir, device=local_rank, options=options)
-        plan.upload([np.ones(shape, np.float32)])
+        plan.upload([synthetic(shape)])
 
         def step():
             plan.execute(1)
@@ -155,7 +175,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic (uniform random [0,1), seed %d)" % SEED,
         "config": {
             "workload": "jacobi3d {}x{}x{} float32, {}-operator chain, "
                         "constant BC 0.0, coefficient 0.16666666".format(
@@ -177,7 +197,7 @@ def main():
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK,
-            "traffic": None,
+            "traffic": measured_traffic(name),
             "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": avg_s * 1e6,
             "launches": launches,

@@ -231,7 +231,10 @@ static StarCfg choose_star_cfg(const sf_plan& pl, int T, DT dt) {
   const Program& P = pl.P;
   StarCfg base;
   base.T = T;
-  base.VK = 4;
+  // one 16-byte vector per row and lane: 4 floats or 2 doubles
+  base.VK = (int)pl.opt.get("k1.vk", dt == DT::F64 ? 2 : 4);
+  if (base.VK != 2 && base.VK != 4) throw Error(SF_ERR_INVALID, "k1.vk must be 2 or 4");
+  if (P.n[2] % base.VK != 0) throw Error(SF_ERR_INVALID, "innermost extent must be a multiple of k1.vk");
   base.n0g = P.n[0];
   base.n1 = P.n[1];
   base.n2 = P.n[2];
@@ -312,7 +315,12 @@ static void build_plan(sf_plan& pl) {
       if (seen.insert(a.field).second) consumers[a.field]++;
   }
 
-  const int fuse = (int)std::max<long long>(1, pl.opt.get("fuse", 2));
+  // default fusion depth (measured, profiles/r01_sweep_*): 2 for 3-D f32 (register
+  // budget), 4 for 2-D (3 values of state per stage), 3 for f64 chains
+  long long fuse_default = 2;
+  if (P.n[1] == 1) fuse_default = 4;
+  else if (P.kernels[0].dt == DT::F64) fuse_default = 3;
+  const int fuse = (int)std::max<long long>(1, pl.opt.get("fuse", fuse_default));
   const bool generic_only = pl.opt.get("generic_only", 0) != 0;
   const bool star_ok_dims = (P.nd >= 2) && (P.n[2] % 4 == 0) && P.n[0] > 1;
 

@@ -197,7 +197,8 @@ class SlabRunner:
         self.torch = torch
         self.rank, self.world, self.device = rank, world, device
         options = dict(options or {})
-        fuse = int(options.get("fuse", 2))
+        # default halo = deepest fusion the planner picks by itself (4, for 2-D)
+        fuse = int(options.get("fuse", 4))
         self.halo = int(halo if halo is not None else max(1, fuse))
         self.lo, self.hi = slab_bounds(global_shape[0], rank, world)
         self.n_local = self.hi - self.lo

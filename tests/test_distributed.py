@@ -1,0 +1,163 @@
+"""Multi-rank path: slab arithmetic, the neighbour-exchange protocol over
+torch.distributed (gloo, world_size 2 and 3, CPU tensors) and the whole
+decomposed chain with the oracle standing in for the device (CPU), plus -- on a
+GPU box -- two processes sharing the GPU with host-staged exchange."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawn(fn, world, *args):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(fn, args=(world, port) + args, nprocs=world, join=True)
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def test_slab_bounds_and_regions():
+    from stencilflow_amd.distributed import halo_regions, slab_bounds
+    for n0, world in [(512, 8), (40, 3), (7, 7), (4096, 8)]:
+        cuts = [slab_bounds(n0, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n0
+        assert all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+    r = halo_regions(n_local=10, halo=3, depth=2, plane_bytes=100)
+    assert r["send_down"] == (300, 200) and r["recv_down"] == (100, 200)
+    assert r["send_up"] == (1100, 200) and r["recv_up"] == (1300, 200)
+
+
+def _exchange_worker(rank, world, port, depth, halo):
+    import torch
+    sys.path.insert(0, ROOT)
+    from stencilflow_amd.distributed import (TorchDistExchanger, halo_regions)
+    _init(rank, world, port)
+    n_local, plane = 6 + rank, 16
+    buf = torch.zeros((n_local + 2 * halo) * plane, dtype=torch.uint8)
+    view = buf.view(n_local + 2 * halo, plane)
+    for p in range(n_local):  # owned plane p of rank r holds 10*r + p
+        view[halo + p] = 10 * rank + p
+    regions = halo_regions(n_local, halo, depth, plane)
+    ex = TorchDistExchanger(rank, world)
+    ex.finish(ex.start(buf, regions, key=0))
+    if rank > 0:
+        n_lo = 6 + rank - 1
+        for d in range(depth):
+            assert int(view[halo - depth + d, 0]) == 10 * (rank - 1) + n_lo - depth + d
+    else:
+        assert int(view[:halo].max()) == 0
+    if rank < world - 1:
+        for d in range(depth):
+            assert int(view[halo + n_local + d, 0]) == 10 * (rank + 1) + d
+    else:
+        assert int(view[halo + n_local:].max()) == 0
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_neighbour_exchange_gloo(world):
+    _spawn(_exchange_worker, world, 2, 3)
+
+
+def _chain_worker(rank, world, port, shape, stages, fuse, tmpdir):
+    """The SlabRunner protocol with the oracle as the compute stand-in: per
+    launch group exchange `fuse` planes, advance the extended slab `fuse`
+    operators, keep the owned planes."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from oracle import numpy_oracle as npo
+    from stencilflow_amd import programs
+    from stencilflow_amd.distributed import (TorchDistExchanger, halo_regions,
+                                             slab_bounds)
+    _init(rank, world, port)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    lo, hi = slab_bounds(shape[0], rank, world)
+    n_local, halo = hi - lo, fuse
+    plane_elems = shape[1] * shape[2]
+    local = np.zeros((n_local + 2 * halo, ) + tuple(shape[1:]), np.float32)
+    local[halo:halo + n_local] = x[lo:hi]
+    ex = TorchDistExchanger(rank, world)
+    done = 0
+    while done < stages:
+        t = min(fuse, stages - done)
+        buf = torch.from_numpy(local.reshape(-1).view(np.uint8))
+        ex.finish(ex.start(buf, halo_regions(n_local, halo, t, plane_elems * 4),
+                           key=0))
+        g_lo, g_hi = max(0, lo - t), min(shape[0], hi + t)
+        ext = local[halo - (lo - g_lo):halo + n_local + (g_hi - hi)]
+        sub = programs.jacobi3d(ext.shape, t, bc_value=0.5)
+        out = npo.run_reference(sub, {"a": ext})["b%d" % (t - 1)]
+        local[halo:halo + n_local] = out[lo - g_lo:lo - g_lo + n_local]
+        done += t
+    want = npo.run_reference(programs.jacobi3d(shape, stages, bc_value=0.5),
+                             {"a": x})["b%d" % (stages - 1)]
+    assert np.array_equal(local[halo:halo + n_local], want[lo:hi])
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fuse", [(2, 2), (3, 1), (2, 3)])
+def test_decomposed_chain_protocol_gloo(tmp_path, world, fuse):
+    _spawn(_chain_worker, world, (18, 6, 8), 5, fuse, str(tmp_path))
+
+
+def _gpu_worker(rank, world, port, shape, stages, overlap):
+    import torch
+    sys.path.insert(0, ROOT)
+    import stencilflow_amd as sf
+    from oracle import numpy_oracle as npo
+    from stencilflow_amd import programs
+    from stencilflow_amd.distributed import SlabRunner, TorchDistExchanger
+    from stencilflow_amd.lowering import lower
+    import tempfile
+    _init(rank, world, port)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    prog = programs.jacobi3d(shape, stages, bc_value=0.25)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = programs.write_program(prog, os.path.join(tmp, "p.json"))
+        sfir = lower(sf.KernelChainGraph(path))
+    runner = SlabRunner(sfir, shape, rank, world, device=0,
+                        exchanger=TorchDistExchanger(rank, world,
+                                                     staging="host"),
+                        overlap=overlap)
+    runner.upload([x[runner.lo:runner.hi]])
+    runner.execute()
+    runner.synchronize()
+    out = np.zeros(runner.local_shape, np.float32)
+    runner.download([out])
+    want = npo.run_reference(prog, {"a": x})["b%d" % (stages - 1)]
+    assert np.array_equal(out, want[runner.lo:runner.hi])
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_processes_one_gpu_host_staged(overlap):
+    """Two ranks (processes) drive their slabs on the same GPU; halos travel
+    through gloo.  Everything but the RCCL transport itself is exercised."""
+    _spawn(_gpu_worker, 2, (36, 20, 64), 6, overlap)
