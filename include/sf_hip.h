@@ -108,6 +108,11 @@ const char* sf_plan_kernel_source(const sf_plan* plan, int index);
 int sf_plan_kernel_stats(sf_plan* plan, int index, int* launches,
                          double* total_ms, double* updates_per_launch,
                          double* algorithmic_bytes_per_launch);
+/* Register / LDS footprint of generated kernel `index`, read from the compiled
+ * code object's metadata (-1 where the compiler did not report a field). */
+int sf_plan_kernel_resources(const sf_plan* plan, int index, int* vgprs,
+                             int* agprs, int* vgpr_spills, int* scratch_bytes,
+                             int* lds_bytes);
 /* Human-readable description of the schedule (groups, tiles, buffers). */
 const char* sf_plan_describe(const sf_plan* plan);
 

@@ -19,7 +19,7 @@ from .lowering import lower
 
 _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
-                         "libsf_hip.so")
+                         os.environ.get("SF_HIP_LIBNAME", "libsf_hip.so"))
 
 SF_OK = 0
 _STATUS_EXC = {
@@ -64,6 +64,7 @@ API = [
     ("sf_plan_kernel_name", _S, [_P, _I]),
     ("sf_plan_kernel_source", _S, [_P, _I]),
     ("sf_plan_kernel_stats", _I, [_P, _I, _IP, _DP, _DP, _DP]),
+    ("sf_plan_kernel_resources", _I, [_P, _I, _IP, _IP, _IP, _IP, _IP]),
     ("sf_plan_describe", _S, [_P]),
     ("sf_plan_num_steps", _I, [_P]),
     ("sf_plan_step_halo", _I, [_P, _I, _IP, _IP]),
@@ -200,6 +201,17 @@ class Plan:
                              total_ms=ms.value,
                              updates_per_launch=upd.value,
                              algorithmic_bytes_per_launch=byt.value)
+        return out
+
+    def kernel_resources(self):
+        """name -> dict(vgprs, agprs, spills, scratch, lds) from the code object."""
+        out = {}
+        for i, name in enumerate(self.kernel_names()):
+            v = [ctypes.c_int() for _ in range(5)]
+            _check(self._lib.sf_plan_kernel_resources(
+                self._h, i, *[ctypes.byref(x) for x in v]))
+            out[name] = dict(zip(("vgprs", "agprs", "spills", "scratch", "lds"),
+                                 [x.value for x in v]))
         return out
 
     def input_bytes(self, i):

@@ -1,6 +1,7 @@
 // star3d.h — fused T-stage plane-streaming kernel for radius-1 star stencils on
-// a 3-D field (CDNA4 / gfx950, wave64).  Compiled at plan creation by hipRTC
-// with the macros and `sf_stage<S>` functors emitted by codegen (codegen.hpp).
+// a 3-D (or, with SF_NOJ, 2-D) field (CDNA4 / gfx950, wave64).  Compiled at plan
+// creation by hipRTC with the macros and `sf_stage<S>` functors emitted by
+// codegen (codegen.hpp).
 //
 // Role in the reference: one launch of this kernel evaluates SF_T consecutive
 // operators of the chain, each with the per-point semantics of
@@ -15,16 +16,20 @@
 //            (and SF_HK columns in k when the row is wider than the tile),
 //            marching along i over one chunk of planes;
 //   thread = SF_RJ consecutive rows x SF_VK consecutive k (one 16-byte vector
-//            per row), for every stage: planes q-1 and q in registers.
+//            per row); for every stage boundary a window of three planes
+//            (q-1, q, q+1) lives in registers.
 //   Per step one new input plane is read from HBM (coalesced 16 B/lane) and
 //   stage s produces plane p-s; i-neighbours come from the register window,
 //   j-neighbours from registers (inner rows) or LDS (first/last row of the
 //   adjacent thread row), k-neighbours from the adjacent lane (__shfl) or,
 //   at a wave edge, from LDS.
+//   The three window slots rotate by *phase*: the step loop is unrolled by 3
+//   with compile-time slot indices, so no register is ever copied -- the slot
+//   that held plane q-1 receives plane q+2.
 //
-// Macros from codegen: SF_T SF_VK SF_RJ SF_BX SF_BY SF_HK SF_KTILED
-//   SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_KERNEL_NAME, typedef sf_t,
-//   struct sf_scalars, template<int S> struct sf_stage {bc(), apply()}.
+// Macros from codegen: SF_T SF_VK SF_RJ SF_BX SF_BY SF_HK SF_KTILED SF_NOJ
+//   SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_LDS_DB SF_ROW_FENCE SF_KERNEL_NAME,
+//   typedef sf_t, struct sf_scalars, template<int S> struct sf_stage {bc(), apply()}.
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 
@@ -47,10 +52,19 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #endif
 #define SF_USE_LDS (!(SF_NOJ && SF_WPR == 1))
 #define SF_EDGE_ELEMS (SF_T * SF_BY * SF_RJ * SF_WPR * 2)
+#define SF_IMAGE_ELEMS (SF_ROWS_ELEMS + SF_EDGE_ELEMS)
 
+// w[s][slot][row]: planes of stage-s data (s = 0 is the input field).  At
+// phase PH the slots hold  prev = PH % 3,  cur = (PH + 1) % 3,  next = (PH + 2) % 3.
 struct sf_state {
-  sf_vec prev[SF_T][SF_RJ];
-  sf_vec cur[SF_T][SF_RJ];
+  sf_vec w[SF_T][3][SF_RJ];
+};
+
+struct sf_ctx {
+  int tx, ty, lane, wave;
+  unsigned jmask, kmask, store_mask;
+  bool kvec_in;
+  int goff, halo, cb, ce, j0, k0;
 };
 
 __device__ __forceinline__ int sf_rows_at(int s, int ty, int which) {
@@ -60,20 +74,17 @@ __device__ __forceinline__ int sf_edge_at(int s, int ty, int r, int w, int side)
   return SF_ROWS_ELEMS + ((((s * SF_BY + ty) * SF_RJ + r) * SF_WPR + w) * 2 + side);
 }
 
-// One stage of the fused group at one step.  `fresh` holds plane q+1 of the
-// source field (stage S-1) on entry and plane q of stage S on return; the
-// source window is rotated row by row so that at most three planes per stage
-// boundary are live.
-template <int S>
-__device__ __forceinline__ void sf_stage_step(
-    sf_state& st, sf_vec (&fresh)[SF_RJ], const sf_t* lds, const sf_scalars& sc,
-    sf_t* __restrict__ out, const int tx, const int ty, const int lane,
-    const int wave, const unsigned jmask, const unsigned kmask,
-    const unsigned store_mask, const int p, const int goff, const int halo,
-    const int cb, const int ce, const int j0, const int k0) {
+// One stage of the fused group at one step: reads the source window of stage
+// S-1 at phase PH and writes plane q = p - S of stage S (into its own window, or
+// to HBM for the last stage).
+template <int S, int PH>
+__device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, const sf_scalars& sc,
+                                              sf_t* __restrict__ out, const sf_ctx& cx, const int p) {
   constexpr int src = S - 1;
+  constexpr int iprev = PH % 3, icur = (PH + 1) % 3, inext = (PH + 2) % 3;
+  const int tx = cx.tx, ty = cx.ty;
   // first / last row of the neighbouring thread rows (LDS)
-  sf_vec jm0 = st.cur[src][0], jpl = st.cur[src][SF_RJ - 1];
+  sf_vec jm0 = st.w[src][icur][0], jpl = st.w[src][icur][SF_RJ - 1];
   if constexpr (!SF_NOJ) {
     if (ty > 0)
       jm0 = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(src, ty - 1, 1) + tx * SF_VK]);
@@ -81,26 +92,27 @@ __device__ __forceinline__ void sf_stage_step(
       jpl = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(src, ty + 1, 0) + tx * SF_VK]);
   }
   const int q = p - S;  // plane this stage produces (local owned coords)
-  const bool plane_in = (q + goff >= 0) && (q + goff < SF_N0G);
-  const bool store_plane = (S == SF_T) && q >= cb && q < ce && plane_in;
+  const bool plane_in = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G);
+  const bool store_plane = (S == SF_T) && q >= cx.cb && q < cx.ce && plane_in;
   sf_t pad = (sf_t)0;
   if constexpr (S < SF_T) pad = sf_stage<(S < SF_T ? S + 1 : S)>::bc();
   sf_vec jm = jm0;
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
-    const sf_vec c = st.cur[src][r];
-    const sf_vec im = st.prev[src][r];
-    const sf_vec ip = fresh[r];
-    const sf_vec jp = (r < SF_RJ - 1) ? st.cur[src][r < SF_RJ - 1 ? r + 1 : r] : jpl;
+    const sf_vec c = st.w[src][icur][r];
+    const sf_vec im = st.w[src][iprev][r];
+    const sf_vec ip = st.w[src][inext][r];
+    const sf_vec jp = (r < SF_RJ - 1) ? st.w[src][icur][r < SF_RJ - 1 ? r + 1 : r] : jpl;
     // innermost-dimension halo: adjacent lanes hold the adjacent vectors
     sf_t km_e = __shfl_up(c[SF_VK - 1], 1);
     sf_t kp_e = __shfl_down(c[0], 1);
-    if (lane == 0)
-      km_e = (SF_WPR > 1 && wave > 0) ? lds[sf_edge_at(src, ty, r, wave > 0 ? wave - 1 : 0, 1)]
-                                      : sf_stage<S>::bc();
-    if (lane == 63)
-      kp_e = (SF_WPR > 1 && wave < SF_WPR - 1)
-                 ? lds[sf_edge_at(src, ty, r, wave < SF_WPR - 1 ? wave + 1 : wave, 0)]
+    if (cx.lane == 0)
+      km_e = (SF_WPR > 1 && cx.wave > 0)
+                 ? lds[sf_edge_at(src, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]
+                 : sf_stage<S>::bc();
+    if (cx.lane == 63)
+      kp_e = (SF_WPR > 1 && cx.wave < SF_WPR - 1)
+                 ? lds[sf_edge_at(src, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]
                  : sf_stage<S>::bc();
     sf_vec o;
 #pragma unroll
@@ -108,27 +120,21 @@ __device__ __forceinline__ void sf_stage_step(
       const sf_t km = (v > 0) ? c[v > 0 ? v - 1 : 0] : km_e;
       const sf_t kp = (v < SF_VK - 1) ? c[v < SF_VK - 1 ? v + 1 : v] : kp_e;
       o[v] = sf_stage<S>::apply(c[v], im[v], ip[v], jm[v], jp[v], km, kp, sc);
-#if SF_ROW_FENCE > 1
-      __builtin_amdgcn_sched_barrier(0);
-#endif
     }
-    // rotate this row of the source window: plane q+1 becomes "current"
     jm = c;
-    st.prev[src][r] = c;
-    st.cur[src][r] = ip;
     if constexpr (S == SF_T) {
       // last stage of the group: write interior, in-domain points
-      if (store_plane && ((store_mask >> r) & 1u)) {
+      if (store_plane && ((cx.store_mask >> r) & 1u)) {
         // wave-uniform plane base (SGPR pair) + 32-bit in-plane offset
-        sf_t* plane = out + (size_t)(q + halo) * ((size_t)SF_N1 * SF_N2);
-        *reinterpret_cast<sf_vec*>(plane + (unsigned)((j0 + r) * SF_N2 + k0)) = o;
+        sf_t* plane = out + (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2);
+        *reinterpret_cast<sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)) = o;
       }
     } else {
       // pad: outside the global domain the next stage must read ITS constant
-      const bool row_in = plane_in && ((jmask >> r) & 1u);
+      const bool row_in = plane_in && ((cx.jmask >> r) & 1u);
 #pragma unroll
-      for (int v = 0; v < SF_VK; ++v) o[v] = (row_in && ((kmask >> v) & 1u)) ? o[v] : pad;
-      fresh[r] = o;
+      for (int v = 0; v < SF_VK; ++v) o[v] = (row_in && ((cx.kmask >> v) & 1u)) ? o[v] : pad;
+      st.w[S < SF_T ? S : 0][inext][r] = o;  // becomes plane "next" of stage S
     }
 #if SF_ROW_FENCE
     __builtin_amdgcn_sched_barrier(0);  // rows in order: bounds the live f64 temporaries
@@ -136,29 +142,89 @@ __device__ __forceinline__ void sf_stage_step(
   }
 }
 
-template <int S>
-__device__ __forceinline__ void sf_later_stages(
-    sf_state& st, sf_vec (&fresh)[SF_RJ], const sf_t* lds, const sf_scalars& sc,
-    sf_t* __restrict__ out, const int tx, const int ty, const int lane,
-    const int wave, const unsigned jmask, const unsigned kmask,
-    const unsigned store_mask, const int p, const int goff, const int halo,
-    const int cb, const int ce, const int j0, const int k0) {
+template <int S, int PH>
+__device__ __forceinline__ void sf_later_stages(sf_state& st, const sf_t* lds, const sf_scalars& sc,
+                                                sf_t* __restrict__ out, const sf_ctx& cx,
+                                                const int p) {
   if constexpr (S <= SF_T) {
-    sf_stage_step<S>(st, fresh, lds, sc, out, tx, ty, lane, wave, jmask, kmask, store_mask, p,
-                     goff, halo, cb, ce, j0, k0);
-    sf_later_stages<S + 1>(st, fresh, lds, sc, out, tx, ty, lane, wave, jmask, kmask,
-                           store_mask, p, goff, halo, cb, ce, j0, k0);
+    sf_stage_step<S, PH>(st, lds, sc, out, cx, p);
+    sf_later_stages<S + 1, PH>(st, lds, sc, out, cx, p);
   }
 }
 
-extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
-    SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc,
-                   int halo, int goff, int i_begin, int i_end, int li) {
-  // SF_LDS_DB: two exchange images used alternately -> one barrier per step
-  __shared__ sf_t lds_all[(SF_LDS_DB ? 2 : 1) * (SF_ROWS_ELEMS + SF_EDGE_ELEMS)];
+__device__ __forceinline__ void sf_load_plane(const sf_t* __restrict__ in, const sf_ctx& cx,
+                                              const int p, sf_vec (&dst)[SF_RJ]) {
+  const sf_t pad0 = sf_stage<1>::bc();
+  const bool plane_in = (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
+  const sf_t* plane = in + (size_t)(p + cx.halo) * ((size_t)SF_N1 * SF_N2);
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    sf_vec v = (sf_vec)pad0;
+    if (plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in)
+      v = *reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0));
+    dst[r] = v;
+  }
+}
 
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int lane = tx & 63, wave = tx >> 6;
+// One step (input plane p) at phase PH.
+template <int PH>
+__device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __restrict__ in,
+                                        sf_t* __restrict__ out, const sf_scalars& sc,
+                                        const sf_ctx& cx, const int p, const int p_end) {
+  constexpr int icur = (PH + 1) % 3;
+  // Make the window opaque at the step boundary: otherwise the compiler keeps
+  // the f64 conversions of whole planes alive from one unrolled step to the
+  // next (fewer v_cvt, but ~80 more VGPRs and spills).
+#if SF_OPAQUE
+#pragma unroll
+  for (int s = 0; s < SF_T; ++s)
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int r = 0; r < SF_RJ; ++r) asm volatile("" : "+v"(st.w[s][w][r]));
+#endif
+  // publish the rows / columns other threads need of every stage's current plane
+#pragma unroll
+  for (int s = 0; s < SF_T; ++s) {
+    if constexpr (!SF_NOJ) {
+      *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(s, cx.ty, 0) + cx.tx * SF_VK]) = st.w[s][icur][0];
+      *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(s, cx.ty, 1) + cx.tx * SF_VK]) =
+          st.w[s][icur][SF_RJ - 1];
+    }
+    if (SF_WPR > 1) {
+      if (cx.lane == 0) {
+#pragma unroll
+        for (int r = 0; r < SF_RJ; ++r) lds[sf_edge_at(s, cx.ty, r, cx.wave, 0)] = st.w[s][icur][r][0];
+      }
+      if (cx.lane == 63) {
+#pragma unroll
+        for (int r = 0; r < SF_RJ; ++r)
+          lds[sf_edge_at(s, cx.ty, r, cx.wave, 1)] = st.w[s][icur][r][SF_VK - 1];
+      }
+    }
+  }
+  if (SF_USE_LDS) __syncthreads();
+  // stage 1 consumes input plane p (slot "next" of the input window) ...
+  sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
+  // ... and frees slot "prev", which receives input plane p+1 while later stages run
+  if (p + 1 < p_end) sf_load_plane(in, cx, p + 1, st.w[0][PH % 3]);
+  sf_later_stages<2, PH>(st, lds, sc, out, cx, p);
+  if (SF_USE_LDS && !SF_LDS_DB) __syncthreads();
+}
+
+extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
+    SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, int halo,
+                   int goff, int i_begin, int i_end, int li) {
+  // SF_LDS_DB: two exchange images used alternately -> one barrier per step
+  __shared__ sf_t lds_all[(SF_LDS_DB ? 2 : 1) * SF_IMAGE_ELEMS];
+
+  sf_ctx cx;
+  cx.tx = threadIdx.x;
+  cx.ty = threadIdx.y;
+  cx.lane = cx.tx & 63;
+  cx.wave = cx.tx >> 6;
+  cx.goff = goff;
+  cx.halo = halo;
 
   // XCD-aware block order: consecutive logical tiles (adjacent in j, sharing
   // halo rows) land on one XCD and therefore one L2 (blocks are dealt
@@ -170,90 +236,55 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   const int kt = (L / SF_NJT) % SF_NKT;
   const int ch = L / (SF_NJT * SF_NKT);
 
-  const int cb = i_begin + ch * li;
-  const int ce = (cb + li < i_end) ? cb + li : i_end;
-  if (cb >= ce) return;
+  cx.cb = i_begin + ch * li;
+  cx.ce = (cx.cb + li < i_end) ? cx.cb + li : i_end;
+  if (cx.cb >= cx.ce) return;
 
-  const int j0 = SF_NOJ ? 0 : (jt * SF_TJI - SF_T + ty * SF_RJ);
-  const int k0 = SF_KTILED ? (kt * SF_TKI - SF_HK + tx * SF_VK) : tx * SF_VK;
+  cx.j0 = SF_NOJ ? 0 : (jt * SF_TJI - SF_T + cx.ty * SF_RJ);
+  cx.k0 = SF_KTILED ? (kt * SF_TKI - SF_HK + cx.tx * SF_VK) : cx.tx * SF_VK;
 
-  unsigned jmask = 0, kmask = 0, store_mask = 0;
+  cx.jmask = 0;
+  cx.kmask = 0;
+  cx.store_mask = 0;
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
-    const int j = j0 + r, tr = ty * SF_RJ + r;
-    const bool in = (j >= 0) && (j < SF_N1);
-    jmask |= (in ? 1u : 0u) << r;
-    store_mask |= ((in && (SF_NOJ || (tr >= SF_T && tr < SF_TJH - SF_T))) ? 1u : 0u) << r;
+    const int j = cx.j0 + r, tr = cx.ty * SF_RJ + r;
+    const bool in_dom = (j >= 0) && (j < SF_N1);
+    cx.jmask |= (in_dom ? 1u : 0u) << r;
+    cx.store_mask |= ((in_dom && (SF_NOJ || (tr >= SF_T && tr < SF_TJH - SF_T))) ? 1u : 0u) << r;
   }
 #pragma unroll
   for (int v = 0; v < SF_VK; ++v)
-    kmask |= ((k0 + v >= 0 && k0 + v < SF_N2) ? 1u : 0u) << v;
-  const bool kvec_in = (kmask & 1u) != 0;  // N2 % VK == 0: whole vector in or out
+    cx.kmask |= ((cx.k0 + v >= 0 && cx.k0 + v < SF_N2) ? 1u : 0u) << v;
+  cx.kvec_in = (cx.kmask & 1u) != 0;  // N2 % VK == 0: whole vector in or out
   if (SF_KTILED) {
-    const int tk = tx * SF_VK;
-    if (!(tk >= SF_HK && tk < SF_TKH - SF_HK && kvec_in)) store_mask = 0;
+    const int tk = cx.tx * SF_VK;
+    if (!(tk >= SF_HK && tk < SF_TKH - SF_HK && cx.kvec_in)) cx.store_mask = 0;
   }
 
   sf_state st;
 #pragma unroll
   for (int s = 0; s < SF_T; ++s)
 #pragma unroll
-    for (int r = 0; r < SF_RJ; ++r) {
-      st.prev[s][r] = (sf_vec)(sf_t)0;
-      st.cur[s][r] = (sf_vec)(sf_t)0;
-    }
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int r = 0; r < SF_RJ; ++r) st.w[s][w][r] = (sf_vec)(sf_t)0;
 
-  const sf_t pad0 = sf_stage<1>::bc();
-  auto load_plane = [&](int p, sf_vec(&dst)[SF_RJ]) {
-    const bool plane_in = (p + goff >= 0) && (p + goff < SF_N0G);
-#pragma unroll
-    for (int r = 0; r < SF_RJ; ++r) {
-      sf_vec v = (sf_vec)pad0;
-      if (plane_in && ((jmask >> r) & 1u) && kvec_in) {
-        const sf_t* plane = in + (size_t)(p + halo) * ((size_t)SF_N1 * SF_N2);
-        v = *reinterpret_cast<const sf_vec*>(plane + (unsigned)((j0 + r) * SF_N2 + k0));
-      }
-      dst[r] = v;
-    }
-  };
+  const int p_begin = cx.cb - SF_T, p_end = cx.ce + SF_T;
+  sf_load_plane(in, cx, p_begin, st.w[0][2]);  // slot "next" of phase 0
 
-  sf_vec pre[SF_RJ];
-  load_plane(cb - SF_T, pre);
-
-  int parity = 0;
-  for (int p = cb - SF_T; p < ce + SF_T; ++p) {
-    sf_t* lds = lds_all + (SF_LDS_DB ? parity * (SF_ROWS_ELEMS + SF_EDGE_ELEMS) : 0);
-    parity ^= 1;
-    // publish the rows / columns other threads need of every stage's current plane
-#pragma unroll
-    for (int s = 0; s < SF_T; ++s) {
-      if constexpr (!SF_NOJ) {
-        *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(s, ty, 0) + tx * SF_VK]) = st.cur[s][0];
-        *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(s, ty, 1) + tx * SF_VK]) = st.cur[s][SF_RJ - 1];
-      }
-      if (SF_WPR > 1) {
-        if (lane == 0) {
-#pragma unroll
-          for (int r = 0; r < SF_RJ; ++r) lds[sf_edge_at(s, ty, r, wave, 0)] = st.cur[s][r][0];
-        }
-        if (lane == 63) {
-#pragma unroll
-          for (int r = 0; r < SF_RJ; ++r)
-            lds[sf_edge_at(s, ty, r, wave, 1)] = st.cur[s][r][SF_VK - 1];
-        }
-      }
-    }
-    if (SF_USE_LDS) __syncthreads();
-    // stage 1 consumes the prefetched input plane p ...
-    sf_stage_step<1>(st, pre, lds, sc, out, tx, ty, lane, wave, jmask, kmask, store_mask, p, goff,
-                     halo, cb, ce, j0, k0);
-    sf_vec fresh[SF_RJ];
-#pragma unroll
-    for (int r = 0; r < SF_RJ; ++r) fresh[r] = pre[r];
-    // ... whose registers then receive input plane p+1 while later stages run
-    if (p + 1 < ce + SF_T) load_plane(p + 1, pre);
-    sf_later_stages<2>(st, fresh, lds, sc, out, tx, ty, lane, wave, jmask, kmask, store_mask, p,
-                       goff, halo, cb, ce, j0, k0);
-    if (SF_USE_LDS && !SF_LDS_DB) __syncthreads();
+  // Two exchange images alternate every step (run-time offset); the window
+  // phase cycles with period 3 (compile-time slot indices).
+  int image = 0;
+  // the trip always runs three steps: up to two surplus steps past p_end
+  // compute planes nobody stores (loads and stores are range-guarded), which
+  // keeps the loop body free of control flow between the phases
+  for (int p = p_begin; p < p_end; p += 3) {
+    sf_step<0>(st, lds_all + image, in, out, sc, cx, p, p_end);
+    if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
+    sf_step<1>(st, lds_all + image, in, out, sc, cx, p + 1, p_end);
+    if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
+    sf_step<2>(st, lds_all + image, in, out, sc, cx, p + 2, p_end);
+    if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
   }
 }

@@ -58,6 +58,8 @@ struct CompiledKernel {
   int launches = 0;
   double total_ms = 0;
   double updates_per_launch = 0, alg_bytes_per_launch = 0;
+  // from the code object's amdhsa metadata (msgpack note)
+  int vgprs = -1, agprs = -1, sgprs = -1, spills = -1, scratch = -1, lds = -1;
 };
 
 struct Buffer {
@@ -138,6 +140,32 @@ static void compile_kernel(CompiledKernel& k) {
   hiprtcDestroyProgram(&prog);
 }
 
+// Value of an unsigned msgpack integer stored right after the string key `key`
+// inside the code object's NT_AMDGPU_METADATA note (-1 if absent).
+static int metadata_uint(const std::vector<char>& code, const char* key) {
+  const size_t klen = std::strlen(key);
+  for (size_t i = 0; i + klen + 1 < code.size(); ++i) {
+    if (std::memcmp(&code[i], key, klen) != 0) continue;
+    const unsigned char* p = (const unsigned char*)&code[i + klen];
+    const unsigned char t = p[0];
+    if (t <= 0x7f) return t;
+    if (t == 0xcc && i + klen + 1 < code.size()) return p[1];
+    if (t == 0xcd && i + klen + 2 < code.size()) return (p[1] << 8) | p[2];
+    if (t == 0xce && i + klen + 4 < code.size())
+      return (int)(((unsigned)p[1] << 24) | (p[2] << 16) | (p[3] << 8) | p[4]);
+  }
+  return -1;
+}
+
+static void read_metadata(CompiledKernel& k) {
+  k.vgprs = metadata_uint(k.code, ".vgpr_count");
+  k.agprs = metadata_uint(k.code, ".agpr_count");
+  k.sgprs = metadata_uint(k.code, ".sgpr_count");
+  k.spills = metadata_uint(k.code, ".vgpr_spill_count");
+  k.scratch = metadata_uint(k.code, ".private_segment_fixed_size");
+  k.lds = metadata_uint(k.code, ".group_segment_fixed_size");
+}
+
 static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& source) {
   auto it = pl.kernel_by_source.find(source);
   if (it != pl.kernel_by_source.end()) return it->second;
@@ -145,6 +173,7 @@ static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::stri
   k.name = prefix + "_" + hex8(fnv1a(source));
   k.source = source;
   compile_kernel(k);
+  read_metadata(k);
   pl.kernels.push_back(std::move(k));
   pl.kernel_by_source[source] = (int)pl.kernels.size() - 1;
   return (int)pl.kernels.size() - 1;
@@ -171,7 +200,7 @@ static size_t star_lds_bytes(const StarCfg& c, DT dt) {
 static int star_regs_estimate(const StarCfg& c, DT dt) {
   const int words = (dt == DT::F64) ? 2 : 1;
   const int P = c.RJ * c.VK;
-  return 3 * c.T * P * words + 60 + (words - 1) * 20;
+  return 3 * c.T * P * words + 95 + (words - 1) * 20;
 }
 
 static int star_blocks_per_cu(const StarCfg& c, DT dt) {
@@ -179,6 +208,7 @@ static int star_blocks_per_cu(const StarCfg& c, DT dt) {
   const int waves_per_simd = (threads + 255) / 256;  // a block's waves on one SIMD
   const int regs = star_regs_estimate(c, dt);
   const int alloc = (regs + 7) / 8 * 8;
+  if (alloc > 256) return 0;  // would lean on AGPR / scratch spills
   const int by_regs = (512 / alloc) / waves_per_simd;
   const size_t lds = std::max<size_t>(star_lds_bytes(c, dt), 1);
   const int by_lds = (int)(160 * 1024 / lds);
@@ -227,7 +257,7 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
   return best_li;
 }
 
-static StarCfg choose_star_cfg(const sf_plan& pl, int T, DT dt) {
+static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   const Program& P = pl.P;
   StarCfg base;
   base.T = T;
@@ -241,15 +271,15 @@ static StarCfg choose_star_cfg(const sf_plan& pl, int T, DT dt) {
   base.noj = (P.n[1] == 1);
   base.row_fence = (int)pl.opt.get("k1.fence", 1);
   base.lds_db = (int)pl.opt.get("k1.db", 1);
+  base.unroll_p = (int)pl.opt.get("k1.unroll", 1);
+  base.opaque = (int)pl.opt.get("k1.opaque", 1);
   const std::string pfx = base.noj ? "k2." : "k1.";
   const long long pin_bx = pl.opt.get(pfx + "bx", 0);
   const long long pin_by = base.noj ? 1 : pl.opt.get("k1.by", 0);
   const long long pin_rj = base.noj ? 1 : pl.opt.get("k1.rj", 0);
   const int range = (int)pl.n_local;
 
-  double best_cost = 1e30;
-  StarCfg best = base;
-  bool found = false;
+  std::vector<std::pair<double, StarCfg>> ranked;
   for (int bx : {64, 128, 256}) {
     if (pin_bx && bx != pin_bx) continue;
     for (int rj = 1; rj <= 8; ++rj) {
@@ -272,16 +302,67 @@ static StarCfg choose_star_cfg(const sf_plan& pl, int T, DT dt) {
         const double kcost = (double)c.NKT * c.BX * c.VK / (double)P.n[2];
         // ties go to the larger block (fewer barriers per point)
         const double cost = jcost * kcost * chunk_cost * (1.0 + 1e-4 / (double)(c.BX * c.BY * c.RJ));
-        if (cost < best_cost - 1e-12) {
-          best_cost = cost;
-          best = c;
-          found = true;
-        }
+        ranked.push_back({cost, c});
       }
     }
   }
-  if (!found) throw Error(SF_ERR_INVALID, "star kernel: no tile shape satisfies the given k1.* options");
-  return best;
+  if (ranked.empty()) throw Error(SF_ERR_INVALID, "star kernel: no tile shape satisfies the given k1.* options");
+  std::stable_sort(ranked.begin(), ranked.end(),
+                   [](const std::pair<double, StarCfg>& a, const std::pair<double, StarCfg>& b) {
+                     return a.first < b.first;
+                   });
+  std::vector<StarCfg> out;
+  for (auto& rc : ranked) out.push_back(rc.second);
+  return out;
+}
+
+// Pick a tile shape for a fused group by compiling candidates in order of
+// modelled cost and reading the code object's metadata.  A kernel that spills,
+// uses scratch or overflows into AGPRs is rejected: besides being slow, such
+// kernels were observed to produce wrong results on gfx950 / ROCm 7 for
+// programs with device math calls (profiles/r01_config_fuzz.log).  Returns
+// false if no clean shape exists (caller shortens the group or goes generic).
+struct StarChoice {
+  bool ok = false;
+  StarCfg cfg;
+  int ck = -1;
+};
+
+static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& memo,
+                              const std::vector<int>& kernels, DT dt) {
+  const Program& P = pl.P;
+  StarCfg probe;
+  probe.T = (int)kernels.size();
+  const std::string sig = std::to_string(fnv1a(gen_star(P, kernels, probe).source));
+  auto it = memo.find(sig);
+  if (it != memo.end()) return it->second;
+  const std::string prefix = std::string("sf_star") + (P.n[1] == 1 ? "2d_" : "3d_") + short_of(dt) + "_t" +
+                             std::to_string(kernels.size());
+  StarChoice out;
+  std::vector<StarCfg> ranked;
+  try {
+    ranked = rank_star_cfgs(pl, (int)kernels.size(), dt);
+  } catch (const Error&) {
+    memo[sig] = out;
+    return out;
+  }
+  const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
+                      (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
+  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
+  for (size_t ci = 0; ci < tries; ++ci) {
+    StarKernelSource g = gen_star(P, kernels, ranked[ci]);
+    const int ck = intern_kernel(pl, prefix, g.source);
+    const CompiledKernel& k = pl.kernels[ck];
+    const int bad = std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs);
+    if (bad == 0 || (pinned && pl.opt.get("allow_spills", 0) != 0)) {
+      out.ok = true;
+      out.cfg = ranked[ci];
+      out.ck = ck;
+      break;
+    }
+  }
+  memo[sig] = out;
+  return out;
 }
 
 static void build_plan(sf_plan& pl) {
@@ -325,6 +406,7 @@ static void build_plan(sf_plan& pl) {
   const bool star_ok_dims = (P.nd >= 2) && (P.n[2] % 4 == 0) && P.n[0] > 1;
 
   // ---- group kernels into launches
+  std::map<std::string, StarChoice> star_memo;
   for (int k = 0; k < K;) {
     Step st;
     std::string src;
@@ -334,10 +416,9 @@ static void build_plan(sf_plan& pl) {
         if (a.off[1] != 0) star = false;
     }
     if (star) {
-      st.star = true;
-      st.kernels.push_back(k);
-      while ((int)st.kernels.size() < fuse && k + (int)st.kernels.size() < K) {
-        const int cur = st.kernels.back(), nxt = cur + 1;
+      std::vector<int> group{k};
+      while ((int)group.size() < fuse && k + (int)group.size() < K) {
+        const int cur = group.back(), nxt = cur + 1;
         const Kernel& kc = P.kernels[cur];
         std::string nsrc;
         if (!star_eligible(P, P.kernels[nxt], &nsrc)) break;
@@ -345,7 +426,22 @@ static void build_plan(sf_plan& pl) {
         if (P.field(kc.name).role != Role::Temp) break;
         if (consumers[kc.name] != 1) break;
         if (P.kernels[nxt].dt != kc.dt) break;
-        st.kernels.push_back(nxt);
+        group.push_back(nxt);
+      }
+      // longest prefix of the group for which a clean kernel exists
+      StarChoice choice;
+      while (!group.empty()) {
+        choice = select_star(pl, star_memo, group, P.kernels[k].dt);
+        if (choice.ok) break;
+        group.pop_back();
+      }
+      if (choice.ok) {
+        st.star = true;
+        st.kernels = group;
+        st.cfg = choice.cfg;
+        st.ck = choice.ck;
+      } else {
+        st.kernels.push_back(k);
       }
     } else {
       st.kernels.push_back(k);
@@ -450,16 +546,12 @@ static void build_plan(sf_plan& pl) {
   for (auto& st : pl.steps) {
     const DT dt = P.kernels[st.kernels[0]].dt;
     if (st.star) {
-      st.cfg = choose_star_cfg(pl, (int)st.kernels.size(), dt);
       if (star_lds_bytes(st.cfg, dt) > 160 * 1024)
         throw Error(SF_ERR_INVALID, "star kernel: tile needs more than 160 KiB of LDS");
       StarKernelSource g = gen_star(P, st.kernels, st.cfg);
       st.scalars = g.scalars;
       st.scalar_offsets = g.scalar_offsets;
       st.scalars_bytes = g.scalars_bytes;
-      std::string prefix = std::string("sf_star") + (st.cfg.noj ? "2d_" : "3d_") + short_of(dt) + "_t" +
-                           std::to_string(st.cfg.T);
-      st.ck = intern_kernel(pl, prefix, g.source);
       st.halo_depth = st.cfg.T;
       st.halo_buf = st.in_bufs[0];
     } else {
@@ -497,7 +589,8 @@ static void build_plan(sf_plan& pl) {
       desc << "[point]";
     desc << " in";
     for (int b : st.in_bufs) desc << " b" << b;
-    desc << " out b" << st.out_buf << "\n";
+    desc << " out b" << st.out_buf << " {vgpr " << ck.vgprs << " agpr " << ck.agprs << " spill " << ck.spills
+         << " scratch " << ck.scratch << "}\n";
   }
   pl.description = desc.str();
   pl.scalar_values.assign(P.num_scalar_inputs, 0.0);
@@ -856,6 +949,17 @@ int sf_plan_kernel_stats(sf_plan* p, int i, int* launches, double* total_ms, dou
   if (total_ms) *total_ms = k.total_ms;
   if (updates) *updates = k.updates_per_launch;
   if (alg_bytes) *alg_bytes = k.alg_bytes_per_launch;
+  return SF_OK;
+}
+int sf_plan_kernel_resources(const sf_plan* p, int i, int* vgprs, int* agprs, int* spills, int* scratch,
+                             int* lds) {
+  if (!p || i < 0 || i >= (int)p->kernels.size()) return SF_ERR_INVALID;
+  const CompiledKernel& k = p->kernels[i];
+  if (vgprs) *vgprs = k.vgprs;
+  if (agprs) *agprs = k.agprs;
+  if (spills) *spills = k.spills;
+  if (scratch) *scratch = k.scratch;
+  if (lds) *lds = k.lds;
   return SF_OK;
 }
 const char* sf_plan_describe(const sf_plan* p) { return p ? p->description.c_str() : nullptr; }
