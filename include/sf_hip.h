@@ -127,10 +127,22 @@ int sf_plan_num_steps(const sf_plan* plan);
  * slab boundaries; depth 0 if the step needs no exchange. */
 int sf_plan_step_halo(const sf_plan* plan, int step, int* buffer_id,
                       int* depth);
+/* Device buffers step `step` reads (ids written to buffer_ids[0..capacity),
+ * return value = their number) and the buffer it writes. */
+int sf_plan_step_inputs(const sf_plan* plan, int step, int* buffer_ids,
+                        int capacity);
+int sf_plan_step_output(const sf_plan* plan, int step);
 /* Execute one step on `stream` (a hipStream_t, or NULL for the plan's own).
  * part: 0 = whole slab, 1 = planes adjacent to the lower slab boundary,
  *       2 = planes adjacent to the upper boundary, 3 = interior only. */
 int sf_plan_execute_step(sf_plan* plan, int step, int part, void* stream);
+/* Execute one step over explicit plane ranges [i_begin, i_end) and (optionally,
+ * i_begin2 < i_end2) [i_begin2, i_end2), in owned-plane coordinates: 0 is the
+ * first owned plane, negative values and values >= the slab height address
+ * halo planes (the launch then recomputes planes a neighbour also owns, which
+ * is how a deep halo is made to last several launches). */
+int sf_plan_execute_step_ranges(sf_plan* plan, int step, int i_begin, int i_end,
+                                int i_begin2, int i_end2, void* stream);
 /* Device address, plane size in bytes and plane count of device buffer `id`. */
 int sf_plan_buffer_info(const sf_plan* plan, int buffer_id, void** device_ptr,
                         size_t* plane_bytes, int* planes);

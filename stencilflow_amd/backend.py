@@ -68,7 +68,10 @@ API = [
     ("sf_plan_describe", _S, [_P]),
     ("sf_plan_num_steps", _I, [_P]),
     ("sf_plan_step_halo", _I, [_P, _I, _IP, _IP]),
+    ("sf_plan_step_inputs", _I, [_P, _I, _IP, _I]),
+    ("sf_plan_step_output", _I, [_P, _I]),
     ("sf_plan_execute_step", _I, [_P, _I, _I, _P]),
+    ("sf_plan_execute_step_ranges", _I, [_P, _I, _I, _I, _I, _I, _P]),
     ("sf_plan_buffer_info", _I,
      [_P, _I, _PP, ctypes.POINTER(ctypes.c_size_t), _IP]),
     ("sf_plan_input_buffer", _I, [_P, _I]),
@@ -290,10 +293,26 @@ class Plan:
                                         ctypes.byref(depth)))
         return buf.value, depth.value
 
+    def step_inputs(self, step):
+        ids = (ctypes.c_int * 16)()
+        n = _check(self._lib.sf_plan_step_inputs(self._h, step, ids, 16))
+        return [ids[i] for i in range(min(n, 16))]
+
+    def step_output(self, step):
+        return _check(self._lib.sf_plan_step_output(self._h, step))
+
     def execute_step(self, step, part=0, stream=None):
         _check(
             self._lib.sf_plan_execute_step(self._h, step, part,
                                            ctypes.c_void_p(stream or 0)))
+
+    def execute_step_ranges(self, step, i_begin, i_end, i_begin2=0, i_end2=0,
+                            stream=None):
+        _check(
+            self._lib.sf_plan_execute_step_ranges(self._h, step, int(i_begin),
+                                                  int(i_end), int(i_begin2),
+                                                  int(i_end2),
+                                                  ctypes.c_void_p(stream or 0)))
 
     def buffer_info(self, buffer_id):
         ptr = ctypes.c_void_p()

@@ -214,7 +214,7 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
 
 extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, int halo,
-                   int goff, int i_begin, int i_end, int li) {
+                   int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2) {
   // SF_LDS_DB: two exchange images used alternately -> one barrier per step
   __shared__ sf_t lds_all[(SF_LDS_DB ? 2 : 1) * SF_IMAGE_ELEMS];
 
@@ -236,8 +236,15 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   const int kt = (L / SF_NJT) % SF_NKT;
   const int ch = L / (SF_NJT * SF_NKT);
 
-  cx.cb = i_begin + ch * li;
-  cx.ce = (cx.cb + li < i_end) ? cx.cb + li : i_end;
+  // chunks [0, nch1) cover planes [i_begin, i_end), later chunks a second range
+  // [i_begin2, i_end2) (both slab boundaries in one launch)
+  if (ch < nch1) {
+    cx.cb = i_begin + ch * li;
+    cx.ce = (cx.cb + li < i_end) ? cx.cb + li : i_end;
+  } else {
+    cx.cb = i_begin2 + (ch - nch1) * li;
+    cx.ce = (cx.cb + li < i_end2) ? cx.cb + li : i_end2;
+  }
   if (cx.cb >= cx.ce) return;
 
   cx.j0 = SF_NOJ ? 0 : (jt * SF_TJI - SF_T + cx.ty * SF_RJ);

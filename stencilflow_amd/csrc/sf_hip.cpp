@@ -629,8 +629,10 @@ static void store_scalar(char* dst, DT dt, double v) {
   }
 }
 
+static void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, int i_begin2, int i_end2,
+                          hipStream_t stream);
+
 static void launch_step(sf_plan& pl, const Step& st, int part, hipStream_t stream) {
-  const Program& P = pl.P;
   int i_begin = 0, i_end = (int)pl.n_local;
   if (part != 0) {
     const int h = std::max(pl.halo, 1);
@@ -639,7 +641,20 @@ static void launch_step(sf_plan& pl, const Step& st, int part, hipStream_t strea
     else if (part == 2) i_begin = (int)pl.n_local - h;
     else { i_begin = h; i_end = (int)pl.n_local - h; }
   }
-  if (i_begin >= i_end) return;
+  launch_ranges(pl, st, i_begin, i_end, 0, 0, stream);
+}
+
+// Launch `st` over planes [i_begin, i_end) and, in the same launch where the
+// kernel supports it, [i_begin2, i_end2) (owned-plane coordinates; negative /
+// beyond-n_local values address halo planes).
+static void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, int i_begin2, int i_end2,
+                          hipStream_t stream) {
+  const Program& P = pl.P;
+  const int lo_limit = -pl.halo, hi_limit = (int)pl.n_local + pl.halo;
+  if (i_begin < lo_limit || i_end > hi_limit || (i_begin2 < i_end2 && (i_begin2 < lo_limit || i_end2 > hi_limit)))
+    throw Error(SF_ERR_INVALID, "plane range outside the slab and its halo");
+  const bool second = i_begin2 < i_end2;
+  if (i_begin >= i_end && !second) return;
   if (P.num_scalar_inputs > 0 && !pl.scalars_set)
     throw Error(SF_ERR_STATE, "the program has 0-D inputs: call sf_plan_set_scalars first");
   CompiledKernel& ck = pl.kernels[st.ck];
@@ -666,16 +681,17 @@ static void launch_step(sf_plan& pl, const Step& st, int part, hipStream_t strea
       store_scalar(scalar_store + st.scalar_offsets[s], sc.dt, pl.scalar_values[sc.input_index]);
     }
     // chunking of the stream axis: whole block waves (star_chunk_planes)
-    const int range = i_end - i_begin;
+    const int range1 = std::max(0, i_end - i_begin), range2 = second ? i_end2 - i_begin2 : 0;
     const int tiles = c.NJT * c.NKT;
     long long li = pl.opt.get(c.noj ? "k2.li" : "k1.li", 0);
-    if (li <= 0) li = star_chunk_planes(c, P.kernels[st.kernels[0]].dt, range);
-    if (li > range) li = range;
-    const int nch = (int)((range + li - 1) / li);
+    if (li <= 0) li = star_chunk_planes(c, P.kernels[st.kernels[0]].dt, std::max(range1, range2));
+    if (li > std::max(range1, range2)) li = std::max(range1, range2);
+    int nch1 = (int)((range1 + li - 1) / li);
+    const int nch2 = (int)((range2 + li - 1) / li);
     int li_i = (int)li;
-    args = {&ptrs[0], &ptrs[1], scalar_store, &halo, &goff, &i_begin, &i_end, &li_i};
-    SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(tiles * nch), 1, 1, c.BX, c.BY, 1, 0, stream,
-                                       args.data(), nullptr));
+    args = {&ptrs[0], &ptrs[1], scalar_store, &halo, &goff, &i_begin, &i_end, &li_i, &nch1, &i_begin2, &i_end2};
+    SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(tiles * (nch1 + nch2)), 1, 1, c.BX, c.BY, 1, 0,
+                                       stream, args.data(), nullptr));
   } else {
     for (int b : st.in_bufs) ptrs.push_back(pl.buffers[b].d);
     ptrs.push_back(pl.buffers[st.out_buf].d);
@@ -694,15 +710,19 @@ static void launch_step(sf_plan& pl, const Step& st, int part, hipStream_t strea
     args.push_back(&i_end);
     const long long plane = P.n[1] * P.n[2];
     const unsigned gx = (unsigned)((plane + 255) / 256);
-    int done = i_begin;
-    while (done < i_end) {  // gridDim.y is limited to 65535
-      int chunk_end = std::min(i_end, done + 65535);
-      int cb = done, ce = chunk_end;
-      args[args.size() - 2] = &cb;
-      args[args.size() - 1] = &ce;
-      SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, gx, (unsigned)(ce - cb), 1, 256, 1, 1, 0, stream,
-                                         args.data(), nullptr));
-      done = chunk_end;
+    const int ranges[2][2] = {{i_begin, i_end}, {i_begin2, i_end2}};
+    for (int ri = 0; ri < 2; ++ri) {
+      int done = ranges[ri][0];
+      const int stop = ranges[ri][1];
+      while (done < stop) {  // gridDim.y is limited to 65535
+        int chunk_end = std::min(stop, done + 65535);
+        int cb = done, ce = chunk_end;
+        args[args.size() - 2] = &cb;
+        args[args.size() - 1] = &ce;
+        SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, gx, (unsigned)(ce - cb), 1, 256, 1, 1, 0, stream,
+                                           args.data(), nullptr));
+        done = chunk_end;
+      }
     }
   }
   if (pl.profile) {
@@ -971,12 +991,33 @@ int sf_plan_step_halo(const sf_plan* p, int step, int* buffer_id, int* depth) {
   if (depth) *depth = p->steps[step].halo_buf >= 0 ? p->steps[step].halo_depth : 0;
   return SF_OK;
 }
+int sf_plan_step_inputs(const sf_plan* p, int step, int* buffer_ids, int capacity) {
+  if (!p || step < 0 || step >= (int)p->steps.size()) return SF_ERR_INVALID;
+  const auto& in = p->steps[step].in_bufs;
+  for (int i = 0; i < (int)in.size() && i < capacity; ++i)
+    if (buffer_ids) buffer_ids[i] = in[i];
+  return (int)in.size();
+}
+int sf_plan_step_output(const sf_plan* p, int step) {
+  if (!p || step < 0 || step >= (int)p->steps.size()) return SF_ERR_INVALID;
+  return p->steps[step].out_buf;
+}
 int sf_plan_execute_step(sf_plan* plan, int step, int part, void* stream) {
   SF_API_BEGIN
   if (!plan || step < 0 || step >= (int)plan->steps.size() || part < 0 || part > 3)
     throw Error(SF_ERR_INVALID, "bad step or part");
   ensure_device(*plan);
   launch_step(*plan, plan->steps[step], part, stream ? (hipStream_t)stream : plan->stream);
+  return SF_OK;
+  SF_API_END
+}
+int sf_plan_execute_step_ranges(sf_plan* plan, int step, int i_begin, int i_end, int i_begin2, int i_end2,
+                                void* stream) {
+  SF_API_BEGIN
+  if (!plan || step < 0 || step >= (int)plan->steps.size()) throw Error(SF_ERR_INVALID, "bad step");
+  ensure_device(*plan);
+  launch_ranges(*plan, plan->steps[step], i_begin, i_end, i_begin2, i_end2,
+                stream ? (hipStream_t)stream : plan->stream);
   return SF_OK;
   SF_API_END
 }

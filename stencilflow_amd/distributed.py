@@ -154,7 +154,7 @@ class LocalExchanger:
 
         class _View:
             def start(self, tensor, regions, key=None):
-                parent.pending[rank] = (tensor, regions)
+                parent.pending.setdefault(rank, []).append((tensor, regions))
                 return rank
 
             def finish(self, handle):
@@ -164,14 +164,13 @@ class LocalExchanger:
                 torch.cuda.synchronize()
                 p = parent.pending
                 for r in range(parent.world - 1):
-                    lo_t, lo_r = p[r]
-                    hi_t, hi_r = p[r + 1]
-                    so, ss = lo_r["send_up"]
-                    ro, rs = hi_r["recv_down"]
-                    hi_t[ro:ro + rs].copy_(lo_t[so:so + ss])
-                    so, ss = hi_r["send_down"]
-                    ro, rs = lo_r["recv_up"]
-                    lo_t[ro:ro + rs].copy_(hi_t[so:so + ss])
+                    for (lo_t, lo_r), (hi_t, hi_r) in zip(p[r], p[r + 1]):
+                        so, ss = lo_r["send_up"]
+                        ro, rs = hi_r["recv_down"]
+                        hi_t[ro:ro + rs].copy_(lo_t[so:so + ss])
+                        so, ss = hi_r["send_down"]
+                        ro, rs = lo_r["recv_up"]
+                        lo_t[ro:ro + rs].copy_(hi_t[so:so + ss])
                 torch.cuda.synchronize()
                 parent.pending = {}
 
@@ -189,23 +188,44 @@ def run_lockstep(runners):
 
 
 class SlabRunner:
-    """One rank of a slab-decomposed chain execution."""
+    """One rank of a slab-decomposed chain execution.
+
+    Schedule.  Halos are ``halo`` planes deep, deeper than one launch needs
+    (default: four launch groups' worth).  After an exchange the rank holds
+    ``halo`` valid ghost planes; a launch of reach ``d`` then computes not only
+    its owned planes but also the ``valid - d`` ghost planes that are still
+    computable (planes the neighbour owns, recomputed locally), so the next
+    launches need no communication.  Only when fewer than ``d`` valid planes
+    are left is the next exchange started; that launch is split: its interior
+    runs beside the transfer, the two boundary regions follow in ONE launch
+    once the halos have landed.  Measured on one MI355X (tools/slab_overhead.py):
+    splitting every launch costs 23 %; one split per four launches ~5 %.
+    """
 
     def __init__(self, sfir_text, global_shape, rank, world, device=0,
-                 options=None, exchanger=None, halo=None, overlap=True):
+                 options=None, exchanger=None, halo=None, overlap=True,
+                 groups_per_exchange=4):
         import torch
         self.torch = torch
         self.rank, self.world, self.device = rank, world, device
         options = dict(options or {})
-        # default halo = deepest fusion the planner picks by itself (4, for 2-D)
-        fuse = int(options.get("fuse", 4))
-        self.halo = int(halo if halo is not None else max(1, fuse))
         self.lo, self.hi = slab_bounds(global_shape[0], rank, world)
         self.n_local = self.hi - self.lo
-        if world > 1 and self.n_local < 2 * self.halo:
-            raise ValueError("slab of {} planes is thinner than two halos".
-                             format(self.n_local))
         self.local_shape = (self.n_local, ) + tuple(global_shape[1:])
+        self.has_lower = rank > 0
+        self.has_upper = rank < world - 1
+        # a plan without halo tells how far each launch reaches
+        probe = Plan(sfir_text, device=device, options=options)
+        depths = [probe.step_halo(s)[1] for s in range(probe.num_steps)]
+        probe.close()
+        reach = max([1] + depths)
+        if halo is None:
+            halo = reach * max(1, groups_per_exchange)
+            halo = max(reach, min(halo, self.n_local // 2))
+        self.halo = int(halo)
+        if world > 1 and (self.n_local < self.halo or self.n_local < 2 * reach):
+            raise ValueError("slab of {} planes is too thin for a halo of {}".
+                             format(self.n_local, self.halo))
         if world > 1:
             options["slab"] = "{}:{}:{}".format(self.lo, self.hi, self.halo)
         self.plan = Plan(sfir_text, device=device, options=options)
@@ -215,7 +235,14 @@ class SlabRunner:
         self.overlap = overlap
         self.stream = torch.cuda.Stream(device=device)
         self._tensors = {}
-        self.steps = [self.plan.step_halo(s) for s in range(self.plan.num_steps)]
+        n = self.plan.num_steps
+        self.steps = [self.plan.step_halo(s) for s in range(n)]
+        self.inputs = [self.plan.step_inputs(s) for s in range(n)]
+        self.outputs = [self.plan.step_output(s) for s in range(n)]
+        # a *chain*: every launch reads exactly the field the previous one wrote
+        self.is_chain = all(len(i) == 1 for i in self.inputs) and all(
+            self.inputs[s][0] == self.outputs[s - 1] for s in range(1, n))
+        self._valid = 0
 
     def _buffer_tensor(self, buf):
         if buf not in self._tensors:
@@ -230,39 +257,79 @@ class SlabRunner:
     def download(self, local_outputs):
         self.plan.download(local_outputs)
 
+    # ------------------------------------------------------------------ steps
+    def _slabbed_inputs(self, s):
+        out = []
+        for b in self.inputs[s]:
+            _, _, planes = self.plan.buffer_info(b)
+            if planes > 1:
+                out.append(b)
+        return out
+
     def step_begin(self, s):
         """Start the halo exchange step ``s`` needs (if any) and launch the part
-        of the step that does not depend on it."""
+        of the step that does not depend on it.  Returns a handle for
+        ``step_end``."""
         torch = self.torch
         raw = self.stream.cuda_stream
-        buf, depth = self.steps[s]
+        n, H = self.n_local, self.halo
+        _, d = self.steps[s]
+        if s == 0:
+            self._valid = 0
         with torch.cuda.stream(self.stream):
-            if self.world == 1 or depth == 0 or buf < 0:
+            if self.world == 1:
                 self.plan.execute_step(s, 0, raw)
                 return None
-            tensor, plane_bytes, _ = self._buffer_tensor(buf)
-            regions = halo_regions(self.n_local, self.halo, depth, plane_bytes)
-            # the transfer waits for everything queued so far (the planes it
-            # sends were produced by the previous launch) ...
-            handle = self.exchanger.start(tensor, regions, key=buf)
+            if self.is_chain and d <= self._valid:
+                # deep halo still good: recompute the ghost planes that remain
+                ext = self._valid - d
+                self.plan.execute_step_ranges(
+                    s, -ext if self.has_lower else 0,
+                    n + (ext if self.has_upper else 0), stream=raw)
+                self._valid = ext
+                return None
+            if d == 0:
+                self.plan.execute_step(s, 0, raw)
+                return None
+            depth = H if self.is_chain else d
+            handles = []
+            for buf in (self._slabbed_inputs(s) if not self.is_chain
+                        else [self.inputs[s][0]]):
+                tensor, plane_bytes, _ = self._buffer_tensor(buf)
+                regions = halo_regions(n, H, depth, plane_bytes)
+                # the transfer waits for everything queued so far (the planes it
+                # sends were produced by the previous launch) ...
+                handles.append(self.exchanger.start(tensor, regions, key=buf))
             if self.overlap:
                 # ... and runs beside the interior of this launch
-                self.plan.execute_step(s, 3, raw)
-            return handle
+                self.plan.execute_step_ranges(
+                    s, d if self.has_lower else 0,
+                    n - (d if self.has_upper else 0), stream=raw)
+            return (handles, depth)
 
     def step_end(self, s, handle):
+        if handle is None:
+            return
         torch = self.torch
         raw = self.stream.cuda_stream
-        buf, depth = self.steps[s]
-        if self.world == 1 or depth == 0 or buf < 0:
-            return
+        n = self.n_local
+        _, d = self.steps[s]
+        handles, depth = handle
+        ext = depth - d
         with torch.cuda.stream(self.stream):
-            self.exchanger.finish(handle)
+            for h in handles:
+                self.exchanger.finish(h)
+            lo_ext = ext if self.has_lower else 0
+            hi_ext = ext if self.has_upper else 0
             if self.overlap:
-                self.plan.execute_step(s, 1, raw)
-                self.plan.execute_step(s, 2, raw)
+                lo = (-lo_ext, d) if self.has_lower else (0, 0)
+                hi = (n - d, n + hi_ext) if self.has_upper else (0, 0)
+                self.plan.execute_step_ranges(s, lo[0], lo[1], hi[0], hi[1],
+                                              stream=raw)
             else:
-                self.plan.execute_step(s, 0, raw)
+                self.plan.execute_step_ranges(s, -lo_ext, n + hi_ext,
+                                              stream=raw)
+            self._valid = ext if self.is_chain else 0
 
     def execute(self):
         """One execution of the whole chain (asynchronous on ``self.stream``)."""

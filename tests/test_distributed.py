@@ -123,7 +123,7 @@ def test_decomposed_chain_protocol_gloo(tmp_path, world, fuse):
     _spawn(_chain_worker, world, (18, 6, 8), 5, fuse, str(tmp_path))
 
 
-def _gpu_worker(rank, world, port, shape, stages, overlap):
+def _gpu_worker(rank, world, port, shape, stages, overlap, groups):
     import torch
     sys.path.insert(0, ROOT)
     import stencilflow_amd as sf
@@ -142,7 +142,7 @@ def _gpu_worker(rank, world, port, shape, stages, overlap):
     runner = SlabRunner(sfir, shape, rank, world, device=0,
                         exchanger=TorchDistExchanger(rank, world,
                                                      staging="host"),
-                        overlap=overlap)
+                        overlap=overlap, groups_per_exchange=groups)
     runner.upload([x[runner.lo:runner.hi]])
     runner.execute()
     runner.synchronize()
@@ -156,8 +156,8 @@ def _gpu_worker(rank, world, port, shape, stages, overlap):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("overlap", [True, False])
-def test_two_processes_one_gpu_host_staged(overlap):
+@pytest.mark.parametrize("overlap,groups", [(True, 4), (False, 4), (True, 1)])
+def test_two_processes_one_gpu_host_staged(overlap, groups):
     """Two ranks (processes) drive their slabs on the same GPU; halos travel
     through gloo.  Everything but the RCCL transport itself is exercised."""
-    _spawn(_gpu_worker, 2, (36, 20, 64), 6, overlap)
+    _spawn(_gpu_worker, 2, (36, 20, 64), 9, overlap, groups)

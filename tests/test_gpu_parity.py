@@ -274,24 +274,27 @@ def test_full_size_properties():
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("overlap", [True, False])
-def test_slab_decomposition_in_process(tmp_path, world, overlap):
+@pytest.mark.parametrize("groups", [1, 2, 4])
+def test_slab_decomposition_in_process(tmp_path, world, overlap, groups):
     """Slab-decomposed execution (one plan per rank, halos copied between the
     ranks' device buffers by the driver) equals the undivided run bit for bit.
     All ranks share this GPU; the transport is the only part not covered."""
     from stencilflow_amd.distributed import (LocalExchanger, SlabRunner,
                                              run_lockstep, slab_bounds)
     from stencilflow_amd.lowering import lower
-    shape, stages = (40, 24, 64), 6
+    shape, stages = (52, 24, 64), 11
     rng = np.random.default_rng(SEED + 7)
     x = rng.uniform(-1, 1, shape).astype(np.float32)
     prog = programs.jacobi3d(shape, stages, bc_value=0.5)
     path = _write(tmp_path, prog)
-    want = npo.run_reference(prog, {"a": x})["b5"]
+    want = npo.run_reference(prog, {"a": x})["b10"]
     sfir = lower(sf.KernelChainGraph(path))
     exch = LocalExchanger(world)
     runners = [SlabRunner(sfir, shape, r, world, options={"fuse": 2},
-                          exchanger=exch.for_rank(r), overlap=overlap)
+                          exchanger=exch.for_rank(r), overlap=overlap,
+                          groups_per_exchange=groups)
                for r in range(world)]
+    assert runners[0].is_chain and runners[0].halo == 2 * groups
     for r in runners:
         r.upload([x[r.lo:r.hi]])
     run_lockstep(runners)
@@ -316,3 +319,52 @@ def test_long_chain(tmp_path):
     got, desc = _run_gpu(path, {"a": x})
     assert "150 launches" in desc and "4 device buffers" in desc
     assert np.array_equal(got["b299"], want)
+
+
+def test_slab_dag_program_in_process(tmp_path):
+    """A DAG (two inputs, fan-out, generic kernels) under slab decomposition:
+    every slab-split field a launch reads across planes is exchanged."""
+    from stencilflow_amd.distributed import (LocalExchanger, SlabRunner,
+                                             run_lockstep)
+    from stencilflow_amd.lowering import lower
+    shape = (20, 12, 16)
+    prog = {
+        "inputs": {"a": {"data": "constant:1.0", "data_type": "float32"},
+                   "w": {"data": "constant:1.0", "data_type": "float64"}},
+        "outputs": ["e", "d"],
+        "dimensions": list(shape),
+        "program": {
+            "b": {"computation_string": "b = a[i-1,j,k] + w[i+2,j,k-1] * 0.5",
+                  "boundary_conditions": {"a": {"type": "constant", "value": 1.0},
+                                          "w": {"type": "constant", "value": -1.0}},
+                  "data_type": "float64"},
+            "d": {"computation_string": "d = b[i,j+1,k+1] * a[i,j,k] - b[i+1,j,k]",
+                  "boundary_conditions": {"b": {"type": "constant", "value": 0.25}},
+                  "data_type": "float32"},
+            "e": {"computation_string": "e = d[i-1,j,k] + b[i,j,k] + w[i,j,k]",
+                  "boundary_conditions": {"d": {"type": "constant", "value": 2.0}},
+                  "data_type": "float64"}}}
+    rng = np.random.default_rng(SEED + 9)
+    a = rng.uniform(-1, 1, shape).astype(np.float32)
+    w = rng.uniform(-1, 1, shape)
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, {"a": a, "w": w})
+    sfir = lower(sf.KernelChainGraph(path))
+    world = 2
+    exch = LocalExchanger(world)
+    runners = [SlabRunner(sfir, shape, r, world, exchanger=exch.for_rank(r))
+               for r in range(world)]
+    assert not runners[0].is_chain
+    for r in runners:
+        r.upload([a[r.lo:r.hi], w[r.lo:r.hi]])
+    run_lockstep(runners)
+    got_e = np.zeros(shape, np.float64)
+    got_d = np.zeros(shape, np.float32)
+    for r in runners:
+        pe = np.zeros(r.local_shape, np.float64)
+        pd = np.zeros(r.local_shape, np.float32)
+        outs = {"e": pe, "d": pd}
+        r.download([outs[n] for n in r.plan.output_names])
+        got_e[r.lo:r.hi], got_d[r.lo:r.hi] = pe, pd
+        r.close()
+    assert np.array_equal(got_d, want["d"]) and np.array_equal(got_e, want["e"])
