@@ -143,3 +143,148 @@ def write_program(program, path):
     with open(path, "w") as f:
         json.dump(program, f, indent=1)
     return path
+
+
+def _offset_text(iterator, value):
+    if value > 0:
+        return "{}+{}".format(iterator, value)
+    if value < 0:
+        return "{}-{}".format(iterator, -value)
+    return iterator
+
+
+def synthesize(data_type,
+               num_stages,
+               num_fields_spatial,
+               size_x,
+               size_y,
+               size_z,
+               extent_x,
+               extent_y,
+               extent_z,
+               fork_frequency=0.0,
+               fork_length_left=2,
+               fork_length_right=2,
+               stencil_shape="cross",
+               vectorize=1):
+    """Synthetic program generator with the parameters and output conventions of
+    the reference's bin/synthesize.py (:34-294): a chain of `num_stages`
+    stencils `b0..` over input `a`, optional extra input fields per stage,
+    optional fork/join sections, shapes cross | box | diffusion | hotspot.
+    Returns (program dict, canonical file name)."""
+    sizes = [size_x, size_y, size_z]
+    extents = [extent_x, extent_y, extent_z]
+    shape = [s for s in sizes if s > 0]
+    nd = len(shape)
+    iterators = ["i", "j", "k"][3 - nd:]
+
+    per_dim = []
+    for size, extent in list(zip(sizes, extents))[:nd]:
+        if extent == 0:
+            per_dim.append([0])
+        elif stencil_shape == "box":
+            per_dim.append(list(range(-extent, extent + 1)))
+        else:
+            per_dim.append([o for o in range(-extent, extent + 1) if o != 0])
+    offsets = []
+    if stencil_shape == "box":
+        def rec(d, cur):
+            if d == nd:
+                offsets.append(tuple(cur))
+                return
+            for o in per_dim[d]:
+                rec(d + 1, cur + [o])
+        rec(0, [])
+    else:
+        if stencil_shape in ("diffusion", "hotspot"):
+            offsets.append(tuple([0] * nd))
+        for d in range(nd):
+            for o in per_dim[d]:
+                offsets.append(tuple(o if e == d else 0 for e in range(nd)))
+    index_texts = [", ".join(_offset_text(it, o) for it, o in zip(iterators, off))
+                   for off in offsets]
+
+    program = {
+        "inputs": {"a": {"data": "constant:1", "data_type": data_type,
+                         "input_dims": list(iterators)}},
+        "outputs": [],
+        "program": {},
+        "dimensions": shape,
+        "vectorization": vectorize,
+    }
+    state = {"fields": 1, "credit": 0.0}
+
+    def expression(name, fields):
+        if stencil_shape == "hotspot":
+            f = fields[0]
+            power = "power" if state["fields"] - 1 == 0 else "power{}".format(state["fields"] - 1)
+            if nd == 3:
+                return ("{n} = cc * {f}[i, j, k] + cn * {f}[i, j-1, k] + cs * {f}[i, j+1, k] + "
+                        "cw * {f}[i, j, k-1] + ce * {f}[i, j, k+1] + ca * {f}[i-1, j, k] + "
+                        "cb * {f}[i+1, j, k] + sdc * {p}[i, j, k] + ca * amb").format(n=name, f=f, p=power)
+            if nd == 2:
+                return ("{n} = {f}[j, k] + sdc * ({p}[j, k] + "
+                        "({f}[j-1, k] + {f}[j+1, k] - 2.0 * {f}[j, k]) * r_y + "
+                        "({f}[j, k-1] + {f}[j, k+1] - 2.0 * {f}[j, k]) * r_x + "
+                        "(amb - {f}[j, k]) * r_z)").format(n=name, f=f, p=power)
+            raise ValueError("Unsupported number of indices for hotspot.")
+        operands = ["{}[{}]".format(f, ix) for f in fields for ix in index_texts]
+        if stencil_shape == "diffusion":
+            return "{} = {}".format(name, " + ".join(
+                "c{}*{}".format(i, o) for i, o in enumerate(operands)))
+        return "{} = {}*({})".format(name, 1 / len(operands), " + ".join(operands))
+
+    def add_stencil(sources, name):
+        extra = []
+        state["credit"] += num_fields_spatial
+        if state["credit"] >= 1:
+            while state["credit"] >= 1:
+                prefix = "power" if stencil_shape == "hotspot" else "a"
+                field = "{}{}".format(prefix, state["fields"])
+                extra.append(field)
+                program["inputs"][field] = {"data": "constant:0.5", "data_type": data_type}
+                state["fields"] += 1
+                state["credit"] -= 1
+        elif stencil_shape == "hotspot":
+            extra.append("power" if state["fields"] - 1 < 1 else "power{}".format(state["fields"] - 1))
+        fields = list(sources) + extra
+        program["program"][name] = {
+            "data_type": data_type,
+            "boundary_conditions": {f: {"type": "constant", "value": 0} for f in fields},
+            "computation_string": expression(name, fields),
+        }
+
+    previous, joins, fork_credit, name = "a", [], 0.0, "a"
+    for stage in range(num_stages):
+        name = "b{}".format(stage)
+        add_stencil(joins if joins else [previous], name)
+        joins = []
+        fork_credit += fork_frequency
+        if stage < num_stages - 1 and fork_credit >= 1:
+            for tag, length in (("a", fork_length_left), ("b", fork_length_right)):
+                tail = name
+                for i in range(length):
+                    branch = "{}{}{}".format(name, tag, i)
+                    add_stencil([tail], branch)
+                    tail = branch
+                joins.append(tail)
+            fork_credit = 0.0
+        previous = name
+
+    scalars = []
+    if stencil_shape == "hotspot":
+        program["inputs"]["power"] = {"data": "constant:0.5", "data_type": data_type}
+        scalars = (["sdc", "r_x", "r_y", "r_z", "amb"] if nd == 2 else
+                   ["cc", "cn", "cs", "cw", "ce", "ca", "cb", "sdc", "amb"])
+        if nd not in (2, 3):
+            raise NotImplementedError
+    elif stencil_shape == "diffusion":
+        scalars = ["c{}".format(i) for i in range(len(index_texts))]
+    for s in scalars:
+        program["inputs"][s] = {"data": "constant:0.5", "data_type": data_type, "input_dims": []}
+    program["outputs"].append(name)
+
+    args = [data_type, num_stages, num_fields_spatial, size_x, size_y, size_z, extent_x, extent_y,
+            extent_z, fork_frequency, fork_length_left, fork_length_right, stencil_shape, vectorize]
+    filename = "_".join(map(str, args)).replace(".", "p") + ".json"
+    return program, filename

@@ -160,3 +160,29 @@ def test_thousand_stage_chain_is_linear_time(tmp_path):
     assert len(chain.kernel_nodes) == 1000 and text.count("\nkernel ") == 1000
     assert chain.cell_updates() == 512**3 * 1000
     assert chain.algorithmic_bytes() == 512**3 * 1000 * 8
+
+
+def test_synthesize_conventions():
+    """Own workload generator follows bin/synthesize.py's conventions (checked
+    against the reference generator's output when this was written: identical
+    JSON for cross / box / diffusion / hotspot, forks, fractional extra fields)."""
+    from stencilflow_amd.programs import synthesize
+    prog, name = synthesize("float32", 3, 0, 16, 16, 32, 1, 1, 1)
+    assert name == "float32_3_0_16_16_32_1_1_1_0p0_2_2_cross_1.json"
+    assert prog["dimensions"] == [16, 16, 32] and prog["outputs"] == ["b2"]
+    assert prog["program"]["b1"]["computation_string"] == (
+        "b1 = 0.16666666666666666*(b0[i-1, j, k] + b0[i+1, j, k] + "
+        "b0[i, j-1, k] + b0[i, j+1, k] + b0[i, j, k-1] + b0[i, j, k+1])")
+    assert prog["program"]["b0"]["boundary_conditions"] == {
+        "a": {"type": "constant", "value": 0}}
+    prog, _ = synthesize("float64", 4, 0.5, 64, 64, 0, 2, 1, 0,
+                         fork_frequency=0.5, stencil_shape="box")
+    assert set(prog["program"]) == {"b0", "b1", "b1a0", "b1a1", "b1b0", "b1b1",
+                                    "b2", "b3", "b3a0"} - {"b3a0"}
+    assert "a1" in prog["inputs"] and prog["program"]["b2"][
+        "boundary_conditions"].keys() >= {"b1a1", "b1b1"}
+    prog, _ = synthesize("float32", 2, 0, 8, 8, 8, 1, 1, 1,
+                         stencil_shape="diffusion")
+    assert prog["inputs"]["c6"]["input_dims"] == []
+    assert prog["program"]["b0"]["computation_string"].startswith(
+        "b0 = c0*a[i, j, k] + c1*a[i-1, j, k]")

@@ -368,3 +368,121 @@ def test_slab_dag_program_in_process(tmp_path):
         got_e[r.lo:r.hi], got_d[r.lo:r.hi] = pe, pd
         r.close()
     assert np.array_equal(got_d, want["d"]) and np.array_equal(got_e, want["e"])
+
+
+def test_full_size_jacobi2d_properties():
+    """BASELINE configs[1] size (4096 x 4096 f32): fused == unfused bit for bit,
+    symmetry of the constant-input solution, corner block against the oracle."""
+    import tempfile
+    n, stages = 4096, 12
+    prog = programs.jacobi2d((n, n), stages)
+    x = np.ones((n, n), np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = programs.write_program(prog, os.path.join(tmp, "c2.json"))
+        fused, desc = _run_gpu(path, {"a": x}, options={"fuse": 4})
+        unfused, _ = _run_gpu(path, {"a": x}, options={"fuse": 1})
+    assert "star2d" in desc and "T=4" in desc
+    out = fused["b11"]
+    assert np.array_equal(out, unfused["b11"])
+    assert np.array_equal(out, out.T) and np.array_equal(out, out[::-1])
+    assert np.array_equal(out, out[:, ::-1])
+    assert 0.0 <= out.min() and out.max() <= 1.0
+    m = 64
+    ref = npo.run_reference(programs.jacobi2d((m, m), stages),
+                            {"a": np.ones((m, m), np.float32)})["b11"]
+    c = m - stages - 1
+    assert np.array_equal(out[:c, :c], ref[:c, :c])
+
+
+def test_full_size_three_operator_chain_properties():
+    """BASELINE configs[4] size (512^3 f64): the chain fused into ONE launch
+    equals the three separate launches bit for bit; a corner block with random
+    data equals the oracle."""
+    import tempfile
+    n = 512
+    prog = programs.diffusion_advection_laplacian((n, n, n))
+    rng = np.random.default_rng(SEED + 10)
+    x = rng.random((n, n, n))
+    ins = _inputs_of(prog)
+    ins["a"] = x
+    with tempfile.TemporaryDirectory() as tmp:
+        path = programs.write_program(prog, os.path.join(tmp, "c5.json"))
+        fused, desc = _run_gpu(path, ins)
+        assert "1 launches" in desc and "T=3" in desc and "f64" in desc
+        split, desc1 = _run_gpu(path, ins, options={"fuse": 1})
+        assert "3 launches" in desc1
+    assert np.array_equal(fused["lap"], split["lap"])
+    del split
+    m = 24
+    small = programs.diffusion_advection_laplacian((m, m, m))
+    sins = _inputs_of(small)
+    sins["a"] = np.ascontiguousarray(x[:m, :m, :m])
+    ref = npo.run_reference(small, inputs=sins)["lap"]
+    c = m - 4
+    assert np.array_equal(fused["lap"][:c, :c, :c], ref[:c, :c, :c])
+
+
+def test_copy_boundary_condition(tmp_path):
+    """`copy`: out-of-domain reads take the centre value (the FPGA expansions'
+    semantics, reference stencil/intel_fpga.py:225-227; the reference's CPU
+    path raises NameError for it, stencil/cpu.py:87 -- so this is checked
+    against a direct NumPy statement of that rule, not against the oracle)."""
+    shape = (6, 10, 16)
+    prog = programs.jacobi3d(shape, 1)
+    prog["program"]["b0"]["boundary_conditions"]["a"] = {"type": "copy"}
+    rng = np.random.default_rng(SEED + 11)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    path = _write(tmp_path, prog)
+    got, desc = _run_gpu(path, {"a": x})
+    assert "point" in desc
+    xd = x.astype(np.float64)
+
+    def nb(axis, off):
+        sh = np.roll(xd, -off, axis=axis)
+        idx = [slice(None)] * 3
+        idx[axis] = slice(-1, None) if off > 0 else slice(0, 1)
+        sh[tuple(idx)] = xd[tuple(idx)]  # out of domain -> centre value
+        return sh
+
+    s = nb(0, -1) + nb(0, 1)
+    s = s + nb(1, -1)
+    s = s + nb(1, 1)
+    s = s + nb(2, -1)
+    s = s + nb(2, 1)
+    want = (0.16666666 * s).astype(np.float32)
+    # every access of this kernel has a BC select, so all operands are float
+    # (copy keeps the field type): the sum is accumulated in float32
+    xs = x
+    def nbf(axis, off):
+        sh = np.roll(xs, -off, axis=axis)
+        idx = [slice(None)] * 3
+        idx[axis] = slice(-1, None) if off > 0 else slice(0, 1)
+        sh[tuple(idx)] = xs[tuple(idx)]
+        return sh
+    sf32 = ((((nbf(0, -1) + nbf(0, 1)) + nbf(1, -1)) + nbf(1, 1)) + nbf(2, -1)) + nbf(2, 1)
+    want32 = (0.16666666 * sf32.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got["b0"], want32), npo.max_rel_err(want, got["b0"])
+
+
+@pytest.mark.parametrize("args,kwargs", [
+    (("float32", 4, 0, 12, 20, 32, 1, 1, 1), {}),
+    (("float32", 3, 0, 10, 12, 16, 1, 1, 1), {"stencil_shape": "diffusion"}),
+    (("float64", 3, 1, 40, 36, 0, 2, 1, 0), {"stencil_shape": "box"}),
+    (("float32", 5, 0.5, 24, 32, 0, 1, 2, 0), {"fork_frequency": 0.5,
+                                              "fork_length_left": 1,
+                                              "fork_length_right": 2}),
+    (("float64", 3, 0, 8, 12, 16, 1, 1, 1), {"stencil_shape": "hotspot"}),
+    (("float32", 3, 0.4, 28, 40, 0, 1, 1, 0), {"stencil_shape": "hotspot"}),
+    (("float32", 6, 0, 200, 0, 0, 3, 0, 0), {}),
+])
+def test_synthesized_programs(tmp_path, args, kwargs):
+    """Programs from the workload generator (the reference's bin/synthesize.py
+    conventions): cross / box / diffusion / hotspot shapes, extra input fields,
+    forks and joins, 1-D to 3-D -- random array inputs, oracle comparison."""
+    prog, name = programs.synthesize(*args, **kwargs)
+    path = _write(tmp_path, prog, name[:-5])
+    ins = _inputs_of(path, None, np.random.default_rng(SEED + 12))
+    want = npo.run_reference(path, inputs=ins)
+    got, _ = _run_gpu(path, ins)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), (name, k, npo.max_rel_err(want[k], got[k]))
