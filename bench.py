@@ -29,11 +29,11 @@ HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
 SEED = 20261003
 
 
-def synthetic(shape, rank=0):
+def synthetic(shape, rank=0, dtype=np.float32):
     """Uniform random grid (timing on constant data flatters the clock:
     cdna_hip_programming.md §5.4 rule 25)."""
     rng = np.random.default_rng(SEED + rank)
-    return rng.random(shape, dtype=np.float32)
+    return rng.random(shape, dtype=dtype)
 
 
 def measured_traffic(kernel):
@@ -84,7 +84,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3",
+                    help="c3 = jacobi3d 512^3 f32 (headline, default); c2 = "
+                    "jacobi2d 4096^2 f32; c5 = diffusion/advection/laplacian "
+                    "512^3 f64 (own records; single GPU only)")
+    ap.add_argument("--size", type=int, default=0)
     ap.add_argument("--stages", type=int, default=1000)
     ap.add_argument("--options", type=str, default="")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,9 +110,30 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
 
-    n = args.size
-    shape = (n * world, n, n)
-    prog = programs.jacobi3d(shape, args.stages)
+    if args.workload != "c3" and world > 1:
+        raise SystemExit("only the c3 workload is slab-decomposed by bench.py")
+    if args.workload == "c3":
+        n = args.size or 512
+        shape = (n * world, n, n)
+        prog = programs.jacobi3d(shape, args.stages)
+        np_dtype, dtype_name, bpu = np.float32, "f32", 8.0
+        label = ("jacobi3d {}x{}x{} float32, {}-operator chain, constant BC 0.0, "
+                 "coefficient 0.16666666").format(shape[0], shape[1], shape[2], args.stages)
+    elif args.workload == "c2":
+        n = args.size or 4096
+        shape = (n, n)
+        prog = programs.jacobi2d(shape, args.stages)
+        np_dtype, dtype_name, bpu = np.float32, "f32", 8.0
+        label = "jacobi2d {}x{} float32, {}-operator chain, constant BC 0.0".format(
+            n, n, args.stages)
+    else:
+        n = args.size or 512
+        shape = (n, n, n)
+        args.stages = max(3, args.stages // 3 * 3)
+        prog = programs.diffusion_advection_laplacian(shape, repeats=args.stages // 3)
+        np_dtype, dtype_name, bpu = np.float64, "f64", 16.0
+        label = ("diffusion->advection->laplacian {}^3 float64, {} operators "
+                 "({} chain applications), constant BC 0.0").format(n, args.stages, args.stages // 3)
     options = {k: v for k, v in (kv.split("=") for kv in args.options.split(";") if kv)}
 
     with tempfile.TemporaryDirectory() as tmp:
@@ -132,7 +157,10 @@ def main():
             dist.barrier()
     else:
         plan = Plan(sfir, device=local_rank, options=options)
-        plan.upload([synthetic(shape)])
+        scalar_values = [chain.inputs[k]["data"] for k in plan.scalar_names]
+        if scalar_values:
+            plan.set_scalars(scalar_values)
+        plan.upload([synthetic(shape, dtype=np_dtype)])
 
         def step():
             plan.execute(1)
@@ -164,7 +192,8 @@ def main():
     cells = float(np.prod(shape)) * args.stages * args.steps
     result = {
         "metric": "Mcells/s (updates) and achieved HBM GB/s vs roofline, "
-                  "jacobi3d 512^3 f32",
+                  "jacobi3d 512^3 f32" if args.workload == "c3" else
+                  "Mcells/s (updates) and achieved HBM GB/s vs roofline, " + args.workload,
         "value": cells / elapsed / 1e6,
         "unit": "Mcells/s",
         "n_gpus": world,
@@ -174,12 +203,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": dtype_name,
         "data": "synthetic (uniform random [0,1), seed %d)" % SEED,
         "config": {
-            "workload": "jacobi3d {}x{}x{} float32, {}-operator chain, "
-                        "constant BC 0.0, coefficient 0.16666666".format(
-                            shape[0], shape[1], shape[2], args.stages),
+            "workload": label,
             "decomposition": "slab{}".format(world) if world > 1 else "single",
         },
     }
@@ -187,7 +214,7 @@ def main():
         stats = plan.kernel_stats()
         launches = plan.num_launches * args.steps
         name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"])
-        alg = cells * 8.0 / launches  # 2 * sizeof(f32) per cell update
+        alg = cells * bpu / launches  # 2 * sizeof(dtype) per cell update
         avg_s = kernel_ms * 1e-3 / launches
         achieved = alg / avg_s
         result["roofline"] = {
@@ -203,7 +230,7 @@ def main():
             "launches": launches,
         }
         result["config"]["schedule"] = plan.describe().splitlines()[1].strip()
-        if not args.no_cpu_baseline and rank == 0:
+        if not args.no_cpu_baseline and rank == 0 and args.workload == "c3":
             result["cpu_baseline"] = cpu_baseline(shape, budget_s=args.cpu_seconds)
     if rank == 0:
         print(json.dumps(result), flush=True)
