@@ -113,6 +113,10 @@ int sf_plan_kernel_stats(sf_plan* plan, int index, int* launches,
 int sf_plan_kernel_resources(const sf_plan* plan, int index, int* vgprs,
                              int* agprs, int* vgpr_spills, int* scratch_bytes,
                              int* lds_bytes);
+/* Diagnostic builds only (option "stamp=1"): read and clear the in-kernel cycle
+ * counters of the star kernel (publish+barrier, stage 1, load issue, later
+ * stages, wave count; summed over waves and launches). */
+int sf_plan_debug_counters(sf_plan* plan, unsigned long long* out, int count);
 /* Human-readable description of the schedule (groups, tiles, buffers). */
 const char* sf_plan_describe(const sf_plan* plan);
 

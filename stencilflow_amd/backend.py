@@ -65,6 +65,7 @@ API = [
     ("sf_plan_kernel_source", _S, [_P, _I]),
     ("sf_plan_kernel_stats", _I, [_P, _I, _IP, _DP, _DP, _DP]),
     ("sf_plan_kernel_resources", _I, [_P, _I, _IP, _IP, _IP, _IP, _IP]),
+    ("sf_plan_debug_counters", _I, [_P, ctypes.POINTER(ctypes.c_ulonglong), _I]),
     ("sf_plan_describe", _S, [_P]),
     ("sf_plan_num_steps", _I, [_P]),
     ("sf_plan_step_halo", _I, [_P, _I, _IP, _IP]),
@@ -216,6 +217,11 @@ class Plan:
             out[name] = dict(zip(("vgprs", "agprs", "spills", "scratch", "lds"),
                                  [x.value for x in v]))
         return out
+
+    def debug_counters(self, count=5):
+        buf = (ctypes.c_ulonglong * 8)()
+        _check(self._lib.sf_plan_debug_counters(self._h, buf, count))
+        return [buf[i] for i in range(count)]
 
     def input_bytes(self, i):
         return self._lib.sf_plan_input_bytes(self._h, i)

@@ -58,9 +58,13 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 // phase PH the slots hold  prev = PH % 3,  cur = (PH + 1) % 3,  next = (PH + 2) % 3.
 struct sf_state {
   sf_vec w[SF_T][3][SF_RJ];
+#if SF_PREFETCH2
+  sf_vec pf[SF_RJ];  // input plane in flight (p+2): a full step to land
+#endif
 };
 
 struct sf_ctx {
+  const sf_t* in;
   int tx, ty, lane, wave;
   unsigned jmask, kmask, store_mask;
   bool kvec_in;
@@ -74,18 +78,53 @@ __device__ __forceinline__ int sf_edge_at(int s, int ty, int r, int w, int side)
   return SF_ROWS_ELEMS + ((((s * SF_BY + ty) * SF_RJ + r) * SF_WPR + w) * 2 + side);
 }
 
+// Value of the adjacent lane (lane-1 for DOWN = false ... see callers) through the
+// DPP data path (v_mov_b32_dpp wave_shr:1 / wave_shl:1 on gfx9): one VALU move,
+// no trip through the LDS crossbar that __shfl_up/__shfl_down (ds_bpermute) take.
+template <bool FROM_LOWER, typename T>
+__device__ __forceinline__ T sf_neighbour_lane(T x) {
+#if SF_DPP
+  constexpr int ctrl = FROM_LOWER ? 0x138 /* wave_shr:1 */ : 0x130 /* wave_shl:1 */;
+  if constexpr (sizeof(T) == 4) {
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false));
+  } else {
+    const long long v = __builtin_bit_cast(long long, x);
+    const int lo = (int)(v & 0xffffffffll), hi = (int)(v >> 32);
+    const int rlo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false);
+    const int rhi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);
+    return __builtin_bit_cast(T, ((long long)rhi << 32) | (unsigned int)rlo);
+  }
+#else
+  return FROM_LOWER ? __shfl_up(x, 1) : __shfl_down(x, 1);
+#endif
+}
+
+// Row r of input plane p (padded with stage 1's boundary constant outside the
+// global domain).
+__device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, const int r) {
+  sf_vec v = (sf_vec)sf_stage<1>::bc();
+  const bool plane_in = (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
+  if (plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in) {
+    const sf_t* plane = cx.in + (size_t)(p + cx.halo) * ((size_t)SF_N1 * SF_N2);
+    v = *reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0));
+  }
+  return v;
+}
+
 // One stage of the fused group at one step: reads the source window of stage
 // S-1 at phase PH and writes plane q = p - S of stage S (into its own window, or
 // to HBM for the last stage).
 template <int S, int PH>
 __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, const sf_scalars& sc,
-                                              sf_t* __restrict__ out, const sf_ctx& cx, const int p) {
+                                              sf_t* __restrict__ out, const sf_ctx& cx, const int p,
+                                              const bool load_next = false) {
   constexpr int src = S - 1;
   constexpr int iprev = PH % 3, icur = (PH + 1) % 3, inext = (PH + 2) % 3;
   const int tx = cx.tx, ty = cx.ty;
   // first / last row of the neighbouring thread rows (LDS)
   sf_vec jm0 = st.w[src][icur][0], jpl = st.w[src][icur][SF_RJ - 1];
-  if constexpr (!SF_NOJ) {
+  if constexpr (!SF_NOJ && SF_EXPERIMENT != 4) {
     if (ty > 0)
       jm0 = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(src, ty - 1, 1) + tx * SF_VK]);
     if (ty < SF_BY - 1)
@@ -104,13 +143,14 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
     const sf_vec ip = st.w[src][inext][r];
     const sf_vec jp = (r < SF_RJ - 1) ? st.w[src][icur][r < SF_RJ - 1 ? r + 1 : r] : jpl;
     // innermost-dimension halo: adjacent lanes hold the adjacent vectors
-    sf_t km_e = __shfl_up(c[SF_VK - 1], 1);
-    sf_t kp_e = __shfl_down(c[0], 1);
-    if (cx.lane == 0)
+    // SF_EXPERIMENT 3: timing-only build without the lane exchange (invalid results)
+    sf_t km_e = (SF_EXPERIMENT == 3) ? c[SF_VK - 1] : sf_neighbour_lane<true>(c[SF_VK - 1]);
+    sf_t kp_e = (SF_EXPERIMENT == 3) ? c[0] : sf_neighbour_lane<false>(c[0]);
+    if (SF_EXPERIMENT != 3 && cx.lane == 0)
       km_e = (SF_WPR > 1 && cx.wave > 0)
                  ? lds[sf_edge_at(src, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]
                  : sf_stage<S>::bc();
-    if (cx.lane == 63)
+    if (SF_EXPERIMENT != 3 && cx.lane == 63)
       kp_e = (SF_WPR > 1 && cx.wave < SF_WPR - 1)
                  ? lds[sf_edge_at(src, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]
                  : sf_stage<S>::bc();
@@ -122,9 +162,26 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       o[v] = sf_stage<S>::apply(c[v], im[v], ip[v], jm[v], jp[v], km, kp, sc);
     }
     jm = c;
+#if SF_PREFETCH2
+    if constexpr (S == 1) {
+      // row r of the input window's "prev" slot is dead now: it takes row r of
+      // plane p+1 from the staging registers (loaded during the previous step),
+      // which then receive row r of plane p+2
+      st.w[0][iprev][r] = st.pf[r];
+      if (load_next) st.pf[r] = sf_load_row(cx, p + 2, r);
+    }
+#elif SF_SPREAD_LOADS
+    if constexpr (S == 1) {
+      // row r of the input window's "prev" slot is dead now: it receives row r of
+      // input plane p+1 -- loads are spread over stage 1 instead of issued in a burst
+      if (load_next) st.w[0][iprev][r] = sf_load_row(cx, p + 1, r);
+    }
+#endif
     if constexpr (S == SF_T) {
       // last stage of the group: write interior, in-domain points
-      if (store_plane && ((cx.store_mask >> r) & 1u)) {
+      // SF_EXPERIMENT 1: timing-only build without the output stores (invalid results)
+      if (SF_EXPERIMENT == 1) asm volatile("" ::"v"(o));
+      if (SF_EXPERIMENT != 1 && store_plane && ((cx.store_mask >> r) & 1u)) {
         // wave-uniform plane base (SGPR pair) + 32-bit in-plane offset
         sf_t* plane = out + (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2);
         *reinterpret_cast<sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)) = o;
@@ -167,10 +224,31 @@ __device__ __forceinline__ void sf_load_plane(const sf_t* __restrict__ in, const
 }
 
 // One step (input plane p) at phase PH.
+#if SF_STAMP
+// Diagnostic build only (option stamp=1): where a step spends its cycles.
+// acc[0] publish + barrier, [1] stage 1 (incl. wait for the input plane),
+// [2] issue of the next plane's loads, [3] later stages.
+#define SF_STAMP_AT(i)                                                              \
+  do {                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    unsigned long long t_;                                                          \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    acc[i] += t_ - t_prev;                                                          \
+    t_prev = t_;                                                                    \
+  } while (0)
+#define SF_STAMP_ARGS , unsigned long long (&acc)[4], unsigned long long& t_prev
+#define SF_STAMP_PASS , acc, t_prev
+#else
+#define SF_STAMP_AT(i)
+#define SF_STAMP_ARGS
+#define SF_STAMP_PASS
+#endif
+
 template <int PH>
 __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __restrict__ in,
                                         sf_t* __restrict__ out, const sf_scalars& sc,
-                                        const sf_ctx& cx, const int p, const int p_end) {
+                                        const sf_ctx& cx, const int p, const int p_end SF_STAMP_ARGS) {
   constexpr int icur = (PH + 1) % 3;
   // Make the window opaque at the step boundary: otherwise the compiler keeps
   // the f64 conversions of whole planes alive from one unrolled step to the
@@ -186,7 +264,7 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
   // publish the rows / columns other threads need of every stage's current plane
 #pragma unroll
   for (int s = 0; s < SF_T; ++s) {
-    if constexpr (!SF_NOJ) {
+    if constexpr (!SF_NOJ && SF_EXPERIMENT != 4) {
       *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(s, cx.ty, 0) + cx.tx * SF_VK]) = st.w[s][icur][0];
       *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(s, cx.ty, 1) + cx.tx * SF_VK]) =
           st.w[s][icur][SF_RJ - 1];
@@ -203,22 +281,41 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
       }
     }
   }
-  if (SF_USE_LDS) __syncthreads();
-  // stage 1 consumes input plane p (slot "next" of the input window) ...
+  // SF_EXPERIMENT 2/4: timing-only builds without the barrier (invalid results)
+  if (SF_USE_LDS && SF_EXPERIMENT != 2 && SF_EXPERIMENT != 4) __syncthreads();
+  SF_STAMP_AT(0);
+  // stage 1 consumes input plane p (slot "next" of the input window) and frees
+  // slot "prev", which receives input plane p+1
+#if SF_PREFETCH2
+  sf_stage_step<1, PH>(st, lds, sc, out, cx, p, p + 2 < p_end);
+  SF_STAMP_AT(1);
+#elif SF_SPREAD_LOADS
+  sf_stage_step<1, PH>(st, lds, sc, out, cx, p, p + 1 < p_end);
+  SF_STAMP_AT(1);
+#else
   sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
-  // ... and frees slot "prev", which receives input plane p+1 while later stages run
+  SF_STAMP_AT(1);
   if (p + 1 < p_end) sf_load_plane(in, cx, p + 1, st.w[0][PH % 3]);
+#endif
+  SF_STAMP_AT(2);
   sf_later_stages<2, PH>(st, lds, sc, out, cx, p);
   if (SF_USE_LDS && !SF_LDS_DB) __syncthreads();
+  SF_STAMP_AT(3);
 }
 
 extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, int halo,
-                   int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2) {
+                   int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2
+#if SF_STAMP
+                   ,
+                   unsigned long long* dbg
+#endif
+    ) {
   // SF_LDS_DB: two exchange images used alternately -> one barrier per step
   __shared__ sf_t lds_all[(SF_LDS_DB ? 2 : 1) * SF_IMAGE_ELEMS];
 
   sf_ctx cx;
+  cx.in = in;
   cx.tx = threadIdx.x;
   cx.ty = threadIdx.y;
   cx.lane = cx.tx & 63;
@@ -279,19 +376,32 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 
   const int p_begin = cx.cb - SF_T, p_end = cx.ce + SF_T;
   sf_load_plane(in, cx, p_begin, st.w[0][2]);  // slot "next" of phase 0
+#if SF_PREFETCH2
+  if (p_begin + 1 < p_end) sf_load_plane(in, cx, p_begin + 1, st.pf);
+#endif
 
   // Two exchange images alternate every step (run-time offset); the window
   // phase cycles with period 3 (compile-time slot indices).
   int image = 0;
+#if SF_STAMP
+  unsigned long long acc[4] = {0, 0, 0, 0}, t_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
   // the trip always runs three steps: up to two surplus steps past p_end
   // compute planes nobody stores (loads and stores are range-guarded), which
   // keeps the loop body free of control flow between the phases
   for (int p = p_begin; p < p_end; p += 3) {
-    sf_step<0>(st, lds_all + image, in, out, sc, cx, p, p_end);
+    sf_step<0>(st, lds_all + image, in, out, sc, cx, p, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
-    sf_step<1>(st, lds_all + image, in, out, sc, cx, p + 1, p_end);
+    sf_step<1>(st, lds_all + image, in, out, sc, cx, p + 1, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
-    sf_step<2>(st, lds_all + image, in, out, sc, cx, p + 2, p_end);
+    sf_step<2>(st, lds_all + image, in, out, sc, cx, p + 2, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
   }
+#if SF_STAMP
+  if (cx.lane == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&dbg[i], acc[i]);
+    atomicAdd(&dbg[4], 1ull);
+  }
+#endif
 }

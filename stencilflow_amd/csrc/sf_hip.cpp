@@ -108,6 +108,7 @@ struct sf_plan {
   long long n_local = 0, goff = 0;
   int halo = 0;
   std::string description;
+  void* debug_buffer = nullptr;  // diagnostic builds (option stamp=1): 8 x uint64
   // per-launch profiling events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<int> prof_kernel;
@@ -200,7 +201,7 @@ static size_t star_lds_bytes(const StarCfg& c, DT dt) {
 static int star_regs_estimate(const StarCfg& c, DT dt) {
   const int words = (dt == DT::F64) ? 2 : 1;
   const int P = c.RJ * c.VK;
-  return 3 * c.T * P * words + 95 + (words - 1) * 20;
+  return 3 * c.T * P * words + 95 + (words - 1) * 20 + (c.prefetch2 ? P * words : 0);
 }
 
 static int star_blocks_per_cu(const StarCfg& c, DT dt) {
@@ -271,8 +272,12 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   base.noj = (P.n[1] == 1);
   base.row_fence = (int)pl.opt.get("k1.fence", 1);
   base.lds_db = (int)pl.opt.get("k1.db", 1);
-  base.unroll_p = (int)pl.opt.get("k1.unroll", 1);
   base.opaque = (int)pl.opt.get("k1.opaque", 1);
+  base.stamp = (int)pl.opt.get("stamp", 0);
+  base.spread = (int)pl.opt.get("k1.spread", 1);
+  base.prefetch2 = (int)pl.opt.get("k1.pf2", dt == DT::F32 ? 1 : 0);
+  base.experiment = (int)pl.opt.get("experiment", 0);
+  base.dpp = (int)pl.opt.get("k1.dpp", 1);
   const std::string pfx = base.noj ? "k2." : "k1.";
   const long long pin_bx = pl.opt.get(pfx + "bx", 0);
   const long long pin_by = base.noj ? 1 : pl.opt.get("k1.by", 0);
@@ -616,6 +621,8 @@ static void ensure_device(sf_plan& pl) {
     SF_HIP_CHECK(hipMalloc(&b.d, b.bytes()));
     SF_HIP_CHECK(hipMemsetAsync(b.d, 0, b.bytes(), pl.stream));
   }
+  SF_HIP_CHECK(hipMalloc(&pl.debug_buffer, 64));
+  SF_HIP_CHECK(hipMemsetAsync(pl.debug_buffer, 0, 64, pl.stream));
   SF_HIP_CHECK(hipStreamSynchronize(pl.stream));
   pl.device_ready = true;
 }
@@ -690,6 +697,7 @@ static void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, i
     const int nch2 = (int)((range2 + li - 1) / li);
     int li_i = (int)li;
     args = {&ptrs[0], &ptrs[1], scalar_store, &halo, &goff, &i_begin, &i_end, &li_i, &nch1, &i_begin2, &i_end2};
+    if (c.stamp) args.push_back(&pl.debug_buffer);
     SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(tiles * (nch1 + nch2)), 1, 1, c.BX, c.BY, 1, 0,
                                        stream, args.data(), nullptr));
   } else {
@@ -846,6 +854,7 @@ int sf_plan_destroy(sf_plan* plan) {
     collect_profile(*plan);
     for (auto& b : plan->buffers)
       if (b.d) (void)hipFree(b.d);
+    if (plan->debug_buffer) (void)hipFree(plan->debug_buffer);
     for (auto& k : plan->kernels)
       if (k.mod) (void)hipModuleUnload(k.mod);
     (void)hipEventDestroy(plan->ev_begin);
@@ -981,6 +990,16 @@ int sf_plan_kernel_resources(const sf_plan* p, int i, int* vgprs, int* agprs, in
   if (scratch) *scratch = k.scratch;
   if (lds) *lds = k.lds;
   return SF_OK;
+}
+int sf_plan_debug_counters(sf_plan* plan, unsigned long long* out, int count) {
+  SF_API_BEGIN
+  if (!plan || !out || count < 0 || count > 8) throw Error(SF_ERR_INVALID, "bad argument");
+  ensure_device(*plan);
+  SF_HIP_CHECK(hipStreamSynchronize(plan->stream));
+  SF_HIP_CHECK(hipMemcpy(out, plan->debug_buffer, sizeof(unsigned long long) * count, hipMemcpyDeviceToHost));
+  SF_HIP_CHECK(hipMemset(plan->debug_buffer, 0, 64));
+  return SF_OK;
+  SF_API_END
 }
 const char* sf_plan_describe(const sf_plan* p) { return p ? p->description.c_str() : nullptr; }
 

@@ -142,6 +142,10 @@ def test_jacobi3d_chain_random(tmp_path, shape, fuse):
     {"fuse": 2, "k1.bx": 64, "k1.by": 4, "k1.rj": 4},
     {"fuse": 2, "k1.li": 7},
     {"fuse": 4, "k1.rj": 2, "k1.by": 8},
+    {"fuse": 2, "k1.pf2": 1},
+    {"fuse": 1, "k1.pf2": 1, "k1.li": 5},
+    {"fuse": 3, "k1.pf2": 1, "k1.spread": 0},
+    {"fuse": 2, "k1.spread": 0, "k1.db": 0},
     {"generic_only": 1},
 ])
 def test_jacobi3d_tile_shapes(tmp_path, options):
