@@ -68,6 +68,7 @@ struct sf_ctx {
   int tx, ty, lane, wave;
   unsigned jmask, kmask, store_mask;
   bool kvec_in;
+  bool tile_inside;  // block-uniform: every point of the tile lies in the (j,k) domain
   int goff, halo, cb, ce, j0, k0;
 };
 
@@ -188,9 +189,12 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       }
     } else {
       // pad: outside the global domain the next stage must read ITS constant
-      const bool row_in = plane_in && ((cx.jmask >> r) & 1u);
+      // (skipped by a block-uniform branch for tiles and planes strictly inside)
+      if (!(cx.tile_inside && plane_in)) {
+        const bool row_in = plane_in && ((cx.jmask >> r) & 1u);
 #pragma unroll
-      for (int v = 0; v < SF_VK; ++v) o[v] = (row_in && ((cx.kmask >> v) & 1u)) ? o[v] : pad;
+        for (int v = 0; v < SF_VK; ++v) o[v] = (row_in && ((cx.kmask >> v) & 1u)) ? o[v] : pad;
+      }
       st.w[S < SF_T ? S : 0][inext][r] = o;  // becomes plane "next" of stage S
     }
 #if SF_ROW_FENCE
@@ -347,6 +351,11 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   cx.j0 = SF_NOJ ? 0 : (jt * SF_TJI - SF_T + cx.ty * SF_RJ);
   cx.k0 = SF_KTILED ? (kt * SF_TKI - SF_HK + cx.tx * SF_VK) : cx.tx * SF_VK;
 
+  {
+    const int tj0 = SF_NOJ ? 0 : (jt * SF_TJI - SF_T);
+    const int tk0 = SF_KTILED ? (kt * SF_TKI - SF_HK) : 0;
+    cx.tile_inside = tj0 >= 0 && tj0 + (SF_NOJ ? 1 : SF_TJH) <= SF_N1 && tk0 >= 0 && tk0 + SF_TKH <= SF_N2;
+  }
   cx.jmask = 0;
   cx.kmask = 0;
   cx.store_mask = 0;
