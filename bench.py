@@ -108,6 +108,11 @@ def main():
         raise SystemExit("--gpus must equal WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # test hook: all ranks on device 0 with the exchange staged through gloo
+    # (exercises the multi-rank path on a one-GPU box; never used for records)
+    one_device = os.environ.get("SF_BENCH_SINGLE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     if args.workload != "c3" and world > 1:
@@ -142,11 +147,16 @@ def main():
         sfir = lower(chain)
 
     if world > 1:
-        from stencilflow_amd.distributed import SlabRunner
+        from stencilflow_amd.distributed import SlabRunner, TorchDistExchanger
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+            exchanger = TorchDistExchanger(rank, world, staging="host")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            exchanger = TorchDistExchanger(rank, world, staging="device")
         runner = SlabRunner(sfir, shape, rank, world, device=local_rank,
-                            options=options)
+                            options=options, exchanger=exchanger)
         runner.upload([synthetic(runner.local_shape, rank)])
 
         def step():
@@ -185,7 +195,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if one_device else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -207,7 +218,9 @@ def main():
         "data": "synthetic (uniform random [0,1), seed %d)" % SEED,
         "config": {
             "workload": label,
-            "decomposition": "slab{}".format(world) if world > 1 else "single",
+            "decomposition": ("slab{} (halo {} planes, one exchange per {} launches)".format(
+                world, runner.halo, runner.halo // max(1, runner.steps[0][1]))
+                if world > 1 else "single"),
         },
     }
     if world == 1:
