@@ -1,0 +1,168 @@
+"""Seeded generator of random stencil programs in the reference's JSON format,
+used to compare implementations on inputs nobody hand-picked: random DAGs,
+offsets (also farther than the domain), mixed float32/float64, lower-
+dimensional and scalar inputs, program constants, int and float boundary
+literals, `shrink`, ternaries / comparisons / boolean operators, min / max,
+multi-statement kernels.  Only + - * (no division, no transcendental calls), so
+every implementation must agree bit for bit."""
+import numpy as np
+
+ITERATORS = ["i", "j", "k"]
+
+
+def _offset_text(it, o):
+    return it if o == 0 else ("{}+{}".format(it, o) if o > 0 else "{}-{}".format(it, -o))
+
+
+def random_program(seed):
+    rng = np.random.default_rng(seed)
+    nd = int(rng.integers(1, 4))
+    own = ITERATORS[3 - nd:]
+    if nd == 3:
+        dims = [int(rng.integers(3, 11)), int(rng.integers(3, 13)),
+                int(rng.choice([4, 8, 12, 16, 10, 7]))]
+    elif nd == 2:
+        dims = [int(rng.integers(3, 40)), int(rng.choice([8, 16, 36, 5, 11, 64]))]
+    else:
+        dims = [int(rng.choice([16, 33, 100]))]
+    prog = {"inputs": {}, "outputs": [], "dimensions": dims, "program": {}}
+    fields = {}  # name -> (dims list, dtype)
+    scalars = []
+    n_inputs = int(rng.integers(1, 4))
+    for n in range(n_inputs):
+        name = "in{}".format(n)
+        dtype = str(rng.choice(["float32", "float64"]))
+        if n > 0 and nd > 1 and rng.random() < 0.3:
+            keep = sorted(rng.choice(nd, size=int(rng.integers(1, nd)), replace=False))
+            fdims = [own[d] for d in keep]
+        else:
+            fdims = list(own)
+        prog["inputs"][name] = {"data": "constant:1.0", "data_type": dtype}
+        if fdims != list(own):
+            prog["inputs"][name]["input_dims"] = fdims
+        fields[name] = (fdims, dtype)
+    if rng.random() < 0.6:
+        prog["inputs"]["s0"] = {"data": float(np.round(rng.uniform(-2, 2), 3)),
+                                "data_type": str(rng.choice(["float32", "float64"])),
+                                "input_dims": []}
+        scalars.append("s0")
+    if rng.random() < 0.4:
+        prog["constants"] = {"kc": {"value": float(np.round(rng.uniform(-1, 1), 2)),
+                                    "data_type": "float64"}}
+        scalars.append("kc")
+
+    n_kernels = int(rng.integers(1, 6))
+    consumed = set()
+    for kn in range(n_kernels):
+        kname = "k{}".format(kn)
+        candidates = list(fields)
+        n_reads = int(rng.integers(1, min(3, len(candidates)) + 1))
+        # prefer reading the previous kernel so chains (and fusion) occur
+        reads = []
+        if kn > 0 and rng.random() < 0.8:
+            reads.append("k{}".format(kn - 1))
+        while len(reads) < n_reads:
+            c = str(rng.choice(candidates))
+            if c not in reads:
+                reads.append(c)
+        bcs, terms = {}, []
+        for f in reads:
+            fdims, _ = fields[f]
+            consumed.add(f)
+            kind = rng.random()
+            if kind < 0.15:
+                bcs[f] = {"type": "shrink"}
+            elif kind < 0.45:
+                bcs[f] = {"type": "constant", "value": int(rng.integers(-2, 3))}
+            else:
+                bcs[f] = {"type": "constant", "value": float(np.round(rng.uniform(-1, 1), 2))}
+            star = rng.random() < 0.6
+            for _ in range(int(rng.integers(1, 5))):
+                offs = [0] * len(fdims)
+                if star:
+                    d = int(rng.integers(0, len(fdims)))
+                    offs[d] = int(rng.choice([-1, 0, 1]))
+                else:
+                    for d in range(len(fdims)):
+                        offs[d] = int(rng.choice([-2, -1, 0, 0, 1, 2, 13]))
+                terms.append("{}[{}]".format(f, ", ".join(
+                    _offset_text(it, o) for it, o in zip(fdims, offs))))
+        def leaf():
+            r = rng.random()
+            if r < 0.7 or not scalars:
+                return str(rng.choice(terms))
+            if r < 0.85:
+                return str(rng.choice(scalars))
+            return repr(float(np.round(rng.uniform(-2, 2), 3))) if rng.random() < 0.7 \
+                else str(int(rng.integers(1, 4)))
+        def expr(depth):
+            if depth == 0 or rng.random() < 0.25:
+                return leaf()
+            r = rng.random()
+            if r < 0.6:
+                return "({} {} {})".format(expr(depth - 1), rng.choice(["+", "-", "*"]),
+                                           expr(depth - 1))
+            if r < 0.72:
+                return "(-{})".format(expr(depth - 1))
+            if r < 0.84:
+                return "{}({}, {})".format(rng.choice(["min", "max"]), expr(depth - 1),
+                                           expr(depth - 1))
+            cond = "{} {} {}".format(expr(depth - 1), rng.choice(["<", "<=", ">", ">=", "=="]),
+                                     expr(depth - 1))
+            if rng.random() < 0.3:
+                cond = "({}) {} ({} > 0.1)".format(cond, rng.choice(["and", "or"]), leaf())
+            return "({} if {} else {})".format(expr(depth - 1), cond, expr(depth - 1))
+        # make sure every read field is actually used
+        body = " + ".join(["0.5 * " + t for t in terms[:1]] + [expr(3)])
+        used = [f for f in reads if (f + "[") in body]
+        for f in reads:
+            if f not in used:
+                fdims, _ = fields[f]
+                body += " + {}[{}]".format(f, ", ".join(fdims))
+        if rng.random() < 0.3:
+            text = "tmp = {}; {} = tmp * 0.25 + {}".format(body, kname, leaf())
+            for f in reads:  # `leaf` may have named only already-used fields
+                pass
+        else:
+            text = "{} = {}".format(kname, body)
+        prog["program"][kname] = {
+            "computation_string": text,
+            "boundary_conditions": bcs,
+            "data_type": str(rng.choice(["float32", "float64"])),
+        }
+        fields[kname] = (list(own), prog["program"][kname]["data_type"])
+    # outputs: the last kernel plus every kernel nobody reads (no orphans)
+    outs = []
+    for kn in range(n_kernels):
+        kname = "k{}".format(kn)
+        read_by_later = any((kname + "[") in prog["program"]["k{}".format(m)]["computation_string"]
+                            for m in range(kn + 1, n_kernels))
+        if kn == n_kernels - 1 or not read_by_later or rng.random() < 0.2:
+            outs.append(kname)
+    prog["outputs"] = outs
+    # drop inputs nobody reads (the reference would leave them dangling)
+    text_all = " ".join(k["computation_string"] for k in prog["program"].values())
+    for name in list(prog["inputs"]):
+        if name.startswith("in") and (name + "[") not in text_all:
+            del prog["inputs"][name]
+    if "s0" in prog["inputs"] and "s0" not in text_all:
+        del prog["inputs"]["s0"]
+    if "constants" in prog and "kc" not in text_all:
+        del prog["constants"]
+    return prog
+
+
+def random_inputs(prog, seed):
+    """Random arrays for the array inputs, the declared value for scalars."""
+    from oracle import numpy_oracle as npo
+    rng = np.random.default_rng(seed)
+    p = npo.load_program(prog)
+    vals = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        if dims:
+            shape = npo._dims_shape(p, dims)
+            vals[name] = rng.uniform(-1, 1, shape).astype(npo._NP[desc["data_type"]])
+        else:
+            vals[name] = desc["data"]
+    return vals

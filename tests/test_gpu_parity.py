@@ -116,7 +116,7 @@ def test_run_program_driver_compare_to_reference(programs_dir, tmp_path,
 
 
 SHAPES_3D = [(32, 32, 32), (20, 44, 64), (17, 9, 12), (40, 70, 260),
-             (9, 30, 512), (6, 5, 520)]
+             (9, 30, 512), (6, 5, 520), (8, 6, 10), (3, 3, 4), (70, 3, 8)]
 
 
 @pytest.mark.parametrize("shape", SHAPES_3D)
@@ -131,7 +131,8 @@ def test_jacobi3d_chain_random(tmp_path, shape, fuse):
     path = _write(tmp_path, prog)
     want = npo.run_reference(prog, {"a": x})["b%d" % (stages - 1)]
     got, desc = _run_gpu(path, {"a": x}, options={"fuse": fuse})
-    assert "star" in desc
+    # rows that are not a multiple of the vector width run on the generic kernel
+    assert ("star" in desc) == (shape[2] % 4 == 0)
     assert np.array_equal(got["b%d" % (stages - 1)], want), npo.max_rel_err(
         want, got["b%d" % (stages - 1)])
 
@@ -490,3 +491,28 @@ def test_synthesized_programs(tmp_path, args, kwargs):
     got, _ = _run_gpu(path, ins)
     for k in want:
         assert np.array_equal(got[k], want[k]), (name, k, npo.max_rel_err(want[k], got[k]))
+
+
+def test_run_program_flags(programs_dir, tmp_path, monkeypatch):
+    """Driver flags of the reference (bin/run_program.py:12-37): -generate-input
+    (all inputs constant 0.5), -repetitions, -halo pruning of the saved files,
+    skip-execution returning None, unknown mode raising ValueError."""
+    from stencilflow_amd.run_program import run_program
+    monkeypatch.chdir(tmp_path)
+    prog = programs.jacobi3d((12, 16, 32), 3)
+    for k in prog["program"].values():
+        for bc in k["boundary_conditions"].values():
+            bc["type"] = "shrink"
+            del bc["value"]
+    path = _write(tmp_path, prog, "shrunk")
+    assert run_program(path, "hardware", compare_to_reference=True, generate_input=True,
+                       halo=3, repetitions=2, log_level=sf.LogLevel.NO_LOG) == 0
+    out = np.fromfile(tmp_path / "results" / "shrunk" / "b2.dat", np.float32)
+    assert out.size == 6 * 10 * 26          # pruned by `halo` on every side
+    ref = npo.run_reference(prog, generate_input=True)["b2"][3:-3, 3:-3, 3:-3]
+    assert np.array_equal(out, ref.ravel()) and len(np.unique(out)) == 1
+    assert run_program(path, "emulation", skip_execution=True,
+                       log_level=sf.LogLevel.NO_LOG) is None
+    assert run_program(path, "hip", log_level=sf.LogLevel.NO_LOG) is None
+    with pytest.raises(ValueError, match="Unrecognized execution mode"):
+        run_program(path, "simulation", log_level=sf.LogLevel.NO_LOG)
