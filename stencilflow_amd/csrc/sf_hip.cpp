@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 #include "codegen.hpp"
 
@@ -167,13 +168,32 @@ static void read_metadata(CompiledKernel& k) {
   k.lds = metadata_uint(k.code, ".group_segment_fixed_size");
 }
 
+// Code objects are cached per process: plans of the same program (slab ranks,
+// repeated runs, the tile search of another chain) do not recompile.
+static std::mutex g_code_cache_mutex;
+static std::map<std::string, std::vector<char>> g_code_cache;  // name + source -> code object
+
 static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& source) {
   auto it = pl.kernel_by_source.find(source);
   if (it != pl.kernel_by_source.end()) return it->second;
   CompiledKernel k;
   k.name = prefix + "_" + hex8(fnv1a(source));
   k.source = source;
-  compile_kernel(k);
+  const std::string key = k.name + "\n" + source;
+  bool cached = false;
+  {
+    std::lock_guard<std::mutex> lock(g_code_cache_mutex);
+    auto c = g_code_cache.find(key);
+    if (c != g_code_cache.end()) {
+      k.code = c->second;
+      cached = true;
+    }
+  }
+  if (!cached) {
+    compile_kernel(k);
+    std::lock_guard<std::mutex> lock(g_code_cache_mutex);
+    g_code_cache[key] = k.code;
+  }
   read_metadata(k);
   pl.kernels.push_back(std::move(k));
   pl.kernel_by_source[source] = (int)pl.kernels.size() - 1;

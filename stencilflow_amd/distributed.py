@@ -214,21 +214,45 @@ class SlabRunner:
         self.local_shape = (self.n_local, ) + tuple(global_shape[1:])
         self.has_lower = rank > 0
         self.has_upper = rank < world - 1
-        # a plan without halo tells how far each launch reaches
-        probe = Plan(sfir_text, device=device, options=options)
-        depths = [probe.step_halo(s)[1] for s in range(probe.num_steps)]
-        probe.close()
-        reach = max([1] + depths)
-        if halo is None:
-            halo = reach * max(1, groups_per_exchange)
-            halo = max(reach, min(halo, self.n_local // 2))
-        self.halo = int(halo)
-        if world > 1 and (self.n_local < self.halo or self.n_local < 2 * reach):
-            raise ValueError("slab of {} planes is too thin for a halo of {}".
-                             format(self.n_local, self.halo))
-        if world > 1:
-            options["slab"] = "{}:{}:{}".format(self.lo, self.hi, self.halo)
-        self.plan = Plan(sfir_text, device=device, options=options)
+        def make_plan(h):
+            opts = dict(options)
+            if world > 1:
+                opts["slab"] = "{}:{}:{}".format(self.lo, self.hi, h)
+            return Plan(sfir_text, device=device, options=opts)
+
+        def check(h, reach):
+            if world > 1 and (self.n_local < h or self.n_local < 2 * reach):
+                raise ValueError("slab of {} planes is too thin for a halo of {}".
+                                 format(self.n_local, h))
+
+        if halo is not None:
+            self.halo = int(halo)
+            check(self.halo, 1)
+            self.plan = make_plan(self.halo)
+        else:
+            # first guess: every launch reaches as far as the deepest default
+            # fusion (4); the plan refuses a halo shallower than its reach, in
+            # which case a halo-less plan is asked how far the launches reach
+            guess = int(options.get("fuse", 4)) * max(1, groups_per_exchange)
+            guess = max(1, min(guess, self.n_local // 2))
+            try:
+                plan = make_plan(guess)
+                reach = max([1] + [plan.step_halo(s)[1] for s in range(plan.num_steps)])
+            except ValueError as exc:
+                if "shallower" not in str(exc):
+                    raise
+                probe = Plan(sfir_text, device=device, options=options)
+                reach = max([1] + [probe.step_halo(s)[1] for s in range(probe.num_steps)])
+                probe.close()
+                plan = None
+            want = max(reach, min(reach * max(1, groups_per_exchange), self.n_local // 2))
+            check(want, reach)
+            if plan is None or want != guess:
+                if plan is not None:
+                    plan.close()
+                plan = make_plan(want)
+            self.halo = want
+            self.plan = plan
         self.exchanger = exchanger
         if self.exchanger is None and world > 1:
             self.exchanger = TorchDistExchanger(rank, world)

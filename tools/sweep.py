@@ -27,10 +27,15 @@ def main():
     ap.add_argument("--kind", default="jacobi3d")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--random", action="store_true")
+    ap.add_argument("--shape", default="", help="explicit shape, e.g. 4096x512x512")
     ap.add_argument("opts", nargs="*")
     args = ap.parse_args()
     n = args.size
-    if args.kind == "jacobi3d":
+    if args.shape:
+        shape = tuple(int(v) for v in args.shape.split("x"))
+        prog = (programs.jacobi3d if len(shape) == 3 else programs.jacobi2d)(shape, args.stages)
+        dtype, bpu = np.float32, 8.0
+    elif args.kind == "jacobi3d":
         shape = (n, n, n)
         prog = programs.jacobi3d(shape, args.stages)
         dtype, bpu = np.float32, 8.0
