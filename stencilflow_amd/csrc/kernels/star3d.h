@@ -65,6 +65,7 @@ struct sf_state {
 
 struct sf_ctx {
   const sf_t* in;
+  sf_auxptrs aux;  // centre-only auxiliary fields (same layout as `in`)
   int tx, ty, lane, wave;
   unsigned jmask, kmask, store_mask;
   bool kvec_in;
@@ -155,12 +156,17 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       kp_e = (SF_WPR > 1 && cx.wave < SF_WPR - 1)
                  ? lds[sf_edge_at(src, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]
                  : sf_stage<S>::bc();
+    // centre-only auxiliary fields of this stage, row r of plane q
+    const auto ax = sf_stage<S>::load_aux(
+        cx.aux,
+        (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2) + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0),
+        plane_in && (q + cx.halo >= 0) && ((cx.jmask >> r) & 1u) && cx.kvec_in);
     sf_vec o;
 #pragma unroll
     for (int v = 0; v < SF_VK; ++v) {
       const sf_t km = (v > 0) ? c[v > 0 ? v - 1 : 0] : km_e;
       const sf_t kp = (v < SF_VK - 1) ? c[v < SF_VK - 1 ? v + 1 : v] : kp_e;
-      o[v] = sf_stage<S>::apply(c[v], im[v], ip[v], jm[v], jp[v], km, kp, sc);
+      o[v] = sf_stage<S>::apply(c[v], im[v], ip[v], jm[v], jp[v], km, kp, sc, ax, v);
     }
     jm = c;
 #if SF_PREFETCH2
@@ -308,7 +314,8 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
 }
 
 extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
-    SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, int halo,
+    SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc,
+                   sf_auxptrs aux, int halo,
                    int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2
 #if SF_STAMP
                    ,
@@ -320,6 +327,7 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 
   sf_ctx cx;
   cx.in = in;
+  cx.aux = aux;
   cx.tx = threadIdx.x;
   cx.ty = threadIdx.y;
   cx.lane = cx.tx & 63;

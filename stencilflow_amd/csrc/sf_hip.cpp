@@ -82,6 +82,7 @@ struct Step {
   std::vector<size_t> scalar_offsets;
   size_t scalars_bytes = 4;
   StarCfg cfg;
+  int num_aux = 0;                    // centre-only auxiliary fields of a star step
   int halo_buf = -1, halo_depth = 0;  // what must be exchanged before the step
   std::string note;
 };
@@ -434,8 +435,8 @@ static void build_plan(sf_plan& pl) {
   std::map<std::string, StarChoice> star_memo;
   for (int k = 0; k < K;) {
     Step st;
-    std::string src;
-    bool star = !generic_only && star_ok_dims && star_eligible(P, P.kernels[k], &src);
+    StarShape shape;
+    bool star = !generic_only && star_ok_dims && star_eligible(P, P.kernels[k], &shape);
     if (star && P.n[1] == 1) {
       for (auto& a : P.kernels[k].acc)
         if (a.off[1] != 0) star = false;
@@ -445,12 +446,18 @@ static void build_plan(sf_plan& pl) {
       while ((int)group.size() < fuse && k + (int)group.size() < K) {
         const int cur = group.back(), nxt = cur + 1;
         const Kernel& kc = P.kernels[cur];
-        std::string nsrc;
-        if (!star_eligible(P, P.kernels[nxt], &nsrc)) break;
-        if (nsrc != kc.name) break;
+        StarShape nshape;
+        if (!star_eligible(P, P.kernels[nxt], &nshape)) break;
+        if (nshape.primary != kc.name) break;
         if (P.field(kc.name).role != Role::Temp) break;
         if (consumers[kc.name] != 1) break;
         if (P.kernels[nxt].dt != kc.dt) break;
+        // auxiliary fields must exist in memory: not produced inside this group
+        bool aux_ok = true;
+        for (auto& f : nshape.aux)
+          for (int g : group)
+            if (P.kernels[g].name == f) aux_ok = false;
+        if (!aux_ok) break;
         group.push_back(nxt);
       }
       // longest prefix of the group for which a clean kernel exists
@@ -500,7 +507,15 @@ static void build_plan(sf_plan& pl) {
   auto step_reads = [&](const Step& st) {
     std::vector<std::string> r;
     if (st.star) {
-      r.push_back(P.kernels[st.kernels[0]].acc[0].field);
+      StarShape sh0;
+      star_eligible(P, P.kernels[st.kernels[0]], &sh0);
+      r.push_back(sh0.primary);  // argument 0: the streamed field
+      for (int k : st.kernels) {
+        StarShape sh;
+        star_eligible(P, P.kernels[k], &sh);
+        for (auto& f : sh.aux)
+          if (std::find(r.begin(), r.end(), f) == r.end()) r.push_back(f);
+      }
     } else {
       for (auto& a : P.kernels[st.kernels[0]].acc)
         if (std::find(r.begin(), r.end(), a.field) == r.end()) r.push_back(a.field);
@@ -577,6 +592,15 @@ static void build_plan(sf_plan& pl) {
       st.scalars = g.scalars;
       st.scalar_offsets = g.scalar_offsets;
       st.scalars_bytes = g.scalars_bytes;
+      st.num_aux = (int)g.aux.size();
+      // the generator numbers auxiliary pointers in first-use order over the
+      // fused stages, which is the order step_reads() lists them after the primary
+      {
+        const std::vector<std::string> reads = step_reads(st);
+        if (reads.size() != g.aux.size() + 1) throw Error(SF_ERR_STATE, "star step: auxiliary count mismatch");
+        for (size_t a = 0; a < g.aux.size(); ++a)
+          if (reads[a + 1] != g.aux[a]) throw Error(SF_ERR_STATE, "star step: auxiliary order mismatch");
+      }
       st.halo_depth = st.cfg.T;
       st.halo_buf = st.in_bufs[0];
     } else {
@@ -702,6 +726,8 @@ static void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, i
     const StarCfg& c = st.cfg;
     ptrs.push_back(pl.buffers[st.in_bufs[0]].d);
     ptrs.push_back(pl.buffers[st.out_buf].d);
+    if ((int)st.in_bufs.size() - 1 != st.num_aux)
+      throw Error(SF_ERR_STATE, "star launch: auxiliary buffers do not match the generated kernel");
     std::memset(scalar_store, 0, sizeof scalar_store);
     for (size_t s = 0; s < st.scalars.size(); ++s) {
       const Scalar& sc = P.scalars[st.scalars[s]];
@@ -716,7 +742,11 @@ static void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, i
     int nch1 = (int)((range1 + li - 1) / li);
     const int nch2 = (int)((range2 + li - 1) / li);
     int li_i = (int)li;
-    args = {&ptrs[0], &ptrs[1], scalar_store, &halo, &goff, &i_begin, &i_end, &li_i, &nch1, &i_begin2, &i_end2};
+    // auxiliary field pointers (argument order = in_bufs[1..], as gen_star numbers them)
+    void* aux_ptrs[kMaxStarAux] = {nullptr, nullptr, nullptr, nullptr};
+    for (size_t a = 1; a < st.in_bufs.size() && a <= (size_t)kMaxStarAux; ++a)
+      aux_ptrs[a - 1] = pl.buffers[st.in_bufs[a]].d;
+    args = {&ptrs[0], &ptrs[1], scalar_store, aux_ptrs, &halo, &goff, &i_begin, &i_end, &li_i, &nch1, &i_begin2, &i_end2};
     if (c.stamp) args.push_back(&pl.debug_buffer);
     SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(tiles * (nch1 + nch2)), 1, 1, c.BX, c.BY, 1, 0,
                                        stream, args.data(), nullptr));

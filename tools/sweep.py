@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--random", action="store_true")
     ap.add_argument("--shape", default="", help="explicit shape, e.g. 4096x512x512")
+    ap.add_argument("--bc-int", action="store_true",
+                    help="integer boundary literal (bin/synthesize.py convention): float32 sums")
     ap.add_argument("opts", nargs="*")
     args = ap.parse_args()
     n = args.size
@@ -37,7 +39,7 @@ def main():
         dtype, bpu = np.float32, 8.0
     elif args.kind == "jacobi3d":
         shape = (n, n, n)
-        prog = programs.jacobi3d(shape, args.stages)
+        prog = programs.jacobi3d(shape, args.stages, bc_value=0 if args.bc_int else 0.0)
         dtype, bpu = np.float32, 8.0
     elif args.kind == "jacobi2d":
         shape = (n, n)
