@@ -83,6 +83,7 @@ struct Step {
   size_t scalars_bytes = 4;
   StarCfg cfg;
   int num_aux = 0;                    // centre-only auxiliary fields of a star step
+  int generic_vk = 1;                 // points per thread of a generic step
   int halo_buf = -1, halo_depth = 0;  // what must be exchanged before the step
   std::string note;
 };
@@ -604,7 +605,10 @@ static void build_plan(sf_plan& pl) {
       st.halo_depth = st.cfg.T;
       st.halo_buf = st.in_bufs[0];
     } else {
-      GenericKernelSource g = gen_generic(P, st.kernels[0]);
+      // 4 points per thread with aligned vector loads when rows allow it
+      const bool vec = (P.n[2] % 4 == 0) && pl.opt.get("generic.vec", 1) != 0;
+      GenericKernelSource g = vec ? gen_generic_vec(P, st.kernels[0]) : gen_generic(P, st.kernels[0]);
+      st.generic_vk = g.vk;
       st.scalars = g.scalars;
       st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
       int depth = 0, hb = -1;
@@ -766,7 +770,7 @@ static void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, i
     args.push_back(&goff);
     args.push_back(&i_begin);
     args.push_back(&i_end);
-    const long long plane = P.n[1] * P.n[2];
+    const long long plane = P.n[1] * (P.n[2] / st.generic_vk);
     const unsigned gx = (unsigned)((plane + 255) / 256);
     const int ranges[2][2] = {{i_begin, i_end}, {i_begin2, i_end2}};
     for (int ri = 0; ri < 2; ++ri) {
