@@ -605,12 +605,21 @@ static void build_plan(sf_plan& pl) {
       st.halo_depth = st.cfg.T;
       st.halo_buf = st.in_bufs[0];
     } else {
-      // 4 points per thread with aligned vector loads when rows allow it
+      // 4 points per thread with aligned vector loads when rows allow it; the
+      // one-point form is kept for short rows and for operators whose vector
+      // form would spill (same acceptance rule as for the star kernels)
       const bool vec = (P.n[2] % 4 == 0) && pl.opt.get("generic.vec", 1) != 0;
       GenericKernelSource g = vec ? gen_generic_vec(P, st.kernels[0]) : gen_generic(P, st.kernels[0]);
+      st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
+      if (vec) {
+        const CompiledKernel& k = pl.kernels[st.ck];
+        if (std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs) > 0) {
+          g = gen_generic(P, st.kernels[0]);
+          st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
+        }
+      }
       st.generic_vk = g.vk;
       st.scalars = g.scalars;
-      st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
       int depth = 0, hb = -1;
       for (size_t ai = 0; ai < P.kernels[st.kernels[0]].acc.size(); ++ai) {
         const Access& a = P.kernels[st.kernels[0]].acc[ai];
