@@ -13,3 +13,4 @@ from .helper import (ITERATORS, aligned, arrays_are_equal, arrays_match,
 from .dtypes import str_to_dtype
 from .log_level import LogLevel
 from .kernel_chain_graph import Input, Kernel, KernelChainGraph, Output
+from .run_program import run_program, set_reference_backend

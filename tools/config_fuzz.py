@@ -47,11 +47,15 @@ def main():
         for name, prog, x, want, tol, scal in cases:
             path = programs.write_program(prog, os.path.join(tmp, "p.json"))
             sfir = lower(sf.KernelChainGraph(path))
-            for fuse, bx, by, rj, db in itertools.product([1, 2, 3], [64, 128], [1, 2, 3, 4, 8],
-                                                          [1, 2, 3, 4, 5, 6, 7, 8], [0, 1]):
+            quick = "--quick" in sys.argv
+            space = itertools.product([1, 2, 3], [64, 128], [1, 2, 4] if quick else [1, 2, 3, 4, 8],
+                                      [1, 2, 3, 5] if quick else [1, 2, 3, 4, 5, 6, 7, 8],
+                                      [1] if quick else [0, 1])
+            for fuse, bx, by, rj, db in space:
                 if bx * by > 1024 or by * rj - 2 * fuse < 1:
                     continue
-                opt = {"fuse": fuse, "k1.bx": bx, "k1.by": by, "k1.rj": rj, "k1.db": db}
+                opt = {"fuse": fuse, "k1.bx": bx, "k1.by": by, "k1.rj": rj, "k1.db": db,
+                       "allow_spills": 1}
                 try:
                     plan = Plan(sfir, options=opt)
                 except ValueError:
