@@ -280,7 +280,8 @@ class CompiledReference:
         results = {}
         pool = []
         if self.threads:
-            os.environ["OMP_NUM_THREADS"] = str(self.threads)
+            # the OpenMP runtime is already initialised: set the team size directly
+            self.lib.omp_set_num_threads(int(self.threads))
         for i, kname in enumerate(order):
             reads, used = self.signatures[kname]
             dt = npo._NP[prog["program"][kname]["data_type"]]
