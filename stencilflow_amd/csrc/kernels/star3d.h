@@ -109,7 +109,11 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, con
   const bool plane_in = (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
   if (plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in) {
     const sf_t* plane = cx.in + (size_t)(p + cx.halo) * ((size_t)SF_N1 * SF_N2);
+#if SF_NT & 2
+    v = __builtin_nontemporal_load(reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)));
+#else
     v = *reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0));
+#endif
   }
   return v;
 }
@@ -191,7 +195,11 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       if (SF_EXPERIMENT != 1 && store_plane && ((cx.store_mask >> r) & 1u)) {
         // wave-uniform plane base (SGPR pair) + 32-bit in-plane offset
         sf_t* plane = out + (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2);
+#if SF_NT & 1
+        __builtin_nontemporal_store(o, reinterpret_cast<sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)));
+#else
         *reinterpret_cast<sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)) = o;
+#endif
       }
     } else {
       // pad: outside the global domain the next stage must read ITS constant

@@ -300,6 +300,7 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   base.prefetch2 = (int)pl.opt.get("k1.pf2", dt == DT::F32 ? 1 : 0);
   base.experiment = (int)pl.opt.get("experiment", 0);
   base.dpp = (int)pl.opt.get("k1.dpp", 1);
+  base.nt = (int)pl.opt.get("k1.nt", 0);
   const std::string pfx = base.noj ? "k2." : "k1.";
   const long long pin_bx = pl.opt.get(pfx + "bx", 0);
   const long long pin_by = base.noj ? 1 : pl.opt.get("k1.by", 0);
