@@ -1,45 +1,51 @@
 #!/usr/bin/env python3
-"""Command line of the driver; same flags as the reference's bin/run_program.py
-(:12-37).  FPGA-only flags are accepted and ignored."""
+"""Command line of the driver.  Flag names, defaults and the positional
+arguments are those of the reference's bin/run_program.py (:12-37) so existing
+invocations keep working; flags that only steer the FPGA toolchain are accepted
+and ignored.  Extra: ``-device``, ``-options`` (backend tuning overrides)."""
 import argparse
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 import stencilflow_amd  # noqa: E402
-from stencilflow_amd.run_program import run_program  # noqa: E402
 
-if __name__ == "__main__":
-    parser = argparse.ArgumentParser()
+# (flag, kwargs) -- single-dash long options, as in the reference
+SWITCHES = ["run-simulation", "compare-to-reference", "use-cached-sdfg", "skip-execution",
+            "generate-input", "specialize-scalars", "plot", "print-result", "xilinx"]
+VALUED = [
+    ("input-directory", dict(default=None)),
+    ("halo", dict(type=int, default=0)),
+    ("repetitions", dict(type=int, default=1)),
+    ("synthetic-reads", dict(type=float, default=None)),
+    ("log-level", dict(type=int, choices=[0, 1, 2, 3], default=1)),
+    ("device", dict(type=int, default=0)),
+    ("options", dict(type=str, default=None, help="e.g. 'fuse=2;k1.rj=5'")),
+]
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description=__doc__)
     parser.add_argument("stencil_file")
     parser.add_argument("mode", choices=["emulation", "hardware", "hip"])
-    parser.add_argument("-run-simulation", action="store_true")
-    parser.add_argument("-compare-to-reference", action="store_true")
-    parser.add_argument("-input-directory")
-    parser.add_argument("-use-cached-sdfg", dest="use_cached_sdfg",
-                        action="store_true")
-    parser.add_argument("-skip-execution", dest="skip_execution",
-                        action="store_true")
-    parser.add_argument("-generate-input", action="store_true")
-    parser.add_argument("-halo", type=int, default=0)
-    parser.add_argument("-repetitions", type=int, default=1)
-    parser.add_argument("-synthetic-reads", type=float, default=None)
-    parser.add_argument("-specialize-scalars", dest="specialize_scalars",
-                        action="store_true")
-    parser.add_argument("-plot", action="store_true")
-    parser.add_argument("-log-level", type=int, choices=[0, 1, 2, 3],
-                        default=1)
-    parser.add_argument("-print-result", dest="print_result",
-                        action="store_true")
-    parser.add_argument("-xilinx", dest="xilinx", action="store_true")
-    parser.add_argument("-device", type=int, default=0)
-    parser.add_argument("-options", type=str, default=None,
-                        help="backend tuning overrides, e.g. 'fuse=2;k1.rj=5'")
-    args = parser.parse_args()
-    args.log_level = stencilflow_amd.LogLevel(args.log_level)
-    if args.compare_to_reference:
+    for name in SWITCHES:
+        parser.add_argument("-" + name, dest=name.replace("-", "_"), action="store_true")
+    for name, kw in VALUED:
+        parser.add_argument("-" + name, dest=name.replace("-", "_"), **kw)
+    return parser
+
+
+def main(argv=None):
+    args = vars(build_parser().parse_args(argv))
+    args["log_level"] = stencilflow_amd.LogLevel(args["log_level"])
+    if args["compare_to_reference"]:
         # the CPU checker lives with the tests, not in the product
         from tests.reference_provider import register
         register()
-    sys.exit(run_program(**vars(args)))
+    return stencilflow_amd.run_program(**args)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

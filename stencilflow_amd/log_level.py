@@ -1,18 +1,15 @@
-"""Verbosity levels accepted by ``KernelChainGraph`` and ``run_program``
-(same names and ordering as reference stencilflow/log_level.py:15-24)."""
+"""Verbosity accepted by ``KernelChainGraph`` and ``run_program``.
+
+Same member names, values and ordering as the reference's ``LogLevel``
+(stencilflow/log_level.py:15-24), so ``LogLevel(2)``, ``level >= LogLevel.BASIC``
+and ``.value`` behave identically; implemented as an ``IntEnum``.
+"""
 
 import enum
-import functools
 
 
-@functools.total_ordering
-class LogLevel(enum.Enum):
+class LogLevel(enum.IntEnum):
     NO_LOG = 0
     BASIC = 1
     MODERATE = 2
     FULL = 3
-
-    def __lt__(self, other):
-        if self.__class__ is other.__class__:
-            return self.value < other.value
-        return NotImplemented
