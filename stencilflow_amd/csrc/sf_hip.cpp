@@ -8,8 +8,12 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstring>
+#include <fstream>
 #include <memory>
 #include <mutex>
 
@@ -175,6 +179,34 @@ static void read_metadata(CompiledKernel& k) {
 static std::mutex g_code_cache_mutex;
 static std::map<std::string, std::vector<char>> g_code_cache;  // name + source -> code object
 
+// <dir>/<hash>.co, or "" when the disk cache is off.  Directory: $SF_HIP_CACHE_DIR
+// ("off" disables), default $XDG_CACHE_HOME or ~/.cache + /stencilflow_amd.
+static std::string disk_cache_path(const std::string& key) {
+  const char* env = std::getenv("SF_HIP_CACHE_DIR");
+  std::string dir;
+  if (env && *env) {
+    if (std::string(env) == "off" || std::string(env) == "0") return "";
+    dir = env;
+  } else {
+    const char* xdg = std::getenv("XDG_CACHE_HOME");
+    const char* home = std::getenv("HOME");
+    if (xdg && *xdg) dir = std::string(xdg) + "/stencilflow_amd";
+    else if (home && *home) dir = std::string(home) + "/.cache/stencilflow_amd";
+    else return "";
+  }
+  // mkdir -p (two levels are enough for the defaults)
+  const size_t slash = dir.rfind('/');
+  if (slash != std::string::npos && slash > 0) ::mkdir(dir.substr(0, slash).c_str(), 0755);
+  if (::mkdir(dir.c_str(), 0755) != 0 && errno != EEXIST) return "";
+  int major = 0, minor = 0;
+  hiprtcVersion(&major, &minor);
+  const std::string salted = key + "\nhiprtc " + std::to_string(major) + "." + std::to_string(minor) +
+                             "\ngfx950 -O3 -std=c++17 -ffp-contract=off";
+  char name[40];
+  std::snprintf(name, sizeof name, "%016llx%08x", (unsigned long long)fnv1a(salted), (unsigned)salted.size());
+  return dir + "/" + name + ".co";
+}
+
 static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& source) {
   auto it = pl.kernel_by_source.find(source);
   if (it != pl.kernel_by_source.end()) return it->second;
@@ -192,7 +224,27 @@ static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::stri
     }
   }
   if (!cached) {
-    compile_kernel(k);
+    // second level: code objects on disk, keyed by source, name and hipRTC version
+    const std::string path = disk_cache_path(key);
+    if (!path.empty()) {
+      std::ifstream f(path, std::ios::binary);
+      if (f) {
+        k.code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        cached = !k.code.empty();
+      }
+    }
+    if (!cached) {
+      compile_kernel(k);
+      if (!path.empty()) {
+        const std::string tmp = path + "." + std::to_string((long)getpid());
+        std::ofstream f(tmp, std::ios::binary);
+        if (f) {
+          f.write(k.code.data(), (std::streamsize)k.code.size());
+          f.close();
+          if (std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+        }
+      }
+    }
     std::lock_guard<std::mutex> lock(g_code_cache_mutex);
     g_code_cache[key] = k.code;
   }
