@@ -33,6 +33,16 @@
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 
+#ifndef SF_REVERSE
+#define SF_REVERSE 0
+#endif
+#if SF_REVERSE  // loads are issued at the end of the step: no staging registers
+#undef SF_PREFETCH2
+#define SF_PREFETCH2 0
+#undef SF_SPREAD_LOADS
+#define SF_SPREAD_LOADS 0
+#endif
+
 #define SF_TJH (SF_BY * SF_RJ)
 #define SF_TKH (SF_BX * SF_VK)
 #define SF_WPR (SF_BX / 64)
@@ -58,8 +68,8 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 // phase PH the slots hold  prev = PH % 3,  cur = (PH + 1) % 3,  next = (PH + 2) % 3.
 struct sf_state {
   sf_vec w[SF_T][3][SF_RJ];
-#if SF_PREFETCH2
-  sf_vec pf[SF_RJ];  // input plane in flight (p+2): a full step to land
+#if SF_PREFETCH2 || SF_REVERSE == 2
+  sf_vec pf[SF_RJ];  // input plane in flight: a full step to land
 #endif
 };
 
@@ -107,7 +117,8 @@ __device__ __forceinline__ T sf_neighbour_lane(T x) {
 __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, const int r) {
   sf_vec v = (sf_vec)sf_stage<1>::bc();
   const bool plane_in = (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
-  if (plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in) {
+  // SF_EXPERIMENT 5: timing-only build without the input loads (invalid results)
+  if (SF_EXPERIMENT != 5 && plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in) {
     const sf_t* plane = cx.in + (size_t)(p + cx.halo) * ((size_t)SF_N1 * SF_N2);
 #if SF_NT & 2
     v = __builtin_nontemporal_load(reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)));
@@ -136,7 +147,9 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
     if (ty < SF_BY - 1)
       jpl = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(src, ty + 1, 0) + tx * SF_VK]);
   }
-  const int q = p - S;  // plane this stage produces (local owned coords)
+  // plane this stage produces (local owned coords).  SF_REVERSE: every stage
+  // reads only planes finished in earlier steps, so stage S lags 2S-1 steps.
+  const int q = SF_REVERSE ? p - (2 * S - 1) : p - S;
   const bool plane_in = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G);
   const bool store_plane = (S == SF_T) && q >= cx.cb && q < cx.ce && plane_in;
   sf_t pad = (sf_t)0;
@@ -209,7 +222,9 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
 #pragma unroll
         for (int v = 0; v < SF_VK; ++v) o[v] = (row_in && ((cx.kmask >> v) & 1u)) ? o[v] : pad;
       }
-      st.w[S < SF_T ? S : 0][inext][r] = o;  // becomes plane "next" of stage S
+      // becomes plane "next" of stage S.  SF_REVERSE: stage S+1 ran earlier in
+      // this step and is done with the slot that held its plane "prev".
+      st.w[S < SF_T ? S : 0][SF_REVERSE ? iprev : inext][r] = o;
     }
 #if SF_ROW_FENCE
     __builtin_amdgcn_sched_barrier(0);  // rows in order: bounds the live f64 temporaries
@@ -224,6 +239,17 @@ __device__ __forceinline__ void sf_later_stages(sf_state& st, const sf_t* lds, c
   if constexpr (S <= SF_T) {
     sf_stage_step<S, PH>(st, lds, sc, out, cx, p);
     sf_later_stages<S + 1, PH>(st, lds, sc, out, cx, p);
+  }
+}
+
+// stages S, S-1, ..., 2 (SF_REVERSE order: the storing stage first)
+template <int S, int PH>
+__device__ __forceinline__ void sf_later_stages_desc(sf_state& st, const sf_t* lds,
+                                                     const sf_scalars& sc, sf_t* __restrict__ out,
+                                                     const sf_ctx& cx, const int p) {
+  if constexpr (S >= 2) {
+    sf_stage_step<S, PH>(st, lds, sc, out, cx, p);
+    sf_later_stages_desc<S - 1, PH>(st, lds, sc, out, cx, p);
   }
 }
 
@@ -268,6 +294,13 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
                                         sf_t* __restrict__ out, const sf_scalars& sc,
                                         const sf_ctx& cx, const int p, const int p_end SF_STAMP_ARGS) {
   constexpr int icur = (PH + 1) % 3;
+#if SF_REVERSE == 2
+  // the plane loaded during the previous step (between its last and its first
+  // stage) enters the window as plane "next"; this is the step's only wait on
+  // vector memory, and everything it waits for is at least a stage old
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) st.w[0][(PH + 2) % 3][r] = st.pf[r];
+#endif
   // Make the window opaque at the step boundary: otherwise the compiler keeps
   // the f64 conversions of whole planes alive from one unrolled step to the
   // next (fewer v_cvt, but ~80 more VGPRs and spills).
@@ -277,7 +310,11 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
 #pragma unroll
     for (int w = 0; w < 3; ++w)
 #pragma unroll
-      for (int r = 0; r < SF_RJ; ++r) asm volatile("" : "+v"(st.w[s][w][r]));
+      for (int r = 0; r < SF_RJ; ++r) {
+        // (SF_REVERSE 1: the input plane still in flight must not be touched here)
+        if (SF_REVERSE == 1 && s == 0 && w == (PH + 2) % 3) continue;
+        asm volatile("" : "+v"(st.w[s][w][r]));
+      }
 #endif
   // publish the rows / columns other threads need of every stage's current plane
 #pragma unroll
@@ -302,6 +339,27 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
   // SF_EXPERIMENT 2/4: timing-only builds without the barrier (invalid results)
   if (SF_USE_LDS && SF_EXPERIMENT != 2 && SF_EXPERIMENT != 4) __syncthreads();
   SF_STAMP_AT(0);
+#if SF_REVERSE
+  // Last stage first: its stores are issued at the start of the step and the
+  // input loads at its very end, so the one `s_waitcnt vmcnt(0)` per step (the
+  // compiler cannot count loads and stores apart) waits for loads a whole step
+  // old and for stores most of a step old -- not for stores just issued.
+  sf_later_stages_desc<SF_T, PH>(st, lds, sc, out, cx, p);
+  SF_STAMP_AT(3);
+#if SF_REVERSE == 2
+  if (p + 1 < p_end) sf_load_plane(in, cx, p + 1, st.pf);
+  SF_STAMP_AT(2);
+  sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
+  SF_STAMP_AT(1);
+#else
+  sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
+  SF_STAMP_AT(1);
+  if (p + 1 < p_end) sf_load_plane(in, cx, p + 1, st.w[0][PH % 3]);
+  SF_STAMP_AT(2);
+#endif
+  if (SF_USE_LDS && !SF_LDS_DB) __syncthreads();
+  return;
+#endif
   // stage 1 consumes input plane p (slot "next" of the input window) and frees
   // slot "prev", which receives input plane p+1
 #if SF_PREFETCH2
@@ -399,8 +457,15 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 #pragma unroll
       for (int r = 0; r < SF_RJ; ++r) st.w[s][w][r] = (sf_vec)(sf_t)0;
 
+  // p_end bounds the input planes read; p_last the steps (SF_REVERSE drains
+  // T-1 more steps because its stages lag further)
   const int p_begin = cx.cb - SF_T, p_end = cx.ce + SF_T;
+  const int p_last = SF_REVERSE ? cx.ce + 2 * SF_T - 1 : p_end;
+#if SF_REVERSE == 2
+  sf_load_plane(in, cx, p_begin, st.pf);
+#else
   sf_load_plane(in, cx, p_begin, st.w[0][2]);  // slot "next" of phase 0
+#endif
 #if SF_PREFETCH2
   if (p_begin + 1 < p_end) sf_load_plane(in, cx, p_begin + 1, st.pf);
 #endif
@@ -415,7 +480,7 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   // the trip always runs three steps: up to two surplus steps past p_end
   // compute planes nobody stores (loads and stores are range-guarded), which
   // keeps the loop body free of control flow between the phases
-  for (int p = p_begin; p < p_end; p += 3) {
+  for (int p = p_begin; p < p_last; p += 3) {
     sf_step<0>(st, lds_all + image, in, out, sc, cx, p, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
     sf_step<1>(st, lds_all + image, in, out, sc, cx, p + 1, p_end SF_STAMP_PASS);

@@ -275,7 +275,7 @@ static size_t star_lds_bytes(const StarCfg& c, DT dt) {
 static int star_regs_estimate(const StarCfg& c, DT dt) {
   const int words = (dt == DT::F64) ? 2 : 1;
   const int P = c.RJ * c.VK;
-  return 3 * c.T * P * words + 95 + (words - 1) * 20 + (c.prefetch2 ? P * words : 0);
+  return 3 * c.T * P * words + 95 + (words - 1) * 20 + ((c.prefetch2 || c.reverse == 2) ? P * words : 0);
 }
 
 static int star_blocks_per_cu(const StarCfg& c, DT dt) {
@@ -319,7 +319,7 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
     const long long blocks = (long long)tiles * real_nch;
     const long long rounds = (blocks + slots - 1) / slots;
     const double quant = (double)(rounds * slots) / (double)blocks;
-    const double warm = (double)(li + 2 * c.T) / (double)li;
+    const double warm = (double)(li + 2 * c.T + (c.reverse ? c.T - 1 : 0)) / (double)li;
     // more rounds amortise the tail when block times differ
     const double cost = warm * quant * (1.0 + 0.02 / (double)rounds);
     if (cost < best - 1e-12) {
@@ -349,7 +349,8 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   base.opaque = (int)pl.opt.get("k1.opaque", 1);
   base.stamp = (int)pl.opt.get("stamp", 0);
   base.spread = (int)pl.opt.get("k1.spread", 1);
-  base.prefetch2 = (int)pl.opt.get("k1.pf2", dt == DT::F32 ? 1 : 0);
+  base.reverse = (int)pl.opt.get("k1.rev", 0);
+  base.prefetch2 = base.reverse ? 0 : (int)pl.opt.get("k1.pf2", dt == DT::F32 ? 1 : 0);
   base.experiment = (int)pl.opt.get("experiment", 0);
   base.dpp = (int)pl.opt.get("k1.dpp", 1);
   base.nt = (int)pl.opt.get("k1.nt", 0);
@@ -564,11 +565,13 @@ static void build_plan(sf_plan& pl) {
       StarShape sh0;
       star_eligible(P, P.kernels[st.kernels[0]], &sh0);
       r.push_back(sh0.primary);  // argument 0: the streamed field
+      // then the auxiliary fields in first-use order; a later stage may name the
+      // streamed field itself (centre read at its own plane), which then appears twice
       for (int k : st.kernels) {
         StarShape sh;
         star_eligible(P, P.kernels[k], &sh);
         for (auto& f : sh.aux)
-          if (std::find(r.begin(), r.end(), f) == r.end()) r.push_back(f);
+          if (std::find(r.begin() + 1, r.end(), f) == r.end()) r.push_back(f);
       }
     } else {
       for (auto& a : P.kernels[st.kernels[0]].acc)
@@ -621,9 +624,10 @@ static void build_plan(sf_plan& pl) {
     st.out_buf = ob;
     buf_of[of.name] = ob;
     // release temporaries whose last reader was this step
+    std::set<std::string> released;
     for (auto& f : step_reads(st)) {
       const Field& rf = P.field(f);
-      if (rf.role == Role::Temp && last_use[f] == (int)s) {
+      if (rf.role == Role::Temp && last_use[f] == (int)s && released.insert(f).second) {
         const int b = buf_of[f];
         free_pool.insert({{pl.buffers[b].bytes(), (int)pl.buffers[b].dt}, b});
         buf_of.erase(f);

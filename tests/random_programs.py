@@ -166,3 +166,101 @@ def random_inputs(prog, seed):
         else:
             vals[name] = desc["data"]
     return vals
+
+
+# --- random chains of radius-1 star operators (the fused plane-streaming kernel's
+# shape) on awkward domain sizes; only + - * and selects --------------------------
+EXACT = [0.0, 0.25, -1.5, 1.0, 0.5, -0.125, 2.0]
+
+
+def star_program(seed):
+    rng = np.random.default_rng(seed)
+    nd = 3 if rng.random() < 0.7 else 2
+    its = ["i", "j", "k"][3 - nd:]
+    if nd == 3:
+        dims = [int(rng.integers(3, 25)), int(rng.integers(3, 41)), 4 * int(rng.integers(2, 41))]
+    else:
+        dims = [int(rng.integers(3, 120)), 4 * int(rng.integers(2, 80))]
+    dtype = "float32" if rng.random() < 0.6 else "float64"
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": [],
+            "dimensions": dims, "program": {}}
+    if rng.random() < 0.4:
+        prog["inputs"]["p"] = {"data": "constant:0.5",
+                               "data_type": "float32" if rng.random() < 0.5 else "float64"}
+    scalars = []
+    for n in range(int(rng.integers(0, 3))):
+        name = "s%d" % n
+        prog["inputs"][name] = {"data": float(np.round(rng.uniform(-1, 1), 3)), "data_type": dtype,
+                                "input_dims": []}
+        scalars.append(name)
+    stages = int(rng.integers(1, 7))
+    prev = "a"
+    for s in range(stages):
+        name = "b%d" % s
+        offs = []
+        for d in range(nd):
+            for o in (-1, 1):
+                if rng.random() < 0.75:
+                    offs.append((d, o))
+        if not offs:
+            offs.append((int(rng.integers(0, nd)), int(rng.choice([-1, 1]))))
+        if rng.random() < 0.6:
+            offs.append((0, 0))
+        order = rng.permutation(len(offs))
+        terms = []
+        for t in order:
+            d, o = offs[int(t)]
+            idx = [it if e != d or o == 0 else "%s%+d" % (it, o) for e, it in enumerate(its)]
+            acc = "%s[%s]" % (prev, ",".join(idx))
+            r = rng.random()
+            if r < 0.5:
+                terms.append(acc)
+            elif r < 0.8 or not scalars:
+                terms.append("%r*%s" % (float(np.round(rng.uniform(-1, 1), 4)), acc))
+            else:
+                terms.append("%s*%s" % (rng.choice(scalars), acc))
+        expr = terms[0]
+        for t in terms[1:]:
+            expr = "%s %s %s" % (expr, rng.choice(["+", "+", "-"]), t)
+            if rng.random() < 0.3:
+                expr = "(" + expr + ")"
+        bcs = {}
+        extra = []
+        if "p" in prog["inputs"] and rng.random() < 0.4:
+            extra.append("p")
+        if s >= 2 and rng.random() < 0.2:
+            extra.append("b%d" % int(rng.integers(0, s - 1)))
+        if prev != "a" and rng.random() < 0.15:
+            extra.append("a")
+        for f in extra:
+            expr = "%s %s %s[%s]" % (expr, rng.choice(["+", "-", "*"]), f, ",".join(its))
+            bcs[f] = {"type": "constant", "value": 0.0}
+        coef = rng.random()
+        if coef < 0.5:
+            expr = "%r * (%s)" % (float(np.round(rng.uniform(0.1, 0.3), 8)), expr)
+        elif coef < 0.65 and scalars:
+            expr = "%s * (%s)" % (rng.choice(scalars), expr)
+        if rng.random() < 0.15:
+            centre = "%s[%s]" % (prev, ",".join(its))
+            expr = "(%s) if %s > 0.0 else (%s + 1)" % (expr, centre, expr)
+        kind = rng.random()
+        if kind < 0.1:
+            bcs[prev] = {"type": "shrink"}
+        elif kind < 0.35:
+            bcs[prev] = {"type": "constant", "value": int(rng.integers(-1, 3))}
+        else:
+            bcs[prev] = {"type": "constant", "value": float(rng.choice(EXACT))}
+        prog["program"][name] = {"computation_string": "%s = %s" % (name, expr),
+                                 "boundary_conditions": bcs, "data_type": dtype}
+        if s < stages - 1 and rng.random() < 0.1:
+            prog["outputs"].append(name)
+        prev = name
+    prog["outputs"].append(prev)
+    text = " ".join(k["computation_string"] for k in prog["program"].values())
+    for name in list(prog["inputs"]):
+        if name != "a" and (name + "[") not in text and name not in scalars:
+            del prog["inputs"][name]
+    for name in scalars:
+        if name not in text:
+            del prog["inputs"][name]
+    return prog

@@ -63,3 +63,50 @@ def test_hip_matches_oracle_on_random_programs(seed, tmp_path):
     for k in want:
         assert np.array_equal(outs[k], want[k], equal_nan=True), (
             seed, k, npo.max_rel_err(want[k], outs[k]), json.dumps(prog)[:400])
+
+
+STAR_CPU_SEEDS = list(range(0, 12))
+STAR_GPU_SEEDS = list(range(0, 48))
+
+
+def _star_case(seed, tmp_path):
+    from tests.random_programs import star_program
+    prog = star_program(seed)
+    rng = np.random.default_rng(seed + 7)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    path = programs.write_program(prog, str(tmp_path / "p.json"))
+    return prog, ins, sf.KernelChainGraph(path), {"fuse": int(rng.integers(1, 5))}
+
+
+@pytest.mark.parametrize("seed", STAR_CPU_SEEDS)
+def test_random_star_chains_plan(seed, tmp_path):
+    """Every random star chain is planned onto fused star kernels (CPU: hipRTC
+    only) and the two oracles agree on it."""
+    prog, ins, chain, opt = _star_case(seed, tmp_path)
+    a = npo.run_reference(prog, inputs=ins)
+    b = c_oracle.CompiledReference(prog).run(inputs=ins)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (seed, k)
+    with Plan(lower(chain), options=opt) as plan:
+        assert "[star" in plan.describe()
+        assert sorted(plan.output_names) == sorted(prog["outputs"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", STAR_GPU_SEEDS)
+def test_hip_matches_oracle_on_random_star_chains(seed, tmp_path):
+    prog, ins, chain, opt = _star_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain), options=opt) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]])
+                for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:400])
