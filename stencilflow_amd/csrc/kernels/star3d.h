@@ -36,6 +36,9 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #ifndef SF_REVERSE
 #define SF_REVERSE 0
 #endif
+#ifndef SF_PFD
+#define SF_PFD 1
+#endif
 #if SF_REVERSE  // loads are issued at the end of the step: no staging registers
 #undef SF_PREFETCH2
 #define SF_PREFETCH2 0
@@ -68,8 +71,10 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 // phase PH the slots hold  prev = PH % 3,  cur = (PH + 1) % 3,  next = (PH + 2) % 3.
 struct sf_state {
   sf_vec w[SF_T][3][SF_RJ];
-#if SF_PREFETCH2 || SF_REVERSE == 2
-  sf_vec pf[SF_RJ];  // input plane in flight: a full step to land
+#if SF_REVERSE == 2 || SF_PREFETCH2
+  // input planes in flight: a ring of SF_PFD (1 or 3) planes, so a load has
+  // SF_PFD full steps to land (slot = phase % SF_PFD)
+  sf_vec pf[SF_PFD][SF_RJ];
 #endif
 };
 
@@ -191,8 +196,8 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       // row r of the input window's "prev" slot is dead now: it takes row r of
       // plane p+1 from the staging registers (loaded during the previous step),
       // which then receive row r of plane p+2
-      st.w[0][iprev][r] = st.pf[r];
-      if (load_next) st.pf[r] = sf_load_row(cx, p + 2, r);
+      st.w[0][iprev][r] = st.pf[PH % SF_PFD][r];
+      if (load_next) st.pf[PH % SF_PFD][r] = sf_load_row(cx, p + 1 + SF_PFD, r);
     }
 #elif SF_SPREAD_LOADS
     if constexpr (S == 1) {
@@ -299,7 +304,7 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
   // stage) enters the window as plane "next"; this is the step's only wait on
   // vector memory, and everything it waits for is at least a stage old
 #pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) st.w[0][(PH + 2) % 3][r] = st.pf[r];
+  for (int r = 0; r < SF_RJ; ++r) st.w[0][(PH + 2) % 3][r] = st.pf[PH % SF_PFD][r];
 #endif
   // Make the window opaque at the step boundary: otherwise the compiler keeps
   // the f64 conversions of whole planes alive from one unrolled step to the
@@ -347,7 +352,7 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
   sf_later_stages_desc<SF_T, PH>(st, lds, sc, out, cx, p);
   SF_STAMP_AT(3);
 #if SF_REVERSE == 2
-  if (p + 1 < p_end) sf_load_plane(in, cx, p + 1, st.pf);
+  if (p + SF_PFD < p_end) sf_load_plane(in, cx, p + SF_PFD, st.pf[PH % SF_PFD]);
   SF_STAMP_AT(2);
   sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
   SF_STAMP_AT(1);
@@ -363,7 +368,7 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
   // stage 1 consumes input plane p (slot "next" of the input window) and frees
   // slot "prev", which receives input plane p+1
 #if SF_PREFETCH2
-  sf_stage_step<1, PH>(st, lds, sc, out, cx, p, p + 2 < p_end);
+  sf_stage_step<1, PH>(st, lds, sc, out, cx, p, p + 1 + SF_PFD < p_end);
   SF_STAMP_AT(1);
 #elif SF_SPREAD_LOADS
   sf_stage_step<1, PH>(st, lds, sc, out, cx, p, p + 1 < p_end);
@@ -461,13 +466,19 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   // T-1 more steps because its stages lag further)
   const int p_begin = cx.cb - SF_T, p_end = cx.ce + SF_T;
   const int p_last = SF_REVERSE ? cx.ce + 2 * SF_T - 1 : p_end;
-#if SF_REVERSE == 2
-  sf_load_plane(in, cx, p_begin, st.pf);
-#else
+#if SF_REVERSE != 2
   sf_load_plane(in, cx, p_begin, st.w[0][2]);  // slot "next" of phase 0
 #endif
-#if SF_PREFETCH2
-  if (p_begin + 1 < p_end) sf_load_plane(in, cx, p_begin + 1, st.pf);
+#if SF_PREFETCH2 || SF_REVERSE == 2
+  // fill the prefetch ring: the planes after the one stage 1 starts with
+  // (SF_REVERSE 2: including that one)
+#pragma unroll
+  for (int d = 0; d < SF_PFD; ++d) {
+    const int pd = p_begin + d + (SF_REVERSE == 2 ? 0 : 1);
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r) st.pf[d][r] = (sf_vec)(sf_t)0;
+    if (pd < p_end) sf_load_plane(in, cx, pd, st.pf[d]);
+  }
 #endif
 
   // Two exchange images alternate every step (run-time offset); the window

@@ -275,7 +275,7 @@ static size_t star_lds_bytes(const StarCfg& c, DT dt) {
 static int star_regs_estimate(const StarCfg& c, DT dt) {
   const int words = (dt == DT::F64) ? 2 : 1;
   const int P = c.RJ * c.VK;
-  return 3 * c.T * P * words + 95 + (words - 1) * 20 + ((c.prefetch2 || c.reverse == 2) ? P * words : 0);
+  return 3 * c.T * P * words + 95 + (words - 1) * 20 + ((c.prefetch2 || c.reverse == 2) ? P * words * c.pfd : 0);
 }
 
 static int star_blocks_per_cu(const StarCfg& c, DT dt) {
@@ -317,6 +317,23 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
     const int li = (range + nch - 1) / nch;
     const int real_nch = (range + li - 1) / li;
     const long long blocks = (long long)tiles * real_nch;
+    if (c.noj) {
+      // 2-D programs: a block is one (or a few) self-contained waves with a
+      // short dependent step, so the sweep is latency-bound until about three
+      // waves share a SIMD (profiles/r01_sweep_10_c2_chunks.log: 4096^2 is
+      // fastest at 24-row chunks = 2.8 waves per SIMD, 1.8x the rate of
+      // 92-row chunks).  Below that, time follows the chunk length; above it,
+      // the warm-up redundancy.
+      const double waves_per_simd = (double)blocks * (double)(c.BX / 64) / 1024.0;
+      const double warm = (double)(li + 2 * c.T + (c.reverse ? c.T - 1 : 0)) / (double)li;
+      const double cost = warm * std::max(1.0, 3.0 / waves_per_simd);
+      if (cost < best - 1e-12) {
+        best = cost;
+        best_li = li;
+      }
+      if (waves_per_simd > 8.0) break;
+      continue;
+    }
     const long long rounds = (blocks + slots - 1) / slots;
     const double quant = (double)(rounds * slots) / (double)blocks;
     const double warm = (double)(li + 2 * c.T + (c.reverse ? c.T - 1 : 0)) / (double)li;
@@ -330,6 +347,14 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
   }
   if (cost_out) *cost_out = best;
   return best_li;
+}
+
+// chunk length used for a launch over `range` planes (options k1.li / k2.li pin it)
+static long long star_chunk_length(const sf_plan& pl, const StarCfg& c, DT dt, int range) {
+  long long li = pl.opt.get(c.noj ? "k2.li" : "k1.li", 0);
+  if (li <= 0) li = star_chunk_planes(c, dt, range);
+  if (li > range) li = range;
+  return std::max<long long>(li, 1);
 }
 
 static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
@@ -346,11 +371,18 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   base.noj = (P.n[1] == 1);
   base.row_fence = (int)pl.opt.get("k1.fence", 1);
   base.lds_db = (int)pl.opt.get("k1.db", 1);
-  base.opaque = (int)pl.opt.get("k1.opaque", 1);
+  base.opaque = (int)pl.opt.get("k1.opaque", base.noj ? 0 : 1);  // 2-D: registers are plentiful
   base.stamp = (int)pl.opt.get("stamp", 0);
   base.spread = (int)pl.opt.get("k1.spread", 1);
-  base.reverse = (int)pl.opt.get("k1.rev", 0);
+  // step order: 3-D kernels run stage 1 first (k1.rev=0); 2-D kernels run the
+  // storing stage first, which makes the stages of one step independent of each
+  // other (more instruction-level parallelism for the lone wave) -- measured
+  // +30 % on C2, no change on C3 (profiles/r01_sweep_9_step_order.log)
+  base.reverse = (int)pl.opt.get("k1.rev", base.noj ? 1 : 0);
   base.prefetch2 = base.reverse ? 0 : (int)pl.opt.get("k1.pf2", dt == DT::F32 ? 1 : 0);
+  base.pfd = (int)pl.opt.get("k1.pfd", 1);
+  if (base.pfd != 1 && base.pfd != 3) throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
+  if (!base.prefetch2 && base.reverse != 2) base.pfd = 1;
   base.experiment = (int)pl.opt.get("experiment", 0);
   base.dpp = (int)pl.opt.get("k1.dpp", 1);
   base.nt = (int)pl.opt.get("k1.nt", 0);
@@ -702,8 +734,9 @@ static void build_plan(sf_plan& pl) {
     for (int k : st.kernels) desc << P.kernels[k].name << " ";
     if (st.star)
       desc << "[star T=" << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
-           << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " lds "
-           << star_lds_bytes(st.cfg, dt) << " B]";
+           << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " chunk "
+           << star_chunk_length(pl, st.cfg, dt, (int)pl.n_local) << " lds " << star_lds_bytes(st.cfg, dt)
+           << " B]";
     else
       desc << "[point]";
     desc << " in";
@@ -806,9 +839,7 @@ static void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, i
     // chunking of the stream axis: whole block waves (star_chunk_planes)
     const int range1 = std::max(0, i_end - i_begin), range2 = second ? i_end2 - i_begin2 : 0;
     const int tiles = c.NJT * c.NKT;
-    long long li = pl.opt.get(c.noj ? "k2.li" : "k1.li", 0);
-    if (li <= 0) li = star_chunk_planes(c, P.kernels[st.kernels[0]].dt, std::max(range1, range2));
-    if (li > std::max(range1, range2)) li = std::max(range1, range2);
+    const long long li = star_chunk_length(pl, c, P.kernels[st.kernels[0]].dt, std::max(range1, range2));
     int nch1 = (int)((range1 + li - 1) / li);
     const int nch2 = (int)((range2 + li - 1) / li);
     int li_i = (int)li;
