@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-end evidence for profiles/: for the C3 (default) and C2 bench workloads
+#   1. rocprofv3 --kernel-trace --stats of the bench command (kernel average duration),
+#   2. FETCH_SIZE and WRITE_SIZE in separate PMC passes (HBM bytes per launch),
+# then tools/hbm_traffic.py folds the counters into profiles/hbm_traffic.json.
+# Every rocprofv3 call runs the program directly after `--` and under its own timeout.
+# usage (on the GPU box): bash tools/profile_round.sh <round-tag>
+set -u
+tag=${1:-r01}
+export TMPDIR=/tmp
+for wl in c3 c2; do
+  out=gpurun_out/prof_${tag}_$wl
+  rm -rf $out; mkdir -p $out
+  args="bench.py --workload $wl --steps 1 --warmup 0 --stages 100 --no-cpu-baseline"
+  # the trace pass runs the bench command itself (default steps / warm-up), so its
+  # average kernel duration is the one the bench line reports
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --workload $wl --no-cpu-baseline > $out/trace.log 2>&1
+  i=0
+  for pmc in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $out/pmc_$i -- python3 $args > $out/pmc_$i.log 2>&1
+  done
+  python3 tools/profile_summary.py $out > /dev/null
+  cp $out/summary.txt gpurun_out/${tag}_bench_${wl}_rocprof_summary.txt
+  f=$(ls -t $out/trace/*/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && cp "$f" gpurun_out/${tag}_bench_${wl}_kernel_stats.csv
+done
+python3 tools/hbm_traffic.py $tag gpurun_out/hbm_traffic.json
