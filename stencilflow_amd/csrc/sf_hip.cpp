@@ -110,6 +110,11 @@ struct sf_plan {
   std::vector<Step> steps;
   std::vector<int> input_buf, output_buf;  // by io_index
   std::vector<double> scalar_values;       // by Scalar::input_index
+  // one repetition of the whole chain as an instantiated hipGraph (launch-bound
+  // plans only, see execute()); rebuilt when the scalars it captured change
+  hipGraphExec_t chain_graph = nullptr;
+  std::vector<double> chain_graph_scalars;
+  double max_updates_per_launch = 0;
   bool scalars_set = false;
   // slab decomposition of I0
   long long n_local = 0, goff = 0;
@@ -698,12 +703,13 @@ static void build_plan(sf_plan& pl) {
       // one-point form is kept for short rows and for operators whose vector
       // form would spill (same acceptance rule as for the star kernels)
       const bool vec = (P.n[2] % 4 == 0) && pl.opt.get("generic.vec", 1) != 0;
-      GenericKernelSource g = vec ? gen_generic_vec(P, st.kernels[0]) : gen_generic(P, st.kernels[0]);
+      const bool xcd = pl.opt.get("generic.xcd", 1) != 0;
+      GenericKernelSource g = vec ? gen_generic_vec(P, st.kernels[0], xcd) : gen_generic(P, st.kernels[0], xcd);
       st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
       if (vec) {
         const CompiledKernel& k = pl.kernels[st.ck];
         if (std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs) > 0) {
-          g = gen_generic(P, st.kernels[0]);
+          g = gen_generic(P, st.kernels[0], xcd);
           st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
         }
       }
@@ -727,6 +733,7 @@ static void build_plan(sf_plan& pl) {
       throw Error(SF_ERR_INVALID, "slab halo is shallower than a launch's reach; raise the halo");
     CompiledKernel& ck = pl.kernels[st.ck];
     ck.updates_per_launch = cells * (double)st.kernels.size();
+    pl.max_updates_per_launch = std::max(pl.max_updates_per_launch, ck.updates_per_launch);
     ck.alg_bytes_per_launch = 0;
     for (int k : st.kernels) ck.alg_bytes_per_launch += cells * 2.0 * (double)size_of(P.kernels[k].dt);
     if (desc.tellp() > 16384) continue;  // long chains: describe the first launches only
@@ -941,6 +948,44 @@ static void execute(sf_plan& pl, int repetitions) {
     k.launches = 0;
     k.total_ms = 0;
   }
+  // Launch-bound chains (many launches of a few microseconds each: small grids)
+  // are replayed as one hipGraph, which removes the per-launch host cost; big
+  // grids keep plain stream launches (nothing to gain, 213 us per launch on C3).
+  // graph=0|1 forces the choice.
+  const bool small = pl.max_updates_per_launch > 0 && pl.max_updates_per_launch < 8.0e6;
+  const bool want_graph = pl.opt.get("graph", (small && pl.steps.size() >= 4) ? 1 : 0) != 0;
+  bool stamp = false;
+  for (auto& st : pl.steps) stamp = stamp || (st.star && st.cfg.stamp);
+  if (want_graph && !pl.profile && !stamp && repetitions > 0) {
+    if (!pl.chain_graph || pl.chain_graph_scalars != pl.scalar_values) {
+      if (pl.chain_graph) {
+        (void)hipGraphExecDestroy(pl.chain_graph);
+        pl.chain_graph = nullptr;
+      }
+      hipGraph_t graph = nullptr;
+      SF_HIP_CHECK(hipStreamBeginCapture(pl.stream, hipStreamCaptureModeThreadLocal));
+      try {
+        for (auto& st : pl.steps) launch_step(pl, st, 0, pl.stream);
+      } catch (...) {
+        (void)hipStreamEndCapture(pl.stream, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+      }
+      SF_HIP_CHECK(hipStreamEndCapture(pl.stream, &graph));
+      const hipError_t inst = hipGraphInstantiate(&pl.chain_graph, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (inst != hipSuccess) {
+        pl.chain_graph = nullptr;
+        throw Error(SF_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(inst));
+      }
+      pl.chain_graph_scalars = pl.scalar_values;
+    }
+    SF_HIP_CHECK(hipEventRecord(pl.ev_begin, pl.stream));
+    for (int r = 0; r < repetitions; ++r) SF_HIP_CHECK(hipGraphLaunch(pl.chain_graph, pl.stream));
+    SF_HIP_CHECK(hipEventRecord(pl.ev_end, pl.stream));
+    pl.timed = true;
+    return;
+  }
   SF_HIP_CHECK(hipEventRecord(pl.ev_begin, pl.stream));
   for (int r = 0; r < repetitions; ++r)
     for (auto& st : pl.steps) launch_step(pl, st, 0, pl.stream);
@@ -1008,6 +1053,7 @@ int sf_plan_destroy(sf_plan* plan) {
     if (plan->debug_buffer) (void)hipFree(plan->debug_buffer);
     for (auto& k : plan->kernels)
       if (k.mod) (void)hipModuleUnload(k.mod);
+    if (plan->chain_graph) (void)hipGraphExecDestroy(plan->chain_graph);
     (void)hipEventDestroy(plan->ev_begin);
     (void)hipEventDestroy(plan->ev_end);
     (void)hipStreamDestroy(plan->stream);

@@ -516,3 +516,32 @@ def test_run_program_flags(programs_dir, tmp_path, monkeypatch):
     assert run_program(path, "hip", log_level=sf.LogLevel.NO_LOG) is None
     with pytest.raises(ValueError, match="Unrecognized execution mode"):
         run_program(path, "simulation", log_level=sf.LogLevel.NO_LOG)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_graph_replay_follows_scalar_changes(tmp_path, graph):
+    """Launch-bound chains are replayed as one hipGraph (sf_hip.cpp: execute);
+    the captured launches carry the scalar arguments by value, so changing a
+    scalar input must rebuild the graph.  Same plan, three runs, two scalar
+    sets; graph=0 is the plain stream path."""
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    shape = (12, 20, 32)
+    rng = np.random.default_rng(SEED + 21)
+    prog = programs.diffusion_advection_laplacian(shape, repeats=3)  # 9 operators
+    x = rng.uniform(-1, 1, shape)
+    path = _write(tmp_path, prog)
+    chain = sf.KernelChainGraph(path)
+    out_name = prog["outputs"][0]
+    with Plan(lower(chain), options={"graph": graph, "fuse": 2}) as plan:
+        assert plan.num_launches >= 4
+        for scale in (1.0, 0.5, 1.0):
+            ins = _inputs_of(prog)
+            for k in ins:
+                ins[k] = ins[k] * scale
+            ins["a"] = x
+            want = npo.run_reference(prog, inputs=ins)[out_name]
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+            got = np.zeros(shape)
+            plan.run([x], [got], 2)  # two repetitions on the same buffers
+            assert np.array_equal(got, want), (graph, scale)
