@@ -39,6 +39,7 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #ifndef SF_PFD
 #define SF_PFD 1
 #endif
+
 #if SF_REVERSE  // loads are issued at the end of the step: no staging registers
 #undef SF_PREFETCH2
 #define SF_PREFETCH2 0
@@ -117,13 +118,18 @@ __device__ __forceinline__ T sf_neighbour_lane(T x) {
 #endif
 }
 
+// Is row r of input plane p inside the global domain (and inside what this chunk reads)?
+__device__ __forceinline__ bool sf_row_ok(const sf_ctx& cx, const int p, const int r) {
+  const bool plane_in = (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
+  // SF_EXPERIMENT 5: timing-only build without the input loads (invalid results)
+  return SF_EXPERIMENT != 5 && plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in;
+}
+
 // Row r of input plane p (padded with stage 1's boundary constant outside the
 // global domain).
 __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, const int r) {
   sf_vec v = (sf_vec)sf_stage<1>::bc();
-  const bool plane_in = (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
-  // SF_EXPERIMENT 5: timing-only build without the input loads (invalid results)
-  if (SF_EXPERIMENT != 5 && plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in) {
+  if (sf_row_ok(cx, p, r)) {
     const sf_t* plane = cx.in + (size_t)(p + cx.halo) * ((size_t)SF_N1 * SF_N2);
 #if SF_NT & 2
     v = __builtin_nontemporal_load(reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)));
@@ -260,16 +266,8 @@ __device__ __forceinline__ void sf_later_stages_desc(sf_state& st, const sf_t* l
 
 __device__ __forceinline__ void sf_load_plane(const sf_t* __restrict__ in, const sf_ctx& cx,
                                               const int p, sf_vec (&dst)[SF_RJ]) {
-  const sf_t pad0 = sf_stage<1>::bc();
-  const bool plane_in = (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
-  const sf_t* plane = in + (size_t)(p + cx.halo) * ((size_t)SF_N1 * SF_N2);
 #pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) {
-    sf_vec v = (sf_vec)pad0;
-    if (plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in)
-      v = *reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0));
-    dst[r] = v;
-  }
+  for (int r = 0; r < SF_RJ; ++r) dst[r] = sf_load_row(cx, p, r);
 }
 
 // One step (input plane p) at phase PH.
@@ -352,7 +350,10 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
   sf_later_stages_desc<SF_T, PH>(st, lds, sc, out, cx, p);
   SF_STAMP_AT(3);
 #if SF_REVERSE == 2
-  if (p + SF_PFD < p_end) sf_load_plane(in, cx, p + SF_PFD, st.pf[PH % SF_PFD]);
+  if (p + SF_PFD < p_end) {
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r) st.pf[PH % SF_PFD][r] = sf_load_row(cx, p + SF_PFD, r);
+  }
   SF_STAMP_AT(2);
   sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
   SF_STAMP_AT(1);
@@ -477,7 +478,10 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     const int pd = p_begin + d + (SF_REVERSE == 2 ? 0 : 1);
 #pragma unroll
     for (int r = 0; r < SF_RJ; ++r) st.pf[d][r] = (sf_vec)(sf_t)0;
-    if (pd < p_end) sf_load_plane(in, cx, pd, st.pf[d]);
+    if (pd < p_end) {
+#pragma unroll
+      for (int r = 0; r < SF_RJ; ++r) st.pf[d][r] = sf_load_row(cx, pd, r);
+    }
   }
 #endif
 
