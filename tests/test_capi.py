@@ -84,3 +84,33 @@ def test_no_cpu_fallback_without_a_device(programs_dir):
     with pytest.raises(RuntimeError, match="no HIP device|hip"):
         prog(a_host=a, b_host=b)
     assert not b.any()
+
+
+def _describe(tmp_path, prog, options=None):
+    path = programs.write_program(prog, str(tmp_path / "p.json"))
+    with backend.Plan(lower(sf.KernelChainGraph(path)), options=options) as plan:
+        return plan.describe()
+
+
+def test_planner_shapes_for_the_benchmark_configurations(tmp_path):
+    """The tile / chunk choices the measured numbers rest on:
+    C3 fills the 256 CUs with exactly one 512-thread block each; C2 is chunked
+    for about three waves per SIMD (the 2-D kernel is issue-bound below that);
+    C5 fuses the three operators into one launch."""
+    c3 = _describe(tmp_path, programs.jacobi3d((512, 512, 512), 4))
+    m = re.search(r"star T=2 block (\d+)x(\d+) rows/thread (\d+) tiles (\d+)x(\d+) chunk (\d+)", c3)
+    assert m, c3
+    bx, by, rj, njt, nkt, li = map(int, m.groups())
+    assert bx * 4 == 512 and nkt == 1              # whole rows, no column halo
+    assert njt * nkt * -(-512 // li) == 256          # one block per CU
+    assert "spill 0 scratch 0" in c3 and "agpr 0" in c3
+
+    c2 = _describe(tmp_path, programs.jacobi2d((4096, 4096), 8))
+    m = re.search(r"star T=4 block 64x1 rows/thread 1 tiles 1x(\d+) chunk (\d+)", c2)
+    assert m, c2
+    strips, li = map(int, m.groups())
+    waves_per_simd = strips * -(-4096 // li) / 1024.0
+    assert 2.5 <= waves_per_simd <= 4.0, c2
+
+    c5 = _describe(tmp_path, programs.diffusion_advection_laplacian((512, 512, 512)))
+    assert "1 launches" in c5 and "star T=3" in c5
