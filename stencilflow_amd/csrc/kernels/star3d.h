@@ -18,18 +18,32 @@
 //   thread = SF_RJ consecutive rows x SF_VK consecutive k (one 16-byte vector
 //            per row); for every stage boundary a window of three planes
 //            (q-1, q, q+1) lives in registers.
-//   Per step one new input plane is read from HBM (coalesced 16 B/lane) and
-//   stage s produces plane p-s; i-neighbours come from the register window,
-//   j-neighbours from registers (inner rows) or LDS (first/last row of the
-//   adjacent thread row), k-neighbours from the adjacent lane (__shfl) or,
-//   at a wave edge, from LDS.
+//   Per step one new input plane is read from HBM (coalesced 16 B/lane);
+//   i-neighbours come from the register window, j-neighbours from registers
+//   (inner rows) or LDS (first/last row of the adjacent thread row),
+//   k-neighbours from the adjacent lane (DPP wave_shr/wave_shl) or, at a wave
+//   edge, from LDS.
 //   The three window slots rotate by *phase*: the step loop is unrolled by 3
 //   with compile-time slot indices, so no register is ever copied -- the slot
 //   that held plane q-1 receives plane q+2.
 //
+// Step order (SF_REVERSE)
+//   0  stage 1 first, then stages 2..T, each consuming what the previous one
+//      produced in the same step; stage S produces plane p-S.  Default in 3-D.
+//   1  the storing stage T first, stage 1 last: every stage reads only planes
+//      finished in earlier steps (stage S produces plane p-(2S-1)), so the
+//      stages of one step are independent of each other.  Default in 2-D, where
+//      a block is a lone wave.
+//   2  as 1, with the input plane staged in `pf` and moved into the window at
+//      the start of the step.
+//
 // Macros from codegen: SF_T SF_VK SF_RJ SF_BX SF_BY SF_HK SF_KTILED SF_NOJ
-//   SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_LDS_DB SF_ROW_FENCE SF_KERNEL_NAME,
-//   typedef sf_t, struct sf_scalars, template<int S> struct sf_stage {bc(), apply()}.
+//   SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_LDS_DB SF_ROW_FENCE SF_OPAQUE SF_REVERSE
+//   SF_PREFETCH2 SF_PFD SF_SPREAD_LOADS SF_DPP SF_NT SF_NAUX SF_KERNEL_NAME;
+//   diagnostic builds: SF_STAMP (cycle stamps), SF_EXPERIMENT (timing-only
+//   variants with parts removed -- results invalid);
+//   typedef sf_t, struct sf_scalars, struct sf_auxptrs,
+//   template<int S> struct sf_stage {bc(), load_aux(), apply()}.
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 
