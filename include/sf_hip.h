@@ -147,6 +147,12 @@ int sf_plan_execute_step(sf_plan* plan, int step, int part, void* stream);
  * is how a deep halo is made to last several launches). */
 int sf_plan_execute_step_ranges(sf_plan* plan, int step, int i_begin, int i_end,
                                 int i_begin2, int i_end2, void* stream);
+/* Keep `cus` of the 256 compute units free of this plan's blocks in the launches
+ * that follow (0 = use them all): the chunking of the star kernels then fills
+ * 256 - cus units.  The slab runner sets it around the interior launch that
+ * runs beside a halo exchange, so that the RCCL copy kernels find free units
+ * instead of queueing behind 200-microsecond blocks that leave no registers. */
+int sf_plan_set_reserved_cus(sf_plan* plan, int cus);
 /* Device address, plane size in bytes and plane count of device buffer `id`. */
 int sf_plan_buffer_info(const sf_plan* plan, int buffer_id, void** device_ptr,
                         size_t* plane_bytes, int* planes);

@@ -73,6 +73,7 @@ API = [
     ("sf_plan_step_output", _I, [_P, _I]),
     ("sf_plan_execute_step", _I, [_P, _I, _I, _P]),
     ("sf_plan_execute_step_ranges", _I, [_P, _I, _I, _I, _I, _I, _P]),
+    ("sf_plan_set_reserved_cus", _I, [_P, _I]),
     ("sf_plan_buffer_info", _I,
      [_P, _I, _PP, ctypes.POINTER(ctypes.c_size_t), _IP]),
     ("sf_plan_input_buffer", _I, [_P, _I]),
@@ -319,6 +320,10 @@ class Plan:
                                                   int(i_end), int(i_begin2),
                                                   int(i_end2),
                                                   ctypes.c_void_p(stream or 0)))
+
+    def set_reserved_cus(self, cus):
+        """Leave `cus` compute units free in the launches that follow (0 = none)."""
+        _check(self._lib.sf_plan_set_reserved_cus(self._h, int(cus)))
 
     def buffer_info(self, buffer_id):
         ptr = ctypes.c_void_p()

@@ -115,6 +115,7 @@ struct sf_plan {
   hipGraphExec_t chain_graph = nullptr;
   std::vector<double> chain_graph_scalars;
   double max_updates_per_launch = 0;
+  int reserved_cus = 0;  // compute units the star launches leave free (sf_plan_set_reserved_cus)
   bool scalars_set = false;
   // slab decomposition of I0
   long long n_local = 0, goff = 0;
@@ -312,9 +313,10 @@ static void star_finish_cfg(StarCfg& c, const Program& P, int T) {
 }
 
 // chunk length along the stream axis for `range` planes: whole block waves
-static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_out = nullptr) {
+static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_out = nullptr,
+                             int reserved_cus = 0) {
   const int tiles = c.NJT * c.NKT;
-  const int slots = 256 * std::max(1, star_blocks_per_cu(c, dt));
+  const int slots = std::max(1, 256 - reserved_cus) * std::max(1, star_blocks_per_cu(c, dt));
   double best = 1e30;
   int best_li = range;
   const int max_nch = std::max(1, range / std::max(1, 2 * c.T));
@@ -357,7 +359,7 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
 // chunk length used for a launch over `range` planes (options k1.li / k2.li pin it)
 static long long star_chunk_length(const sf_plan& pl, const StarCfg& c, DT dt, int range) {
   long long li = pl.opt.get(c.noj ? "k2.li" : "k1.li", 0);
-  if (li <= 0) li = star_chunk_planes(c, dt, range);
+  if (li <= 0) li = star_chunk_planes(c, dt, range, nullptr, pl.reserved_cus);
   if (li > range) li = range;
   return std::max<long long>(li, 1);
 }
@@ -1237,6 +1239,14 @@ int sf_plan_execute_step_ranges(sf_plan* plan, int step, int i_begin, int i_end,
   return SF_OK;
   SF_API_END
 }
+int sf_plan_set_reserved_cus(sf_plan* plan, int cus) {
+  SF_API_BEGIN
+  if (!plan || cus < 0 || cus >= 256) throw sf::Error(SF_ERR_INVALID, "reserved compute units must be in [0, 256)");
+  plan->reserved_cus = cus;
+  return SF_OK;
+  SF_API_END
+}
+
 int sf_plan_buffer_info(const sf_plan* p, int id, void** device_ptr, size_t* plane_bytes, int* planes) {
   SF_API_BEGIN
   if (!p || id < 0 || id >= (int)p->buffers.size()) throw Error(SF_ERR_INVALID, "bad buffer id");

@@ -71,12 +71,17 @@ def halo_regions(n_local, halo, depth, plane_bytes):
 class TorchDistExchanger:
     """Neighbour exchange over ``torch.distributed`` point-to-point ops."""
 
+    # compute units the interior launch leaves to the copy kernels of a
+    # device-side (RCCL) exchange; host staging copies by DMA and needs none
+    RESERVED_CUS = 32
+
     def __init__(self, rank, world, group=None, staging="device"):
         import torch.distributed as dist
         self.dist = dist
         self.rank, self.world, self.group = rank, world, group
         self.staging = staging
         self._host = {}
+        self.reserved_cus = self.RESERVED_CUS if staging == "device" else 0
 
     def _ops(self, buf, regions, as_tensor):
         dist = self.dist
@@ -325,10 +330,20 @@ class SlabRunner:
                 # sends were produced by the previous launch) ...
                 handles.append(self.exchanger.start(tensor, regions, key=buf))
             if self.overlap:
-                # ... and runs beside the interior of this launch
-                self.plan.execute_step_ranges(
-                    s, d if self.has_lower else 0,
-                    n - (d if self.has_upper else 0), stream=raw)
+                # ... and runs beside the interior of this launch, which leaves a
+                # few compute units to the exchange's copy kernels: its blocks
+                # run ~200 us and hold nearly all registers of their unit, so a
+                # copy kernel would otherwise queue behind them
+                reserve = getattr(self.exchanger, "reserved_cus", 0)
+                if reserve:
+                    self.plan.set_reserved_cus(reserve)
+                try:
+                    self.plan.execute_step_ranges(
+                        s, d if self.has_lower else 0,
+                        n - (d if self.has_upper else 0), stream=raw)
+                finally:
+                    if reserve:
+                        self.plan.set_reserved_cus(0)
             return (handles, depth)
 
     def step_end(self, s, handle):

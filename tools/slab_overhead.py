@@ -17,6 +17,8 @@ from stencilflow_amd.lowering import lower  # noqa: E402
 
 
 class Null:
+    reserved_cus = 0  # compute units the overlapped interior launch leaves free
+
     def start(self, tensor, regions, key=None):
         return 1
 
@@ -31,8 +33,11 @@ def main():
         path = programs.write_program(programs.jacobi3d(shape, stages), os.path.join(tmp, "p.json"))
         sfir = lower(sf.KernelChainGraph(path))
     x = np.random.default_rng(0).random((512, 512, 512), dtype=np.float32)
-    for overlap, groups in ((True, 1), (True, 2), (True, 4), (True, 8), (False, 4)):
-        r = SlabRunner(sfir, shape, 0, 2, exchanger=Null(), overlap=overlap, groups_per_exchange=groups)
+    for overlap, groups, reserve in ((True, 1, 0), (True, 2, 0), (True, 4, 0), (True, 4, 16), (True, 4, 32),
+                                     (True, 8, 0), (True, 8, 32), (False, 4, 0)):
+        ex = Null()
+        ex.reserved_cus = reserve
+        r = SlabRunner(sfir, shape, 0, 2, exchanger=ex, overlap=overlap, groups_per_exchange=groups)
         r.upload([x])
         r.execute(); r.synchronize()
         t = time.perf_counter()
@@ -42,8 +47,8 @@ def main():
         r.execute()
         host = time.perf_counter() - t
         r.synchronize()
-        print("slab runner overlap=%s groups/exchange=%d halo=%d: %.3f ms per chain (%.1f us per group), host enqueue %.3f ms" % (
-            overlap, groups, r.halo, dt * 1e3, dt * 1e6 / len(r.steps), host * 1e3))
+        print("slab runner overlap=%s groups/exchange=%d reserved CUs=%d halo=%d: %.3f ms per chain (%.1f us per group), host enqueue %.3f ms" % (
+            overlap, groups, reserve, r.halo, dt * 1e3, dt * 1e6 / len(r.steps), host * 1e3))
         r.close()
     with tempfile.TemporaryDirectory() as tmp:
         path = programs.write_program(programs.jacobi3d((512, 512, 512), stages), os.path.join(tmp, "p.json"))
