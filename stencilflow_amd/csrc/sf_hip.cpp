@@ -279,9 +279,14 @@ static size_t star_lds_bytes(const StarCfg& c, DT dt) {
 //          * (chunk planes + 2T) / chunk planes * (block slots used / blocks)
 // over the tile shapes whose register footprint fits without spilling.
 static int star_regs_estimate(const StarCfg& c, DT dt) {
+  // window + staging registers, plus what the compiler needs around them: fitted
+  // to the code objects of this round (f32 T=2 P=20: 226; f64 T=3 P=6/8/10:
+  // 142/188/232) as 20 + 3.3 P.  It only has to be roughly right -- a shape that
+  // spills after all is rejected by select_star from its metadata.
   const int words = (dt == DT::F64) ? 2 : 1;
   const int P = c.RJ * c.VK;
-  return 3 * c.T * P * words + 95 + (words - 1) * 20 + ((c.prefetch2 || c.reverse == 2) ? P * words * c.pfd : 0);
+  return 3 * c.T * P * words + 20 + (33 * P) / 10 +
+         ((c.prefetch2 || c.reverse == 2) ? P * words * c.pfd : 0);
 }
 
 static int star_blocks_per_cu(const StarCfg& c, DT dt) {
@@ -420,8 +425,17 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
         star_chunk_planes(c, dt, range, &chunk_cost);
         const double jcost = c.noj ? 1.0 : (double)c.NJT * c.BY * c.RJ / (double)P.n[1];
         const double kcost = (double)c.NKT * c.BX * c.VK / (double)P.n[2];
+        // a block whose waves do not divide evenly over the 4 SIMDs of its unit
+        // leaves SIMDs idle (one block per unit); every thread pays two LDS edge
+        // rows per stage whatever its row count (profiles/r01_sweep_13_c5_tiles.log:
+        // 64x7 / 64x11 threads lose 10 % / 5 % to 64x8, 3 rows per thread 5-10 % to 4-5)
+        const int waves = (c.BX * c.BY + 63) / 64;
+        const double simd_balance =
+            (!c.noj && star_blocks_per_cu(c, dt) == 1) ? (double)((waves + 3) / 4 * 4) / (double)waves : 1.0;
+        const double edge_rows = c.noj ? 1.0 : 1.0 + 0.8 / (double)c.RJ;
         // ties go to the larger block (fewer barriers per point)
-        const double cost = jcost * kcost * chunk_cost * (1.0 + 1e-4 / (double)(c.BX * c.BY * c.RJ));
+        const double cost = jcost * kcost * chunk_cost * simd_balance * edge_rows *
+                            (1.0 + 1e-4 / (double)(c.BX * c.BY * c.RJ));
         ranked.push_back({cost, c});
       }
     }
@@ -433,6 +447,11 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
                    });
   std::vector<StarCfg> out;
   for (auto& rc : ranked) out.push_back(rc.second);
+  if (pl.opt.get("debug", 0) != 0)
+    for (size_t i = 0; i < std::min<size_t>(ranked.size(), 8); ++i)
+      std::fprintf(stderr, "[sf_hip] rank %zu cost %.4f: T=%d block %dx%d rows/thread %d tiles %dx%d\n", i + 1,
+                   ranked[i].first, T, ranked[i].second.BX, ranked[i].second.BY, ranked[i].second.RJ,
+                   ranked[i].second.NJT, ranked[i].second.NKT);
   return out;
 }
 
@@ -474,6 +493,10 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
     const int ck = intern_kernel(pl, prefix, g.source);
     const CompiledKernel& k = pl.kernels[ck];
     const int bad = std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs);
+    if (pl.opt.get("debug", 0) != 0)
+      std::fprintf(stderr, "[sf_hip] candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d\n",
+                   ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs,
+                   k.agprs, k.spills, k.scratch);
     if (bad == 0 || (pinned && pl.opt.get("allow_spills", 0) != 0)) {
       out.ok = true;
       out.cfg = ranked[ci];
