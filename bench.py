@@ -169,15 +169,31 @@ def main():
         chain = sf.KernelChainGraph(path)
         sfir = lower(chain)
 
+    transport = None
     if world > 1:
+        import datetime
         from stencilflow_amd.distributed import SlabRunner, TorchDistExchanger
         import torch.distributed as dist
-        if one_device:
-            dist.init_process_group("gloo")
-            exchanger = TorchDistExchanger(rank, world, staging="host")
+        # gloo is the control plane (barriers, the max over ranks) and the spare
+        # halo transport; the halos themselves travel over RCCL (backend "nccl")
+        # if a handshake with both neighbours succeeds on EVERY rank.
+        dist.init_process_group("gloo")
+        ok, why = 1, ""
+        try:
+            rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+            exchanger = TorchDistExchanger(rank, world, group=rccl, staging="device")
+            exchanger.handshake(torch.device("cuda", local_rank))
+        except Exception as exc:  # noqa: BLE001 -- any transport failure selects the spare
+            ok, why = 0, "{}: {}".format(type(exc).__name__, str(exc).splitlines()[0][:120] if str(exc) else "")
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            transport = "RCCL send/recv on device buffers"
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            exchanger = TorchDistExchanger(rank, world, staging="device")
+            exchanger = TorchDistExchanger(rank, world, staging="host")
+            exchanger.handshake()
+            transport = "gloo through pinned host buffers (RCCL handshake failed on some rank{})".format(
+                ": " + why if why else "")
         runner = SlabRunner(sfir, shape, rank, world, device=local_rank,
                             options=options, exchanger=exchanger)
         runner.upload([synthetic(runner.local_shape, rank)])
@@ -218,9 +234,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cpu" if one_device else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # control plane (gloo)
         elapsed = float(t.item())
 
     cells = float(np.prod(shape)) * args.stages * args.steps
@@ -241,8 +256,8 @@ def main():
         "data": "synthetic (uniform random [0,1), seed %d)" % SEED,
         "config": {
             "workload": label,
-            "decomposition": ("slab{} (halo {} planes, one exchange per {} launches)".format(
-                world, runner.halo, runner.halo // max(1, runner.steps[0][1]))
+            "decomposition": ("slab{} (halo {} planes, one exchange per {} launches, {})".format(
+                world, runner.halo, runner.halo // max(1, runner.steps[0][1]), transport)
                 if world > 1 else "single"),
         },
     }

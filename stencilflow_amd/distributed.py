@@ -83,6 +83,28 @@ class TorchDistExchanger:
         self._host = {}
         self.reserved_cus = self.RESERVED_CUS if staging == "device" else 0
 
+    def handshake(self, device=None):
+        """One small exchange with both neighbours: creates the transport's
+        connections outside any timed region and proves that it works (every
+        rank receives its neighbours' ranks).  Raises on failure."""
+        import torch
+        if self.world == 1:
+            return
+        dev = device if self.staging == "device" else "cpu"
+        bufs = {name: torch.full((256, ), 255, dtype=torch.uint8, device=dev)
+                for name in ("recv_down", "recv_up")}
+        bufs["send_down"] = torch.full((256, ), self.rank, dtype=torch.uint8, device=dev)
+        bufs["send_up"] = torch.full((256, ), self.rank, dtype=torch.uint8, device=dev)
+        works = self.dist.batch_isend_irecv(self._ops(None, None, lambda name: bufs[name]))
+        for w in works:
+            w.wait()
+        if self.staging == "device":
+            torch.cuda.synchronize()
+        if self.rank > 0 and int(bufs["recv_down"][0]) != self.rank - 1:
+            raise RuntimeError("halo transport handshake: wrong data from the lower neighbour")
+        if self.rank < self.world - 1 and int(bufs["recv_up"][255]) != self.rank + 1:
+            raise RuntimeError("halo transport handshake: wrong data from the upper neighbour")
+
     def _ops(self, buf, regions, as_tensor):
         dist = self.dist
         ops = []

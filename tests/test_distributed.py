@@ -161,3 +161,41 @@ def test_two_processes_one_gpu_host_staged(overlap, groups):
     """Two ranks (processes) drive their slabs on the same GPU; halos travel
     through gloo.  Everything but the RCCL transport itself is exercised."""
     _spawn(_gpu_worker, 2, (36, 20, 64), 9, overlap, groups)
+
+
+def _handshake_worker(rank, world, port):
+    dist = _init(rank, world, port)
+    from stencilflow_amd.distributed import TorchDistExchanger
+    TorchDistExchanger(rank, world, staging="host").handshake()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_transport_handshake_gloo(world):
+    """The exchanger's self-test (bench.py runs it before trusting a transport)."""
+    _spawn(_handshake_worker, world)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_falls_back_to_gloo():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one
+    rank per process), with both ranks pointed at this box's only GPU: the RCCL
+    handshake cannot succeed there (two ranks, one device), so the run must
+    select the spare transport on every rank and still print its JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, SF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--size", "64", "--stages", "24"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
+    assert rec["scaling"] == "weak" and "slab2" in rec["config"]["decomposition"]
+    assert "gloo" in rec["config"]["decomposition"]
+    assert "128x64x64" in rec["config"]["workload"]
