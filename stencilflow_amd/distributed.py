@@ -247,10 +247,13 @@ class SlabRunner:
                 opts["slab"] = "{}:{}:{}".format(self.lo, self.hi, h)
             return Plan(sfir_text, device=device, options=opts)
 
+        # decisions every rank must take alike use the thinnest slab
+        n_min = global_shape[0] // world
+
         def check(h, reach):
-            if world > 1 and (self.n_local < h or self.n_local < 2 * reach):
+            if world > 1 and (n_min < h or n_min < 2 * reach):
                 raise ValueError("slab of {} planes is too thin for a halo of {}".
-                                 format(self.n_local, h))
+                                 format(n_min, h))
 
         if halo is not None:
             self.halo = int(halo)
@@ -261,7 +264,7 @@ class SlabRunner:
             # fusion (4); the plan refuses a halo shallower than its reach, in
             # which case a halo-less plan is asked how far the launches reach
             guess = int(options.get("fuse", 4)) * max(1, groups_per_exchange)
-            guess = max(1, min(guess, self.n_local // 2))
+            guess = max(1, min(guess, n_min // 2))
             try:
                 plan = make_plan(guess)
                 reach = max([1] + [plan.step_halo(s)[1] for s in range(plan.num_steps)])
@@ -272,7 +275,7 @@ class SlabRunner:
                 reach = max([1] + [probe.step_halo(s)[1] for s in range(probe.num_steps)])
                 probe.close()
                 plan = None
-            want = max(reach, min(reach * max(1, groups_per_exchange), self.n_local // 2))
+            want = max(reach, min(reach * max(1, groups_per_exchange), n_min // 2))
             check(want, reach)
             if plan is None or want != guess:
                 if plan is not None:

@@ -551,3 +551,17 @@ def test_graph_replay_follows_scalar_changes(tmp_path, graph):
             got = np.zeros(shape)
             plan.run([x], [got], 2)  # two repetitions on the same buffers
             assert np.array_equal(got, want), (graph, scale)
+
+
+@pytest.mark.parametrize("seed", range(0, 16))
+def test_random_programs_under_slab_decomposition(tmp_path, seed):
+    """tools/slab_fuzz.py: a random star chain or DAG, 2-4 ranks with unequal
+    slabs, random halo depth and overlap switch, all ranks in this process."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "slab_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                  "tools", "slab_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    status, detail = mod.run_seed(seed, str(tmp_path))
+    assert status in ("ok", "skip"), detail
