@@ -88,6 +88,7 @@ struct Step {
   StarCfg cfg;
   int num_aux = 0;                    // centre-only auxiliary fields of a star step
   int generic_vk = 1;                 // points per thread of a generic step
+  int generic_ppt = 1;                // planes per thread of a generic step
   int halo_buf = -1, halo_depth = 0;  // what must be exchanged before the step
   std::string note;
 };
@@ -737,8 +738,9 @@ static void build_plan(sf_plan& pl) {
       // non-temporal output stores for fields beyond the Infinity Cache (see rank_star_cfgs)
       const double out_bytes = cells * (double)size_of(dt);
       const bool nts = pl.opt.get("generic.nt", out_bytes >= 256.0 * 1024 * 1024 ? 1 : 0) != 0;
+      const int ppt = (int)std::max<long long>(1, std::min<long long>(8, pl.opt.get("generic.ppt", 1)));
       GenericKernelSource g =
-          vec ? gen_generic_vec(P, st.kernels[0], xcd, nts) : gen_generic(P, st.kernels[0], xcd, nts);
+          vec ? gen_generic_vec(P, st.kernels[0], xcd, nts, ppt) : gen_generic(P, st.kernels[0], xcd, nts);
       st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
       if (vec) {
         const CompiledKernel& k = pl.kernels[st.ck];
@@ -748,6 +750,7 @@ static void build_plan(sf_plan& pl) {
         }
       }
       st.generic_vk = g.vk;
+      st.generic_ppt = g.planes_per_thread;
       st.scalars = g.scalars;
       int depth = 0, hb = -1;
       for (size_t ai = 0; ai < P.kernels[st.kernels[0]].acc.size(); ++ai) {
@@ -919,7 +922,8 @@ static void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, i
         int cb = done, ce = chunk_end;
         args[args.size() - 2] = &cb;
         args[args.size() - 1] = &ce;
-        SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, gx, (unsigned)(ce - cb), 1, 256, 1, 1, 0, stream,
+        const unsigned gy = (unsigned)((ce - cb + st.generic_ppt - 1) / st.generic_ppt);
+        SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, gx, gy, 1, 256, 1, 1, 0, stream,
                                            args.data(), nullptr));
         done = chunk_end;
       }
