@@ -740,7 +740,8 @@ static void build_plan(sf_plan& pl) {
       const bool nts = pl.opt.get("generic.nt", out_bytes >= 256.0 * 1024 * 1024 ? 1 : 0) != 0;
       const int ppt = (int)std::max<long long>(1, std::min<long long>(8, pl.opt.get("generic.ppt", 1)));
       GenericKernelSource g =
-          vec ? gen_generic_vec(P, st.kernels[0], xcd, nts, ppt) : gen_generic(P, st.kernels[0], xcd, nts);
+          vec ? gen_generic_vec(P, st.kernels[0], xcd, nts, ppt, pl.opt.get("generic.fast", 0) != 0)
+              : gen_generic(P, st.kernels[0], xcd, nts);
       st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
       if (vec) {
         const CompiledKernel& k = pl.kernels[st.ck];
