@@ -38,14 +38,13 @@ def parse_json(config_path):
     -> ``AttributeError`` (helper.py:59).  The directory of the file is stored
     under ``"path"`` (helper.py:80).
     """
-    if not os.path.isfile(config_path):
-        candidate = os.path.join(_PACKAGE_DIR, config_path)
-        if not os.path.isfile(candidate):
-            raise RuntimeError("file {} does not exists.".format(config_path))
-        config_path = candidate
-    with open(config_path, "r") as handle:
+    located = next((c for c in (config_path, os.path.join(_PACKAGE_DIR, config_path))
+                    if os.path.isfile(c)), None)
+    if located is None:
+        raise RuntimeError("file {} does not exists.".format(config_path))
+    with open(located, "r") as handle:
         config = json.load(handle)
-    config["path"] = os.path.dirname(os.path.abspath(config_path))
+    config["path"] = os.path.dirname(os.path.abspath(located))
     _convert_dtypes(config)
     return config
 
@@ -58,30 +57,34 @@ def _convert_dtypes(tree):
             tree[key] = str_to_dtype(val)
 
 
+def _require(value, kind, label):
+    if not isinstance(value, kind):
+        raise Exception("{} should be of type {}, but is of type {}".format(label, kind, type(value)))
+
+
 def max_dict_entry_key(dict1):
-    if not isinstance(dict1, dict):
-        raise Exception("dict1 should be of type {}, but is of type {}".format(
-            dict, type(dict1)))
-    return max(dict1, key=dict1.get)
+    """Key of the largest value."""
+    _require(dict1, dict, "dict1")
+    best = None
+    for key, value in dict1.items():
+        if best is None or value > dict1[best]:
+            best = key
+    if best is None:
+        raise ValueError("max() arg is an empty sequence")
+    return best
 
 
 def list_add_cwise(list1, list2):
-    for name, lst in (("list1", list1), ("list2", list2)):
-        if not isinstance(lst, list):
-            raise Exception("{} should be of type {}, but is of type {}".format(
-                name, list, type(lst)))
+    _require(list1, list, "list1")
+    _require(list2, list, "list2")
     return [x + y for x, y in zip(list1, list2)]
 
 
 def list_subtract_cwise(list1, list2):
-    for name, lst in (("list1", list1), ("list2", list2)):
-        if not isinstance(lst, list):
-            raise Exception("{} should be of type {}, but is of type {}".format(
-                name, list, type(lst)))
-    return [
-        x - y if x is not None and y is not None else None
-        for x, y in zip(list1, list2)
-    ]
+    """Element-wise difference; ``None`` wherever either side is ``None``."""
+    _require(list1, list, "list1")
+    _require(list2, list, "list2")
+    return [None if (x is None or y is None) else x - y for x, y in zip(list1, list2)]
 
 
 def dim_to_abs_val(input, dimensions):
@@ -118,6 +121,36 @@ def convert_3d_to_1d(dimensions, index):
 _GENERATED = re.compile(r"([^:]+):(.+)")
 
 
+def _is_scalar_input(input_config):
+    dims = input_config.get("input_dims")
+    return dims is not None and len(dims) == 0
+
+
+def _generate(kind, argument, dtype, shape, scalar):
+    if kind == "constant":
+        value = float(argument)
+        return value if scalar else np.full(shape, value, dtype=dtype)
+    if kind == "random":
+        fields = [t for t in re.split(r"[,\s]+|\.\.", argument) if t]
+        low, high = float(fields[0]), float(fields[1])
+        rng = np.random.default_rng(int(fields[2]) if len(fields) > 2 else 0)
+        return float(rng.uniform(low, high)) if scalar else rng.uniform(low, high, shape).astype(dtype)
+    raise ValueError("Unknown generation: " + kind)
+
+
+def _read_file(name, prefix, dtype):
+    candidates = [name] + ([os.path.join(prefix, name)] if prefix is not None else [])
+    path = next((c for c in candidates if os.path.isfile(c)), None)
+    if path is None:
+        raise FileNotFoundError("File {} does not exists.".format(name))
+    extension = os.path.splitext(path)[1]
+    if extension == ".csv":
+        return np.genfromtxt(path, dtype, delimiter=",")
+    if extension == ".dat":
+        return np.fromfile(path, dtype)
+    raise ValueError("Invalid file type: " + path)
+
+
 def load_array(input_config, prefix=None, shape=None):
     """Materialise one program input (reference helper.py:162-217).
 
@@ -128,63 +161,32 @@ def load_array(input_config, prefix=None, shape=None):
     """
     data = input_config["data"]
     dtype = input_config["data_type"].type
-    is_scalar = ("input_dims" in input_config
-                 and input_config["input_dims"] is not None
-                 and len(input_config["input_dims"]) <= 0)
+    scalar = _is_scalar_input(input_config)
     if isinstance(data, str):
-        m = _GENERATED.match(data)
-        if m and not os.path.isfile(data):
-            if shape is None and not is_scalar:
-                raise ValueError(
-                    "Must provide shape when using generated inputs")
-            kind, arg = m.group(1), m.group(2)
-            if kind == "constant":
-                val = float(arg)
-                if is_scalar:
-                    return val
-                arr = np.empty(shape, dtype=dtype)
-                arr[:] = val
-                return arr
-            if kind == "random":
-                parts = [p for p in re.split(r"[,\s]+|\.\.", arg) if p]
-                lo, hi = float(parts[0]), float(parts[1])
-                seed = int(parts[2]) if len(parts) > 2 else 0
-                rng = np.random.default_rng(seed)
-                if is_scalar:
-                    return float(rng.uniform(lo, hi))
-                return rng.uniform(lo, hi, shape).astype(dtype)
-            raise ValueError("Unknown generation: " + kind)
-        path = data
-        if not os.path.isfile(path):
-            if prefix is not None:
-                path = os.path.join(prefix, path)
-            if not os.path.isfile(path):
-                raise FileNotFoundError("File {} does not exists.".format(data))
-        if path.endswith(".csv"):
-            return np.genfromtxt(path, dtype, delimiter=",")
-        if path.endswith(".dat"):
-            return np.fromfile(path, dtype)
-        raise ValueError("Invalid file type: " + path)
-    if is_scalar or (shape is not None and len(shape) == 0):
+        generated = None if os.path.isfile(data) else _GENERATED.match(data)
+        if generated is None:
+            return _read_file(data, prefix, dtype)
+        if shape is None and not scalar:
+            raise ValueError("Must provide shape when using generated inputs")
+        return _generate(generated.group(1), generated.group(2), dtype, shape, scalar)
+    if scalar or (shape is not None and len(shape) == 0):
         return dtype(data)
-    if isinstance(data, np.ndarray):
-        return data
-    return np.array(data, dtype=dtype)
+    return data if isinstance(data, np.ndarray) else np.array(data, dtype=dtype)
 
 
 def load_input_arrays(input_configs, prefix=None, shape=None):
     """All program inputs, arrays 64-byte aligned (helper.py:220-237)."""
-    arrays = dict()
+    loaded = {}
     for name, source in input_configs.items():
-        arr = load_array(source, prefix, shape)
-        if isinstance(arr, np.ndarray) and arr.ndim > 0:
-            arr = aligned(arr, 64)
-        arrays[name] = arr
-    return arrays
+        value = load_array(source, prefix, shape)
+        is_array = isinstance(value, np.ndarray) and value.ndim > 0
+        loaded[name] = aligned(value, 64) if is_array else value
+    return loaded
 
 
 def save_array(array, path):
-    array.tofile(path)
+    """Raw C-order dump."""
+    np.ascontiguousarray(array).tofile(path)
 
 
 def save_output_arrays(outputs, output_dir=str()):
@@ -200,14 +202,9 @@ def arrays_are_equal(reference, result, tolerance=1e-5):
     so negative data passes trivially.  ``arrays_match`` below is the strict
     rule this backend's own parity tests use.
     """
-    if not isinstance(reference, np.ndarray):
-        reference = load_array(reference)
-    if not isinstance(result, np.ndarray):
-        result = load_array(result)
-    relative_diff = (np.abs(reference - result) /
-                     (np.maximum.reduce([reference, result]) +
-                      np.finfo(reference.dtype).eps))
-    return np.all(relative_diff <= tolerance)
+    ref, res = (a if isinstance(a, np.ndarray) else load_array(a) for a in (reference, result))
+    denominator = np.maximum(ref, res) + np.finfo(ref.dtype).eps  # signed, as in the reference
+    return np.all(np.abs(ref - res) / denominator <= tolerance)
 
 
 def arrays_match(reference, result, tolerance=1e-6):
@@ -224,25 +221,33 @@ def arrays_match(reference, result, tolerance=1e-6):
 
 
 def unique(iterable):
-    try:
-        return type(iterable)(
-            [i for i in sorted(set(iterable), key=lambda x: iterable.index(x))])
-    except TypeError:
-        return type(iterable)(collections.OrderedDict(
-            zip(map(str, iterable), iterable)).values())
+    """Distinct elements in first-occurrence order, in a container of the same
+    type; unhashable elements are told apart by their ``str``."""
+    seen, kept = set(), []
+    for item in iterable:
+        try:
+            key = item
+            hash(key)
+        except TypeError:
+            key = str(item)
+        if key not in seen:
+            seen.add(key)
+            kept.append(item)
+    return type(iterable)(kept)
 
 
 def aligned(a, alignment=16):
     """Return ``a`` or a copy whose base address is ``alignment``-aligned."""
-    if (a.ctypes.data % alignment) == 0:
-        return a
-    extra = alignment // a.itemsize + 1
-    buf = np.empty(a.size + extra, dtype=a.dtype)
-    ofs = (-buf.ctypes.data % alignment) // a.itemsize
-    view = buf[ofs:ofs + a.size].reshape(a.shape)
-    np.copyto(view, a)
-    assert view.ctypes.data % alignment == 0
-    return view
+    if a.ctypes.data % alignment:
+        spare = alignment // a.itemsize + 1
+        pool = np.empty(a.size + spare, dtype=a.dtype)
+        first = (-pool.ctypes.data % alignment) // a.itemsize
+        copy = pool[first:first + a.size].reshape(a.shape)
+        copy[...] = a
+        if copy.ctypes.data % alignment:
+            raise MemoryError("could not align a {}-byte element array to {}".format(a.itemsize, alignment))
+        return copy
+    return a
 
 
 class OpCounter(ast.NodeVisitor):
@@ -251,22 +256,20 @@ class OpCounter(ast.NodeVisitor):
     another ``BinOp``; every ``Call`` counts under its function name."""
 
     def __init__(self):
-        self._operation_count = {}
+        self._counts = collections.Counter()
 
     @property
     def operation_count(self):
-        return self._operation_count
-
-    def _bump(self, name):
-        self._operation_count[name] = self._operation_count.get(name, 0) + 1
+        return dict(self._counts)
 
     def visit_BinOp(self, node):
-        if any(
-                isinstance(side, (ast.Subscript, ast.BinOp))
-                for side in (node.left, node.right)):
-            self._bump(type(node.op).__name__)
-        self.generic_visit(node)
+        operands = (node.left, node.right)
+        if any(isinstance(x, (ast.Subscript, ast.BinOp)) for x in operands):
+            self._counts[type(node.op).__name__] += 1
+        for x in operands:
+            self.visit(x)
 
     def visit_Call(self, node):
-        self._bump(node.func.id)
-        self.generic_visit(node)
+        self._counts[node.func.id] += 1
+        for argument in node.args:
+            self.visit(argument)

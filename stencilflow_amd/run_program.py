@@ -17,10 +17,7 @@ test-suite registers the oracle under ``oracle/``).  Without one the flag
 raises ``RuntimeError`` — the product path never computes on the CPU.
 """
 
-import copy
-import itertools
 import os
-import re
 
 import numpy as np
 
@@ -30,6 +27,7 @@ from .kernel_chain_graph import KernelChainGraph
 from .log_level import LogLevel
 
 _REFERENCE_BACKEND = None
+_MODES = ("emulation", "hardware", "hip")
 
 
 def set_reference_backend(fn):
@@ -39,6 +37,74 @@ def set_reference_backend(fn):
     prev = _REFERENCE_BACKEND
     _REFERENCE_BACKEND = fn
     return prev
+
+
+class _Log:
+    def __init__(self, level):
+        self.level = level
+
+    def __call__(self, text, level=LogLevel.BASIC):
+        if self.level >= level:
+            print(text)
+
+
+def _program_name(stencil_file):
+    """`results/` sub-directory of a program: the file name without its last
+    extension, remaining dots replaced (reference run_program.py:66-67)."""
+    stem = os.path.basename(stencil_file)
+    if "." in stem:
+        stem = stem[:stem.rindex(".")]
+    return stem.replace(".", "_")
+
+
+def _materialise_inputs(chain, description, directory, generate_input):
+    """Host arrays (64-byte aligned, C order) for array inputs, Python scalars
+    for 0-D inputs.  `generate_input` replaces every source by `constant:0.5`
+    (reference run_program.py:141-144)."""
+    own_iterators = helper.ITERATORS[3 - chain.kernel_dimensions:]
+    extents = dict(zip(own_iterators, description["dimensions"]))
+    arrays = {}
+    for name, declared in description["inputs"].items():
+        source = dict(declared)
+        if generate_input:
+            source["data"] = "constant:0.5"
+        source["input_dims"] = chain.inputs[name]["input_dims"]
+        shape = [extents[d] for d in source["input_dims"]]
+        value = helper.load_array(source, prefix=directory, shape=shape)
+        if isinstance(value, np.ndarray) and value.ndim > 0:
+            value = helper.aligned(np.ascontiguousarray(value.reshape(shape)), 64)
+        arrays[name] = value
+    return arrays
+
+
+def _zeroed_outputs(description):
+    outputs = {}
+    for name in description["outputs"]:
+        dtype = description["program"][name]["data_type"].type
+        outputs[name] = helper.aligned(np.zeros(description["dimensions"], dtype=dtype), 64)
+    return outputs
+
+
+def _call_arguments(inputs, outputs):
+    """Keyword arguments of the compiled program: arrays under `<name>_host`,
+    0-D inputs under their bare name (reference run_program.py:164-169)."""
+    kwargs = {}
+    for group in (inputs, outputs):
+        for name, value in group.items():
+            is_array = getattr(value, "ndim", 0) > 0
+            kwargs[name + "_host" if is_array else name] = value
+    return kwargs
+
+
+def _without_halo(arrays, halo):
+    inner = slice(halo, -halo)
+    return {name: a[(inner, ) * a.ndim] for name, a in arrays.items()}
+
+
+def _dump(arrays, title, enabled):
+    if enabled:
+        for name, a in arrays.items():
+            print(name + ":", a)
 
 
 def run_program(stencil_file,
@@ -60,23 +126,17 @@ def run_program(stencil_file,
                 device=0,
                 options=None,
                 tolerance=1e-6):
-    def log(msg, level=LogLevel.BASIC):
-        if log_level >= level:
-            print(msg)
-
-    program_description = helper.parse_json(stencil_file)
-    name = os.path.basename(stencil_file)
-    name = re.match(r"(.+)\.[^\.]+", name).group(1).replace(".", "_")
+    log = _Log(log_level)
+    description = helper.parse_json(stencil_file)
+    name = _program_name(stencil_file)
 
     log("Creating kernel graph...")
-    chain = KernelChainGraph(path=stencil_file,
-                             plot_graph=plot,
-                             log_level=log_level)
+    chain = KernelChainGraph(path=stencil_file, plot_graph=plot, log_level=log_level)
 
     if run_simulation:
         raise NotImplementedError(
             "The cycle-level FPGA simulator is not part of the HIP backend")
-    if mode not in ("emulation", "hardware", "hip"):
+    if mode not in _MODES:
         raise ValueError("Unrecognized execution mode: {}".format(mode))
     if compare_to_reference and _REFERENCE_BACKEND is None:
         raise RuntimeError(
@@ -85,102 +145,58 @@ def run_program(stencil_file,
 
     log("Generating and compiling HIP kernels...")
     program = compile_program(chain, device=device, options=options)
-    log(program.plan.describe(), LogLevel.MODERATE)
+    try:
+        log(program.plan.describe(), LogLevel.MODERATE)
+        if skip_execution or repetitions == 0:
+            log("Skipping execution and exiting.")
+            return None
 
-    if skip_execution or repetitions == 0:
-        log("Skipping execution and exiting.")
-        program.close()
-        return
+        log("Loading input arrays...")
+        directory = input_directory if input_directory is not None else os.path.dirname(stencil_file)
+        inputs = _materialise_inputs(chain, description, directory, generate_input)
+        log("Initializing output arrays...")
+        outputs = _zeroed_outputs(description)
 
-    log("Loading input arrays...")
-    if input_directory is None:
-        input_directory = os.path.dirname(stencil_file)
-    input_description = copy.copy(program_description["inputs"])
-    if generate_input:
-        # reference run_program.py:141-144
-        for k in input_description:
-            input_description[k] = dict(input_description[k])
-            input_description[k]["data"] = "constant:0.5"
-    input_arrays = {}
-    for arr_name, source in input_description.items():
-        source = dict(source)
-        source["input_dims"] = chain.inputs[arr_name]["input_dims"]
-        dims = source["input_dims"]
-        own = helper.ITERATORS[3 - chain.kernel_dimensions:]
-        shape = [program_description["dimensions"][own.index(d)] for d in dims]
-        arr = helper.load_array(source, prefix=input_directory, shape=shape)
-        if isinstance(arr, np.ndarray) and arr.ndim > 0:
-            arr = helper.aligned(
-                np.ascontiguousarray(arr.reshape(shape)), 64)
-        input_arrays[arr_name] = arr
-
-    log("Initializing output arrays...")
-    output_arrays = {
-        arr_name: helper.aligned(
-            np.zeros(program_description["dimensions"],
-                     dtype=program_description["program"][arr_name]
-                     ["data_type"].type), 64)
-        for arr_name in program_description["outputs"]
-    }
-
-    # arrays are keyed "<name>_host", 0-D inputs by bare name (reference :164-169)
-    args = {(key + "_host" if hasattr(val, "shape") and len(val.shape) > 0
-             else key): val
-            for key, val in itertools.chain(input_arrays.items(),
-                                            output_arrays.items())}
-    if repetitions == 1:
-        log("Executing program on the GPU...")
-        program(**args)
-        log("Finished running program.")
-    else:
-        for i in range(repetitions):
-            log("Executing repetition {}/{}...".format(i + 1, repetitions))
-            program(**args)
+        kwargs = _call_arguments(inputs, outputs)
+        for rep in range(repetitions):
+            log("Executing program on the GPU..." if repetitions == 1 else
+                "Executing repetition {}/{}...".format(rep + 1, repetitions))
+            program(**kwargs)
             log("Finished running program.")
-    program.close()
+    finally:
+        program.close()
+    _dump(outputs, "result", print_result)
 
-    if print_result:
-        for key, val in output_arrays.items():
-            print(key + ":", val)
-
-    reference_output_arrays = None
+    expected = None
     if compare_to_reference:
         log("Executing reference program...")
-        reference_output_arrays = _REFERENCE_BACKEND(stencil_file,
-                                                     input_arrays)
+        expected = _REFERENCE_BACKEND(stencil_file, inputs)
         log("Finished running program.")
-        if print_result:
-            for key, val in reference_output_arrays.items():
-                print(key + ":", val)
+        _dump(expected, "reference", print_result)
 
-    output_folder = os.path.join("results", name)
-    os.makedirs(output_folder, exist_ok=True)
-    if halo > 0:
-        # prune halos (reference :202-209)
-        for k, v in output_arrays.items():
-            output_arrays[k] = v[tuple(slice(halo, -halo) for _ in v.shape)]
-        if compare_to_reference:
-            for k, v in reference_output_arrays.items():
-                reference_output_arrays[k] = v[tuple(
-                    slice(halo, -halo) for _ in v.shape)]
-    helper.save_output_arrays(output_arrays, output_folder)
-    log("Results saved to " + output_folder)
-    if compare_to_reference:
-        reference_folder = os.path.join(output_folder, "reference")
-        os.makedirs(reference_folder, exist_ok=True)
-        helper.save_output_arrays(reference_output_arrays, reference_folder)
-        log("Reference results saved to " + reference_folder)
+    if halo > 0:  # prune the shrink halo before saving / comparing (reference :202-209)
+        outputs = _without_halo(outputs, halo)
+        if expected is not None:
+            expected = _without_halo(expected, halo)
 
-    if compare_to_reference:
-        log("Comparing to reference...")
-        for outp in output_arrays:
-            got = output_arrays[outp]
-            expected = reference_output_arrays[outp]
-            if not helper.arrays_match(np.ravel(expected), np.ravel(got),
-                                       tolerance):
-                print("Expected: {}".format(expected))
-                print("Got:      {}".format(got))
-                raise ValueError("Result mismatch.")
-        log("Results verified.")
-        return 0
-    return None
+    folder = os.path.join("results", name)
+    os.makedirs(folder, exist_ok=True)
+    helper.save_output_arrays(outputs, folder)
+    log("Results saved to " + folder)
+    if expected is None:
+        return None
+
+    reference_folder = os.path.join(folder, "reference")
+    os.makedirs(reference_folder, exist_ok=True)
+    helper.save_output_arrays(expected, reference_folder)
+    log("Reference results saved to " + reference_folder)
+
+    log("Comparing to reference...")
+    for out_name, got in outputs.items():
+        want = expected[out_name]
+        if not helper.arrays_match(np.ravel(want), np.ravel(got), tolerance):
+            print("Expected: {}".format(want))
+            print("Got:      {}".format(got))
+            raise ValueError("Result mismatch.")
+    log("Results verified.")
+    return 0
