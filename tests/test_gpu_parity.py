@@ -565,3 +565,132 @@ def test_random_programs_under_slab_decomposition(tmp_path, seed):
     spec.loader.exec_module(mod)
     status, detail = mod.run_seed(seed, str(tmp_path))
     assert status in ("ok", "skip"), detail
+
+
+def test_full_benchmark_configuration_bit_exact():
+    """C3 itself -- jacobi3d 512^3 float32, the 1000-operator chain on random
+    data -- against the C oracle, every one of the 134 million results compared
+    bit for bit.  The oracle applies an 8-operator program 125 times, feeding
+    each result back (all operators of the chain are the same operator), which
+    is the same arithmetic as the 1000-operator program."""
+    import tempfile
+    from oracle import c_oracle
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    n, stages, block = 512, 1000, 8
+    rng = np.random.default_rng(SEED + 31)
+    x = rng.uniform(0, 1, (n, n, n)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = programs.write_program(programs.jacobi3d((n, n, n), stages), os.path.join(tmp, "c3.json"))
+        chain = sf.KernelChainGraph(path)
+    got = np.zeros((n, n, n), np.float32)
+    with Plan(lower(chain)) as plan:
+        assert "star T=2" in plan.describe() and plan.num_launches == stages // 2
+        plan.run([x], [got], 1)
+    ref = c_oracle.CompiledReference(programs.jacobi3d((n, n, n), block))
+    ref.threads = _oracle_threads()
+    want = x
+    for _ in range(stages // block):
+        want = ref.run({"a": want})["b%d" % (block - 1)]
+    assert want.dtype == got.dtype
+    assert np.array_equal(got, want), "max |diff| = %g" % float(np.max(np.abs(got - want)))
+    assert float(got.max()) > 0.0  # not a field of zeros
+
+
+def _oracle_threads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, 2 * (-(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def test_full_c2_configuration_bit_exact():
+    """C2 itself: jacobi2d 4096^2 float32, 1000 operators, random data, all
+    16.8 million results against the C oracle (8 operators x 125, fed back)."""
+    import tempfile
+    from oracle import c_oracle
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    n, stages, block = 4096, 1000, 8
+    x = np.random.default_rng(SEED + 32).uniform(0, 1, (n, n)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = programs.write_program(programs.jacobi2d((n, n), stages), os.path.join(tmp, "c2.json"))
+        chain = sf.KernelChainGraph(path)
+    got = np.zeros((n, n), np.float32)
+    with Plan(lower(chain)) as plan:
+        assert "star T=4" in plan.describe()
+        plan.run([x], [got], 1)
+    ref = c_oracle.CompiledReference(programs.jacobi2d((n, n), block))
+    ref.threads = _oracle_threads()
+    want = x
+    for _ in range(stages // block):
+        want = ref.run({"a": want})["b%d" % (block - 1)]
+    assert np.array_equal(got, want)
+
+
+def test_full_c5_configuration_bit_exact():
+    """C5 itself: diffusion -> advection -> laplacian on 512^3 float64 random
+    data, fused into one launch, all 134 million results against the C oracle."""
+    import tempfile
+    from oracle import c_oracle
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    n = 512
+    prog = programs.diffusion_advection_laplacian((n, n, n))
+    x = np.random.default_rng(SEED + 33).uniform(-1, 1, (n, n, n))
+    ins = _inputs_of(prog)
+    ins["a"] = x
+    with tempfile.TemporaryDirectory() as tmp:
+        path = programs.write_program(prog, os.path.join(tmp, "c5.json"))
+        chain = sf.KernelChainGraph(path)
+    got = np.zeros((n, n, n), np.float64)
+    with Plan(lower(chain)) as plan:
+        assert "1 launches" in plan.describe() and "star T=3" in plan.describe()
+        plan.set_scalars([ins[k] for k in plan.scalar_names])
+        plan.run([x], [got], 1)
+    ref = c_oracle.CompiledReference(prog)
+    ref.threads = _oracle_threads()
+    want = ref.run(ins)["lap"]
+    assert np.array_equal(got, want)
+
+
+def test_full_c4_grid_eight_slabs_bit_exact():
+    """C4's grid -- 4096 x 512 x 512 float32 split into eight 512-plane slabs,
+    deep halos, overlapped exchange with reserved compute units -- for the
+    first 40 operators of the chain, all 1.07 billion results against the C
+    oracle.  The eight ranks share this GPU; halos are copied by the in-process
+    exchanger (the RCCL transport is the only part not exercised)."""
+    import tempfile
+    from oracle import c_oracle
+    from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
+    from stencilflow_amd.lowering import lower
+    shape, stages, block, world = (4096, 512, 512), 40, 8, 8
+    x = np.random.default_rng(SEED + 34).random(shape, dtype=np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = programs.write_program(programs.jacobi3d(shape, stages), os.path.join(tmp, "c4.json"))
+        sfir = lower(sf.KernelChainGraph(path))
+    exch = LocalExchanger(world)
+    views = [exch.for_rank(r) for r in range(world)]
+    for v in views:
+        v.reserved_cus = 32
+    runners = [SlabRunner(sfir, shape, r, world, exchanger=views[r]) for r in range(world)]
+    assert runners[0].is_chain and runners[0].halo == 8 and runners[3].n_local == 512
+    for r in runners:
+        r.upload([x[r.lo:r.hi]])
+    run_lockstep(runners)
+    got = np.empty(shape, np.float32)
+    for r in runners:
+        part = np.empty(r.local_shape, np.float32)
+        r.download([part])
+        got[r.lo:r.hi] = part
+        r.close()
+    ref = c_oracle.CompiledReference(programs.jacobi3d(shape, block))
+    ref.threads = _oracle_threads()
+    want = x
+    for _ in range(stages // block):
+        want = ref.run({"a": want})["b%d" % (block - 1)]
+    assert np.array_equal(got, want)
