@@ -178,24 +178,25 @@ def test_transport_handshake_gloo(world):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_on_one_gpu_falls_back_to_gloo():
+def test_bench_three_ranks_on_one_gpu_falls_back_to_gloo():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one
-    rank per process), with both ranks pointed at this box's only GPU: the RCCL
-    handshake cannot succeed there (two ranks, one device), so the run must
+    rank per process), with all ranks (one of them with two neighbours) pointed
+    at this box's only GPU: the RCCL handshake cannot succeed there (several
+    ranks, one device), so the run must
     select the spare transport on every rank and still print its JSON line."""
     import json
     import subprocess
     env = dict(os.environ, SF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
            "--size", "64", "--stages", "24"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
-    assert rec["scaling"] == "weak" and "slab2" in rec["config"]["decomposition"]
+    assert rec["n_gpus"] == 3 and rec["steps"] == 2 and rec["value"] > 0
+    assert rec["scaling"] == "weak" and "slab3" in rec["config"]["decomposition"]
     assert "gloo" in rec["config"]["decomposition"]
-    assert "128x64x64" in rec["config"]["workload"]
+    assert "192x64x64" in rec["config"]["workload"]
