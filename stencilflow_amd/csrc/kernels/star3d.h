@@ -119,12 +119,28 @@ __device__ __forceinline__ T sf_neighbour_lane(T x) {
   constexpr int ctrl = FROM_LOWER ? 0x138 /* wave_shr:1 */ : 0x130 /* wave_shl:1 */;
   if constexpr (sizeof(T) == 4) {
     const int v = __builtin_bit_cast(int, x);
+#if SF_DPP == 2
+    // bound_ctrl: lanes without a source read 0 and nothing of the old value is
+    // kept, so no copy precedes the DPP move (the caller replaces lane 0 / 63)
+    // (the result is made opaque: LLVM's DPP combiner otherwise folds the move into
+    // a consuming f64 conversion, which gfx950 cannot encode with wave_shr/wave_shl)
+    int moved = __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
+    asm volatile("" : "+v"(moved));
+    return __builtin_bit_cast(T, moved);
+#else
     return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false));
+#endif
   } else {
     const long long v = __builtin_bit_cast(long long, x);
     const int lo = (int)(v & 0xffffffffll), hi = (int)(v >> 32);
+#if SF_DPP == 2
+    int rlo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, true);
+    int rhi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, true);
+    asm volatile("" : "+v"(rlo), "+v"(rhi));
+#else
     const int rlo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false);
     const int rhi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);
+#endif
     return __builtin_bit_cast(T, ((long long)rhi << 32) | (unsigned int)rlo);
   }
 #else

@@ -397,7 +397,7 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   if (base.pfd != 1 && base.pfd != 3) throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
   if (!base.prefetch2 && base.reverse != 2) base.pfd = 1;
   base.experiment = (int)pl.opt.get("experiment", 0);
-  base.dpp = (int)pl.opt.get("k1.dpp", 1);
+  base.dpp = (int)pl.opt.get("k1.dpp", 2);  // 2 = DPP with bound_ctrl (no copy before the move), 1 = plain DPP, 0 = __shfl
   // Non-temporal output stores when a field is larger than the 256 MiB Infinity
   // Cache: nothing of it would survive until the next launch reads it, and not
   // allocating the written lines leaves the cache to the input stream (C3 +3 %,
