@@ -53,6 +53,9 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #ifndef SF_PFD
 #define SF_PFD 1
 #endif
+#ifndef SF_UNIFORM
+#define SF_UNIFORM 0
+#endif
 
 #if SF_REVERSE  // loads are issued at the end of the step: no staging registers
 #undef SF_PREFETCH2
@@ -119,7 +122,7 @@ __device__ __forceinline__ T sf_neighbour_lane(T x) {
   constexpr int ctrl = FROM_LOWER ? 0x138 /* wave_shr:1 */ : 0x130 /* wave_shl:1 */;
   if constexpr (sizeof(T) == 4) {
     const int v = __builtin_bit_cast(int, x);
-#if SF_DPP == 2
+#if SF_DPP >= 2
     // bound_ctrl: lanes without a source read 0 and nothing of the old value is
     // kept, so no copy precedes the DPP move (the caller replaces lane 0 / 63)
     // (the result is made opaque: LLVM's DPP combiner otherwise folds the move into
@@ -133,7 +136,7 @@ __device__ __forceinline__ T sf_neighbour_lane(T x) {
   } else {
     const long long v = __builtin_bit_cast(long long, x);
     const int lo = (int)(v & 0xffffffffll), hi = (int)(v >> 32);
-#if SF_DPP == 2
+#if SF_DPP >= 2
     int rlo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, true);
     int rhi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, true);
     asm volatile("" : "+v"(rlo), "+v"(rhi));
@@ -146,6 +149,26 @@ __device__ __forceinline__ T sf_neighbour_lane(T x) {
 #else
   return FROM_LOWER ? __shfl_up(x, 1) : __shfl_down(x, 1);
 #endif
+}
+
+// As above, but lanes without a source (lane 0 when taking from the lower lane,
+// lane 63 from the upper) keep `edge`: one DPP move whose destination register
+// starts out as the value for the wave's edge lane -- no select afterwards.
+template <bool FROM_LOWER, typename T>
+__device__ __forceinline__ T sf_neighbour_lane_or(T x, T edge) {
+  constexpr int ctrl = FROM_LOWER ? 0x138 /* wave_shr:1 */ : 0x130 /* wave_shl:1 */;
+  if constexpr (sizeof(T) == 4) {
+    int moved = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x), ctrl,
+                                            0xf, 0xf, false);
+    asm volatile("" : "+v"(moved));  // keep LLVM's DPP combiner off it (see above)
+    return __builtin_bit_cast(T, moved);
+  } else {
+    const long long v = __builtin_bit_cast(long long, x), e = __builtin_bit_cast(long long, edge);
+    int rlo = __builtin_amdgcn_update_dpp((int)(e & 0xffffffffll), (int)(v & 0xffffffffll), ctrl, 0xf, 0xf, false);
+    int rhi = __builtin_amdgcn_update_dpp((int)(e >> 32), (int)(v >> 32), ctrl, 0xf, 0xf, false);
+    asm volatile("" : "+v"(rlo), "+v"(rhi));
+    return __builtin_bit_cast(T, ((long long)rhi << 32) | (unsigned int)rlo);
+  }
 }
 
 // Is row r of input plane p inside the global domain (and inside what this chunk reads)?
@@ -204,6 +227,25 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
     const sf_vec jp = (r < SF_RJ - 1) ? st.w[src][icur][r < SF_RJ - 1 ? r + 1 : r] : jpl;
     // innermost-dimension halo: adjacent lanes hold the adjacent vectors
     // SF_EXPERIMENT 3: timing-only build without the lane exchange (invalid results)
+#if SF_DPP == 3
+    // Lanes 0 / 63 have no source lane.  Their value is the neighbouring wave's
+    // edge column (LDS, every lane reads the same word) or this stage's boundary
+    // constant; it is handed to the DPP move as the starting destination, so no
+    // select follows -- and a boundary constant of +0 is what bound_ctrl writes.
+    sf_t km_e, kp_e;
+    if (SF_WPR > 1 && cx.wave > 0)
+      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], lds[sf_edge_at(src, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]);
+    else if (sf_stage<S>::bc_zero)
+      km_e = sf_neighbour_lane<true>(c[SF_VK - 1]);
+    else
+      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], sf_stage<S>::bc());
+    if (SF_WPR > 1 && cx.wave < SF_WPR - 1)
+      kp_e = sf_neighbour_lane_or<false>(c[0], lds[sf_edge_at(src, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]);
+    else if (sf_stage<S>::bc_zero)
+      kp_e = sf_neighbour_lane<false>(c[0]);
+    else
+      kp_e = sf_neighbour_lane_or<false>(c[0], sf_stage<S>::bc());
+#else
     sf_t km_e = (SF_EXPERIMENT == 3) ? c[SF_VK - 1] : sf_neighbour_lane<true>(c[SF_VK - 1]);
     sf_t kp_e = (SF_EXPERIMENT == 3) ? c[0] : sf_neighbour_lane<false>(c[0]);
     if (SF_EXPERIMENT != 3 && cx.lane == 0)
@@ -214,6 +256,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       kp_e = (SF_WPR > 1 && cx.wave < SF_WPR - 1)
                  ? lds[sf_edge_at(src, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]
                  : sf_stage<S>::bc();
+#endif
     // centre-only auxiliary fields of this stage, row r of plane q
     const auto ax = sf_stage<S>::load_aux(
         cx.aux,
@@ -431,9 +474,16 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   cx.in = in;
   cx.aux = aux;
   cx.tx = threadIdx.x;
+  // thread row and wave-within-row are the same for all lanes of a wave (SF_BX is
+  // a multiple of 64): telling the compiler so makes every test on them a scalar branch
+#if SF_UNIFORM
+  cx.ty = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  cx.wave = __builtin_amdgcn_readfirstlane(cx.tx >> 6);
+#else
   cx.ty = threadIdx.y;
-  cx.lane = cx.tx & 63;
   cx.wave = cx.tx >> 6;
+#endif
+  cx.lane = cx.tx & 63;
   cx.goff = goff;
   cx.halo = halo;
 

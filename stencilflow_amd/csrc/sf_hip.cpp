@@ -397,12 +397,17 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   if (base.pfd != 1 && base.pfd != 3) throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
   if (!base.prefetch2 && base.reverse != 2) base.pfd = 1;
   base.experiment = (int)pl.opt.get("experiment", 0);
-  base.dpp = (int)pl.opt.get("k1.dpp", 2);  // 2 = DPP with bound_ctrl (no copy before the move), 1 = plain DPP, 0 = __shfl
+  // lane exchange: 0 = __shfl, 1 = DPP, 2 = DPP with bound_ctrl (no copy before the
+  // move), 3 = as 2 and the wave's edge lane gets its value from the move's
+  // starting destination instead of a select.  f32: 2 (3 costs 7 % in scalar
+  // branches); f64, where every value is two moves and two selects: 3 (+4.7 % on C5).
+  base.dpp = (int)pl.opt.get("k1.dpp", dt == DT::F64 ? 3 : 2);
   // Non-temporal output stores when a field is larger than the 256 MiB Infinity
   // Cache: nothing of it would survive until the next launch reads it, and not
   // allocating the written lines leaves the cache to the input stream (C3 +3 %,
   // C5 +1.4 %; the cache-resident 64 MiB field of C2 loses 13 % with them).
   const double field_bytes = (double)pl.n_local * (double)P.n[1] * (double)P.n[2] * (double)size_of(dt);
+  base.uniform = (int)pl.opt.get("k1.uni", base.dpp == 3 ? 1 : 0);
   base.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
   const std::string pfx = base.noj ? "k2." : "k1.";
   const long long pin_bx = pl.opt.get(pfx + "bx", 0);
