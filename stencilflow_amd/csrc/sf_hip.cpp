@@ -401,7 +401,10 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   // move), 3 = as 2 and the wave's edge lane gets its value from the move's
   // starting destination instead of a select.  f32: 2 (3 costs 7 % in scalar
   // branches); f64, where every value is two moves and two selects: 3 (+4.7 % on C5).
-  base.dpp = (int)pl.opt.get("k1.dpp", dt == DT::F64 ? 3 : 2);
+  // One-wave-wide blocks (no neighbouring wave, hence no LDS side) also take 3:
+  // C2 +8 %.
+  const long long dpp_opt = pl.opt.get("k1.dpp", -1);
+  base.dpp = dpp_opt >= 0 ? (int)dpp_opt : (dt == DT::F64 ? 3 : 2);
   // Non-temporal output stores when a field is larger than the 256 MiB Infinity
   // Cache: nothing of it would survive until the next launch reads it, and not
   // allocating the written lines leaves the cache to the input stream (C3 +3 %,
@@ -427,6 +430,8 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
         c.BX = bx;
         c.RJ = rj;
         c.BY = by;
+        if (dpp_opt < 0 && bx == 64) c.dpp = 3;
+        if (pl.opt.get("k1.uni", -1) < 0) c.uniform = (c.dpp == 3) ? 1 : 0;
         if (!c.noj && by * rj - 2 * T < 1) continue;
         star_finish_cfg(c, P, T);
         if (star_lds_bytes(c, dt) > 160 * 1024) continue;
