@@ -56,6 +56,9 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #ifndef SF_UNIFORM
 #define SF_UNIFORM 0
 #endif
+#ifndef SF_AUX_AHEAD
+#define SF_AUX_AHEAD 0
+#endif
 
 #if SF_REVERSE  // loads are issued at the end of the step: no staging registers
 #undef SF_PREFETCH2
@@ -87,7 +90,19 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 
 // w[s][slot][row]: planes of stage-s data (s = 0 is the input field).  At
 // phase PH the slots hold  prev = PH % 3,  cur = (PH + 1) % 3,  next = (PH + 2) % 3.
-struct sf_state {
+// (SF_AUX_AHEAD 2) one row set of auxiliary values per stage, requested a step ahead
+template <int N>
+struct sf_auxslots : sf_auxslots<N - 1> {
+  typename sf_stage<N>::aux_row a[SF_RJ];
+};
+template <>
+struct sf_auxslots<0> {};
+
+struct sf_state
+#if SF_AUX_AHEAD == 2
+    : sf_auxslots<SF_T>
+#endif
+{
   sf_vec w[SF_T][3][SF_RJ];
 #if SF_REVERSE == 2 || SF_PREFETCH2
   // input planes in flight: a ring of SF_PFD (1 or 3) planes, so a load has
@@ -193,6 +208,18 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, con
   return v;
 }
 
+// Auxiliary values of stage S for row r of plane q: only planes this chunk's
+// stage S really evaluates are touched (the surplus steps of the last trip and
+// the warm-up steps must not reach outside the buffer).
+template <int S>
+__device__ __forceinline__ typename sf_stage<S>::aux_row sf_aux_row(const sf_ctx& cx, const int q, const int r) {
+  const bool plane_ok = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G) && (q + cx.halo >= 0) &&
+                        q >= cx.cb - (SF_T - S) && q < cx.ce + (SF_T - S);
+  return sf_stage<S>::load_aux(
+      cx.aux, (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2) + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0),
+      plane_ok && ((cx.jmask >> r) & 1u) && cx.kvec_in);
+}
+
 // One stage of the fused group at one step: reads the source window of stage
 // S-1 at phase PH and writes plane q = p - S of stage S (into its own window, or
 // to HBM for the last stage).
@@ -219,6 +246,21 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
   sf_t pad = (sf_t)0;
   if constexpr (S < SF_T) pad = sf_stage<(S < SF_T ? S + 1 : S)>::bc();
   sf_vec jm = jm0;
+#if SF_AUX_AHEAD
+  // all auxiliary rows of this stage are requested before its first row is
+  // evaluated (they come straight from HBM: issued late they stall every row)
+  typename sf_stage<S>::aux_row axs[SF_RJ];
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+#if SF_AUX_AHEAD == 2
+    // requested during the previous step; the slot then takes the next plane's row
+    axs[r] = static_cast<sf_auxslots<S>&>(st).a[r];
+    static_cast<sf_auxslots<S>&>(st).a[r] = sf_aux_row<S>(cx, q + 1, r);
+#else
+    axs[r] = sf_aux_row<S>(cx, q, r);
+#endif
+  }
+#endif
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     const sf_vec c = st.w[src][icur][r];
@@ -258,10 +300,11 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
                  : sf_stage<S>::bc();
 #endif
     // centre-only auxiliary fields of this stage, row r of plane q
-    const auto ax = sf_stage<S>::load_aux(
-        cx.aux,
-        (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2) + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0),
-        plane_in && (q + cx.halo >= 0) && ((cx.jmask >> r) & 1u) && cx.kvec_in);
+#if SF_AUX_AHEAD
+    const auto ax = axs[r];
+#else
+    const auto ax = sf_aux_row<S>(cx, q, r);
+#endif
     sf_vec o;
 #pragma unroll
     for (int v = 0; v < SF_VK; ++v) {
@@ -336,6 +379,19 @@ __device__ __forceinline__ void sf_later_stages_desc(sf_state& st, const sf_t* l
     sf_later_stages_desc<S - 1, PH>(st, lds, sc, out, cx, p);
   }
 }
+
+#if SF_AUX_AHEAD == 2
+// Fill every stage's auxiliary slot with the rows its first step uses.
+template <int S>
+__device__ __forceinline__ void sf_aux_preload(sf_state& st, const sf_ctx& cx, const int p_first) {
+  if constexpr (S <= SF_T) {
+    const int q = SF_REVERSE ? p_first - (2 * S - 1) : p_first - S;
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r) static_cast<sf_auxslots<S>&>(st).a[r] = sf_aux_row<S>(cx, q, r);
+    sf_aux_preload<S + 1>(st, cx, p_first);
+  }
+}
+#endif
 
 __device__ __forceinline__ void sf_load_plane(const sf_t* __restrict__ in, const sf_ctx& cx,
                                               const int p, sf_vec (&dst)[SF_RJ]) {
@@ -565,6 +621,9 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   }
 #endif
 
+#if SF_AUX_AHEAD == 2
+  sf_aux_preload<1>(st, cx, p_begin);
+#endif
   // Two exchange images alternate every step (run-time offset); the window
   // phase cycles with period 3 (compile-time slot indices).
   int image = 0;

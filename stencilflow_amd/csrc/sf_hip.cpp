@@ -411,6 +411,11 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   // C5 +1.4 %; the cache-resident 64 MiB field of C2 loses 13 % with them).
   const double field_bytes = (double)pl.n_local * (double)P.n[1] * (double)P.n[2] * (double)size_of(dt);
   base.uniform = (int)pl.opt.get("k1.uni", base.dpp == 3 ? 1 : 0);
+  // auxiliary (centre-only) fields: 1 = a stage requests all its rows before its
+  // first row is evaluated (3-D hotspot chains +15 %); 2 = rows are requested a
+  // whole step ahead into per-stage slots (2-D, where a thread has one row and
+  // registers to spare)
+  base.aux_ahead = (int)pl.opt.get("k1.auxpre", base.noj ? 2 : 1);
   base.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
   const std::string pfx = base.noj ? "k2." : "k1.";
   const long long pin_bx = pl.opt.get(pfx + "bx", 0);

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""GPU: throughput of programs from the workload generator (the reference's
+bin/synthesize.py conventions: integer boundary literals -> float32 sums,
+coefficient 1/n, optional extra fields) at benchmark size.
+usage: synth_perf.py [--size 512] [--stages 16]"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import stencilflow_amd as sf  # noqa: E402
+from stencilflow_amd import programs  # noqa: E402
+from stencilflow_amd.backend import Plan  # noqa: E402
+from stencilflow_amd.lowering import lower  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--stages", type=int, default=16)
+    args = ap.parse_args()
+    n, st = args.size, args.stages
+    cases = [
+        ("cross 3-D f32", ("float32", st, 0.0, n, n, n, 1, 1, 1), {}),
+        ("cross 3-D f64", ("float64", st, 0.0, n, n, n, 1, 1, 1), {}),
+        ("diffusion 3-D f32", ("float32", st, 0.0, n, n, n, 1, 1, 1), {"stencil_shape": "diffusion"}),
+        ("hotspot 3-D f32", ("float32", st, 0.0, n, n, n, 1, 1, 1), {"stencil_shape": "hotspot"}),
+        ("box 3-D f32", ("float32", st, 0.0, n, n, n, 1, 1, 1), {"stencil_shape": "box"}),
+        ("cross 3-D f32, extra field every 2nd stage", ("float32", st, 0.5, n, n, n, 1, 1, 1), {}),
+        ("cross 2-D f32", ("float32", st, 0.0, 0, 8 * n, 8 * n, 0, 1, 1), {}),
+        ("hotspot 2-D f32", ("float32", st, 0.0, 0, 8 * n, 8 * n, 0, 1, 1), {"stencil_shape": "hotspot"}),
+    ]
+    rng = np.random.default_rng(5)
+    with tempfile.TemporaryDirectory() as tmp:
+        for label, pos, kw in cases:
+            prog, _ = programs.synthesize(*pos, **kw)
+            path = programs.write_program(prog, os.path.join(tmp, "p.json"))
+            chain = sf.KernelChainGraph(path)
+            plan = Plan(lower(chain))
+            if plan.scalar_names:
+                plan.set_scalars([0.1] * len(plan.scalar_names))
+            shape = prog["dimensions"]
+            dtype = np.float32 if pos[0] == "float32" else np.float64
+            plan.upload([rng.random(shape).astype(dtype) for _ in plan.input_names])
+            for _ in range(2):
+                plan.execute(1)
+                plan.synchronize()
+            times = []
+            for _ in range(3):
+                plan.execute(4)
+                plan.synchronize()
+                times.append(plan.elapsed_ms() / 4)
+            ms = float(np.median(times))
+            ops = len(prog["program"])
+            cells = float(np.prod(shape)) * ops
+            bpu = 8.0 if dtype == np.float32 else 16.0
+            kinds = plan.describe().count("[star"), plan.describe().count("[point]")
+            print(json.dumps({"case": label, "dims": shape, "operators": ops, "launches": plan.num_launches,
+                              "star/point launches": kinds, "ms": round(ms, 3),
+                              "Mcells/s": round(cells / ms / 1e3), "frac_8TB": round(cells * bpu / (ms * 1e-3) / 8e12, 3),
+                              "first": plan.describe().splitlines()[1].strip()[:110]}), flush=True)
+            plan.close()
+
+
+if __name__ == "__main__":
+    main()
