@@ -511,9 +511,22 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
   const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
                       (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
   const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
-  for (size_t ci = 0; ci < tries; ++ci) {
+  int rejected = 0;
+  for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {  // compile errors rarely depend on the shape
     StarKernelSource g = gen_star(P, kernels, ranked[ci]);
-    const int ck = intern_kernel(pl, prefix, g.source);
+    int ck = -1;
+    try {
+      ck = intern_kernel(pl, prefix, g.source);
+    } catch (const Error& e) {
+      // a shape the compiler rejects is no candidate (a pinned shape reports it);
+      // the group is shortened and in the end the generic kernel takes over
+      if (pinned || e.status != SF_ERR_COMPILE) throw;
+      if (pl.opt.get("debug", 0) != 0)
+        std::fprintf(stderr, "[sf_hip] candidate %zu/%zu rejected by the compiler: %.200s\n", ci + 1,
+                     ranked.size(), e.what());
+      ++rejected;
+      continue;
+    }
     const CompiledKernel& k = pl.kernels[ck];
     const int bad = std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs);
     if (pl.opt.get("debug", 0) != 0)
