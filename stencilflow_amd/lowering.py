@@ -29,12 +29,11 @@ SFIR grammar (one record per line, blank-separated)::
     end
 """
 
-import networkx as nx  # noqa: F401  (chain.graph is a networkx graph)
 
 from . import dtypes
 from .expr import JUNK_VAL, access_var, c_literal, to_c
 from .helper import ITERATORS
-from .kernel_chain_graph import Input, Kernel, Output
+from .kernel_chain_graph import Kernel
 
 _SHORT = {
     "float32": "f32",

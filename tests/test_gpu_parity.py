@@ -3,7 +3,6 @@ C ABI of libsf_hip.so).  Floating point contract: results are produced by the
 same typed expression in the same order as the oracle, so they are required to
 be bit-identical for + - * / programs, and within 1e-6 relative (BASELINE.json)
 where device math functions are involved."""
-import json
 import os
 
 import numpy as np
@@ -285,7 +284,7 @@ def test_slab_decomposition_in_process(tmp_path, world, overlap, groups):
     ranks' device buffers by the driver) equals the undivided run bit for bit.
     All ranks share this GPU; the transport is the only part not covered."""
     from stencilflow_amd.distributed import (LocalExchanger, SlabRunner,
-                                             run_lockstep, slab_bounds)
+                                             run_lockstep)
     from stencilflow_amd.lowering import lower
     shape, stages = (52, 24, 64), 11
     rng = np.random.default_rng(SEED + 7)

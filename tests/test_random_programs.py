@@ -3,7 +3,6 @@ implementations agree bit for bit (CPU), the front end lowers every program and
 the library compiles it (CPU), and the HIP backend agrees with the oracle bit
 for bit (GPU)."""
 import json
-import os
 
 import numpy as np
 import pytest

@@ -1,6 +1,6 @@
 """GPU: hotspot chains (centre-only auxiliary field per stage) with and without early
 auxiliary-row requests (k1.auxpre)."""
-import sys, json
+import sys
 sys.path.insert(0, "/root/repo")
 import numpy as np
 import stencilflow_amd as sf
