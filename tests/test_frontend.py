@@ -186,3 +186,24 @@ def test_synthesize_conventions():
     assert prog["inputs"]["c6"]["input_dims"] == []
     assert prog["program"]["b0"]["computation_string"].startswith(
         "b0 = c0*a[i, j, k] + c1*a[i-1, j, k]")
+
+
+def test_degenerate_programs_plan_or_fail_cleanly(tmp_path):
+    """Operators without field accesses, 1x1xN and 1-D domains are planned;
+    malformed descriptions raise the documented exception, not a crash."""
+    import json
+    import pytest
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    from tests.degenerate_programs import INVALID, VALID
+    for name, prog in VALID.items():
+        path = tmp_path / (name + ".json")
+        path.write_text(json.dumps(prog))
+        with Plan(lower(sf.KernelChainGraph(str(path)))) as plan:
+            assert plan.num_launches == 1 and plan.output_names == ["b"], name
+    for name, (exc, text, prog) in INVALID.items():
+        path = tmp_path / (name + ".json")
+        path.write_text(json.dumps(prog))
+        with pytest.raises(exc, match=text):
+            with Plan(lower(sf.KernelChainGraph(str(path)))):
+                pass

@@ -693,3 +693,14 @@ def test_full_c4_grid_eight_slabs_bit_exact():
     for _ in range(stages // block):
         want = ref.run({"a": want})["b%d" % (block - 1)]
     assert np.array_equal(got, want)
+
+
+def test_degenerate_programs(tmp_path):
+    """tests/degenerate_programs.py on the GPU against the oracle."""
+    from tests.degenerate_programs import VALID
+    for name, prog in VALID.items():
+        path = _write(tmp_path, prog, name)
+        ins = _inputs_of(prog)
+        want = npo.run_reference(prog, inputs=ins)["b"]
+        got, _ = _run_gpu(path, ins)
+        assert got["b"].dtype == want.dtype and np.array_equal(got["b"], want), name
