@@ -85,7 +85,12 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #define SF_ROWS_ELEMS (SF_T * SF_BY * 2 * SF_TKH)
 #endif
 #define SF_USE_LDS (!(SF_NOJ && SF_WPR == 1))
-#define SF_EDGE_ELEMS (SF_T * SF_BY * SF_RJ * SF_WPR * 2)
+// (SF_DPP 4: one virtual wave below and one above every row hold the boundary
+// constant, so a wave reads its neighbours' edge columns without testing whether
+// they exist)
+#define SF_VWAVES (SF_DPP == 4 && SF_WPR > 1)
+#define SF_EDGE_WAVES (SF_VWAVES ? SF_WPR + 2 : SF_WPR)
+#define SF_EDGE_ELEMS (SF_T * SF_BY * SF_RJ * SF_EDGE_WAVES * 2)
 #define SF_IMAGE_ELEMS (SF_ROWS_ELEMS + SF_EDGE_ELEMS)
 
 // w[s][slot][row]: planes of stage-s data (s = 0 is the input field).  At
@@ -125,7 +130,8 @@ __device__ __forceinline__ int sf_rows_at(int s, int ty, int which) {
   return ((s * SF_BY + ty) * 2 + which) * SF_TKH;
 }
 __device__ __forceinline__ int sf_edge_at(int s, int ty, int r, int w, int side) {
-  return SF_ROWS_ELEMS + ((((s * SF_BY + ty) * SF_RJ + r) * SF_WPR + w) * 2 + side);
+  return SF_ROWS_ELEMS +
+         ((((s * SF_BY + ty) * SF_RJ + r) * SF_EDGE_WAVES + (SF_VWAVES ? w + 1 : w)) * 2 + side);
 }
 
 // Value of the adjacent lane (lane-1 for DOWN = false ... see callers) through the
@@ -246,6 +252,14 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
   sf_t pad = (sf_t)0;
   if constexpr (S < SF_T) pad = sf_stage<(S < SF_T ? S + 1 : S)>::bc();
   sf_vec jm = jm0;
+#if SF_DPP == 4 && SF_WPR > 1
+  sf_t e_lo[SF_RJ], e_hi[SF_RJ];
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    e_lo[r] = lds[sf_edge_at(src, ty, r, cx.wave - 1, 1)];
+    e_hi[r] = lds[sf_edge_at(src, ty, r, cx.wave + 1, 0)];
+  }
+#endif
 #if SF_AUX_AHEAD
   // all auxiliary rows of this stage are requested before its first row is
   // evaluated (they come straight from HBM: issued late they stall every row)
@@ -269,7 +283,14 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
     const sf_vec jp = (r < SF_RJ - 1) ? st.w[src][icur][r < SF_RJ - 1 ? r + 1 : r] : jpl;
     // innermost-dimension halo: adjacent lanes hold the adjacent vectors
     // SF_EXPERIMENT 3: timing-only build without the lane exchange (invalid results)
-#if SF_DPP == 3
+#if SF_DPP == 4 && SF_WPR > 1
+    // Lanes 0 / 63 take the neighbouring wave's edge column -- or, from the
+    // virtual waves beside the row, the boundary constant -- as the DPP move's
+    // starting destination: no test, no select (the words were read before the
+    // first row, see e_lo / e_hi).
+    const sf_t km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], e_lo[r]);
+    const sf_t kp_e = sf_neighbour_lane_or<false>(c[0], e_hi[r]);
+#elif SF_DPP >= 3
     // Lanes 0 / 63 have no source lane.  Their value is the neighbouring wave's
     // edge column (LDS, every lane reads the same word) or this stage's boundary
     // constant; it is handed to the DPP move as the starting destination, so no
@@ -379,6 +400,25 @@ __device__ __forceinline__ void sf_later_stages_desc(sf_state& st, const sf_t* l
     sf_later_stages_desc<S - 1, PH>(st, lds, sc, out, cx, p);
   }
 }
+
+#if SF_DPP == 4 && SF_WPR > 1
+template <int S>
+__device__ __forceinline__ void sf_edge_prefill(sf_t* lds_all, const sf_ctx& cx) {
+  if constexpr (S <= SF_T) {
+    if (cx.lane == 0 && (cx.wave == 0 || cx.wave == SF_WPR - 1)) {
+#pragma unroll
+      for (int image = 0; image < (SF_LDS_DB ? 2 : 1); ++image)
+#pragma unroll
+        for (int r = 0; r < SF_RJ; ++r) {
+          sf_t* lds = lds_all + image * SF_IMAGE_ELEMS;
+          if (cx.wave == 0) lds[sf_edge_at(S - 1, cx.ty, r, -1, 1)] = sf_stage<S>::bc();
+          if (cx.wave == SF_WPR - 1) lds[sf_edge_at(S - 1, cx.ty, r, SF_WPR, 0)] = sf_stage<S>::bc();
+        }
+    }
+    sf_edge_prefill<S + 1>(lds_all, cx);
+  }
+}
+#endif
 
 #if SF_AUX_AHEAD == 2
 // Fill every stage's auxiliary slot with the rows its first step uses.
@@ -623,6 +663,11 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 
 #if SF_AUX_AHEAD == 2
   sf_aux_preload<1>(st, cx, p_begin);
+#endif
+#if SF_DPP == 4 && SF_WPR > 1
+  // the virtual waves' edge words: window s is read by stage s + 1, whose boundary
+  // constant they hold (never overwritten; the first step's barrier orders them)
+  sf_edge_prefill<1>(lds_all, cx);
 #endif
   // Two exchange images alternate every step (run-time offset); the window
   // phase cycles with period 3 (compile-time slot indices).

@@ -266,7 +266,7 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static size_t star_lds_bytes(const StarCfg& c, DT dt) {
   const size_t rows = c.noj ? 0 : (size_t)c.T * c.BY * 2 * c.BX * c.VK;
-  const size_t edge = (size_t)c.T * c.BY * c.RJ * (c.BX / 64) * 2;
+  const size_t edge = (size_t)c.T * c.BY * c.RJ * (c.BX / 64 + ((c.dpp == 4 && c.BX > 64) ? 2 : 0)) * 2;
   return (rows + edge) * size_of(dt) * (c.lds_db ? 2 : 1);
 }
 
@@ -398,24 +398,24 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   if (!base.prefetch2 && base.reverse != 2) base.pfd = 1;
   base.experiment = (int)pl.opt.get("experiment", 0);
   // lane exchange: 0 = __shfl, 1 = DPP, 2 = DPP with bound_ctrl (no copy before the
-  // move), 3 = as 2 and the wave's edge lane gets its value from the move's
-  // starting destination instead of a select.  f32: 2 (3 costs 7 % in scalar
-  // branches); f64, where every value is two moves and two selects: 3 (+4.7 % on C5).
-  // One-wave-wide blocks (no neighbouring wave, hence no LDS side) also take 3:
-  // C2 +8 %.
+  // move), 3 = as 2 and the wave's edge lane gets its value (boundary constant or
+  // the neighbouring wave's edge column) from the move's starting destination
+  // instead of a select, 4 = as 3 with the neighbour test removed: virtual waves
+  // beside every row hold the boundary constant in LDS.  Measured: C3 2 -> 4 +1 %
+  // (3 costs 7 % there: scalar branches per row), C5 2 -> 3/4 +4.7 %, C2 +8 %.
   const long long dpp_opt = pl.opt.get("k1.dpp", -1);
-  base.dpp = dpp_opt >= 0 ? (int)dpp_opt : (dt == DT::F64 ? 3 : 2);
+  base.dpp = dpp_opt >= 0 ? (int)dpp_opt : 4;
+  base.uniform = (int)pl.opt.get("k1.uni", 0);
+  // auxiliary (centre-only) fields: 1 = a stage requests all its rows before its
+  // first row is evaluated (3-D hotspot chains +21 %); 2 = rows are requested a
+  // whole step ahead into per-stage slots (2-D, where a thread has one row and
+  // registers to spare, +11 %)
+  base.aux_ahead = (int)pl.opt.get("k1.auxpre", base.noj ? 2 : 1);
   // Non-temporal output stores when a field is larger than the 256 MiB Infinity
   // Cache: nothing of it would survive until the next launch reads it, and not
   // allocating the written lines leaves the cache to the input stream (C3 +3 %,
   // C5 +1.4 %; the cache-resident 64 MiB field of C2 loses 13 % with them).
   const double field_bytes = (double)pl.n_local * (double)P.n[1] * (double)P.n[2] * (double)size_of(dt);
-  base.uniform = (int)pl.opt.get("k1.uni", base.dpp == 3 ? 1 : 0);
-  // auxiliary (centre-only) fields: 1 = a stage requests all its rows before its
-  // first row is evaluated (3-D hotspot chains +15 %); 2 = rows are requested a
-  // whole step ahead into per-stage slots (2-D, where a thread has one row and
-  // registers to spare)
-  base.aux_ahead = (int)pl.opt.get("k1.auxpre", base.noj ? 2 : 1);
   base.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
   const std::string pfx = base.noj ? "k2." : "k1.";
   const long long pin_bx = pl.opt.get(pfx + "bx", 0);
@@ -435,8 +435,6 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
         c.BX = bx;
         c.RJ = rj;
         c.BY = by;
-        if (dpp_opt < 0 && bx == 64) c.dpp = 3;
-        if (pl.opt.get("k1.uni", -1) < 0) c.uniform = (c.dpp == 3) ? 1 : 0;
         if (!c.noj && by * rj - 2 * T < 1) continue;
         star_finish_cfg(c, P, T);
         if (star_lds_bytes(c, dt) > 160 * 1024) continue;
