@@ -823,7 +823,12 @@ static void build_plan(sf_plan& pl) {
 
 // ---------------------------------------------------------------- runtime
 static void ensure_device(sf_plan& pl) {
-  if (pl.device_ready) return;
+  if (pl.device_ready) {
+    // every entry point runs on the plan's device, whatever device the calling
+    // thread used last (one thread may drive plans on several GPUs)
+    SF_HIP_CHECK(hipSetDevice(pl.device));
+    return;
+  }
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0)
