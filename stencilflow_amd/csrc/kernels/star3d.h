@@ -18,6 +18,12 @@
 //   thread = SF_RJ consecutive rows x SF_VK consecutive k (one 16-byte vector
 //            per row); for every stage boundary a window of three planes
 //            (q-1, q, q+1) lives in registers.
+//   Input planes (SF_PREFETCH2): 0 = the plane for the next step is loaded into
+//   the window slot stage 1 has just freed; 1 = it is loaded into staging
+//   registers a step earlier and copied into the freed slot (a load has two
+//   steps to land); 2 = the input window has FOUR slots rotating with period 4
+//   (the step loop is unrolled by 4), so the plane after next is loaded straight
+//   into the slot freed now: two steps to land, no copy.
 //   Per step one new input plane is read from HBM (coalesced 16 B/lane);
 //   i-neighbours come from the register window, j-neighbours from registers
 //   (inner rows) or LDS (first/last row of the adjacent thread row),
@@ -59,6 +65,26 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #ifndef SF_AUX_AHEAD
 #define SF_AUX_AHEAD 0
 #endif
+#ifndef SF_UNIFORM_LOADS
+#define SF_UNIFORM_LOADS 0
+#endif
+#ifndef SF_BUFFER_IO
+#define SF_BUFFER_IO 0
+#endif
+
+// SF_BUFFER_IO: planes are read and written with buffer instructions whose
+// resource describes exactly one plane.  A lane (or a whole row, or -- with zero
+// records -- a whole plane) that must not touch memory is given an offset
+// outside the resource: the hardware drops such stores and returns 0 for such
+// loads.  No vector-memory instruction of the step loop sits under a branch any
+// more, so the compiler can count them and waits for the loads it needs
+// (`s_waitcnt vmcnt(N)`) instead of for everything in flight, stores included
+// (`vmcnt(0)`, once per step, as soon as any of them is conditional).
+typedef unsigned sf_u4 __attribute__((ext_vector_type(4)));
+#define SF_OOB 0x80000000u
+#define SF_PLANE_ELEMS ((long long)SF_N1 * (long long)SF_N2)
+#define SF_PLANE_BYTES ((unsigned)(SF_PLANE_ELEMS * (long long)sizeof(sf_t)))
+#define SF_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format (gfx9 / CDNA) */
 
 #if SF_REVERSE  // loads are issued at the end of the step: no staging registers
 #undef SF_PREFETCH2
@@ -66,6 +92,10 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #undef SF_SPREAD_LOADS
 #define SF_SPREAD_LOADS 0
 #endif
+
+// window slots per stage and period of the phase rotation
+#define SF_RING4 (SF_PREFETCH2 == 2)
+#define SF_SLOTS (SF_RING4 ? 4 : 3)
 
 #define SF_TJH (SF_BY * SF_RJ)
 #define SF_TKH (SF_BX * SF_VK)
@@ -94,7 +124,9 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #define SF_IMAGE_ELEMS (SF_ROWS_ELEMS + SF_EDGE_ELEMS)
 
 // w[s][slot][row]: planes of stage-s data (s = 0 is the input field).  At
-// phase PH the slots hold  prev = PH % 3,  cur = (PH + 1) % 3,  next = (PH + 2) % 3.
+// phase PH the slots hold  prev = PH % 3,  cur = (PH + 1) % 3,  next = (PH + 2) % 3
+// (SF_RING4: modulo 4; slot (PH + 3) % 4 of the input window holds the plane in
+// flight, the same slot of the later stages' windows is never live).
 // (SF_AUX_AHEAD 2) one row set of auxiliary values per stage, requested a step ahead
 template <int N>
 struct sf_auxslots : sf_auxslots<N - 1> {
@@ -108,8 +140,8 @@ struct sf_state
     : sf_auxslots<SF_T>
 #endif
 {
-  sf_vec w[SF_T][3][SF_RJ];
-#if SF_REVERSE == 2 || SF_PREFETCH2
+  sf_vec w[SF_T][SF_SLOTS][SF_RJ];
+#if SF_REVERSE == 2 || SF_PREFETCH2 == 1
   // input planes in flight: a ring of SF_PFD (1 or 3) planes, so a load has
   // SF_PFD full steps to land (slot = phase % SF_PFD)
   sf_vec pf[SF_PFD][SF_RJ];
@@ -124,6 +156,11 @@ struct sf_ctx {
   bool kvec_in;
   bool tile_inside;  // block-uniform: every point of the tile lies in the (j,k) domain
   int goff, halo, cb, ce, j0, k0;
+#if SF_BUFFER_IO
+  // byte offset of this lane's vector in row r of a plane, or SF_OOB where the
+  // lane must not load (outside the (j,k) domain) / store (halo rows and columns)
+  unsigned ld_off[SF_RJ], st_off[SF_RJ];
+#endif
 };
 
 __device__ __forceinline__ int sf_rows_at(int s, int ty, int which) {
@@ -201,18 +238,64 @@ __device__ __forceinline__ bool sf_row_ok(const sf_ctx& cx, const int p, const i
 
 // Row r of input plane p (padded with stage 1's boundary constant outside the
 // global domain).
-__device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, const int r) {
+__device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, const int r,
+                                              const bool enabled = true) {
+#if SF_BUFFER_IO
+  // wave-uniform: a plane outside the global domain (or a load the caller has
+  // switched off) gets a resource of zero records
+  const bool plane_ok =
+      enabled && SF_EXPERIMENT != 5 && (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
+  const char* base = reinterpret_cast<const char*>(cx.in) + (long long)(p + cx.halo) * (long long)SF_PLANE_BYTES;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(base), 0, plane_ok ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
+  sf_vec v = __builtin_bit_cast(sf_vec, __builtin_amdgcn_raw_buffer_load_b128(rs, cx.ld_off[r], 0, (SF_NT & 2) ? 2 : 0));
+  if constexpr (!sf_stage<1>::bc_zero) {
+    const bool ok = plane_ok && cx.ld_off[r] != SF_OOB;
+#pragma unroll
+    for (int e = 0; e < SF_VK; ++e) v[e] = ok ? v[e] : sf_stage<1>::bc();
+  }
+  return v;
+#else
+  (void)enabled;
+  const sf_t* plane = cx.in + (size_t)(p + cx.halo) * ((size_t)SF_N1 * SF_N2);
+  const sf_vec* src = reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0));
+#if SF_UNIFORM_LOADS
+  // Tiles strictly inside the (j,k) domain (block-uniform) have no lane to pad:
+  // the test left is the plane's, which is wave-uniform, so the load needs no
+  // execution mask and its destination no fill beforehand.
+  if (cx.tile_inside && SF_EXPERIMENT != 5) {
+    if ((p + cx.goff >= 0) && (p + cx.goff < SF_N0G)) {
+#if SF_NT & 2
+      return __builtin_nontemporal_load(src);
+#else
+      return *src;
+#endif
+    }
+    return (sf_vec)sf_stage<1>::bc();
+  }
+#endif
   sf_vec v = (sf_vec)sf_stage<1>::bc();
   if (sf_row_ok(cx, p, r)) {
-    const sf_t* plane = cx.in + (size_t)(p + cx.halo) * ((size_t)SF_N1 * SF_N2);
 #if SF_NT & 2
-    v = __builtin_nontemporal_load(reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)));
+    v = __builtin_nontemporal_load(src);
 #else
-    v = *reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0));
+    v = *src;
 #endif
   }
   return v;
+#endif  // SF_BUFFER_IO
 }
+
+// `dst = row r of plane p` if `cond` (wave-uniform).  SF_BUFFER_IO: always issued,
+// with a resource of zero records when `cond` is false (dst then holds the padding).
+#if SF_BUFFER_IO
+#define SF_LOAD_ROW_IF(cond, dst, p, r) dst = sf_load_row(cx, p, r, cond)
+#else
+#define SF_LOAD_ROW_IF(cond, dst, p, r) \
+  do {                                  \
+    if (cond) dst = sf_load_row(cx, p, r); \
+  } while (0)
+#endif
 
 // Auxiliary values of stage S for row r of plane q: only planes this chunk's
 // stage S really evaluates are touched (the surplus steps of the last trip and
@@ -234,7 +317,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
                                               sf_t* __restrict__ out, const sf_ctx& cx, const int p,
                                               const bool load_next = false) {
   constexpr int src = S - 1;
-  constexpr int iprev = PH % 3, icur = (PH + 1) % 3, inext = (PH + 2) % 3;
+  constexpr int iprev = PH % SF_SLOTS, icur = (PH + 1) % SF_SLOTS, inext = (PH + 2) % SF_SLOTS;
   const int tx = cx.tx, ty = cx.ty;
   // first / last row of the neighbouring thread rows (LDS)
   sf_vec jm0 = st.w[src][icur][0], jpl = st.w[src][icur][SF_RJ - 1];
@@ -334,26 +417,45 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       o[v] = sf_stage<S>::apply(c[v], im[v], ip[v], jm[v], jp[v], km, kp, sc, ax, v);
     }
     jm = c;
-#if SF_PREFETCH2
+#if SF_RING4
+    if constexpr (S == 1) {
+      // row r of the input window's "prev" slot is dead now: it receives row r of
+      // the plane after next (the next plane is already in flight in the fourth
+      // slot), which has two steps to land -- and nothing is copied
+      SF_LOAD_ROW_IF(load_next, st.w[0][iprev][r], p + 2, r);
+    }
+#elif SF_PREFETCH2
     if constexpr (S == 1) {
       // row r of the input window's "prev" slot is dead now: it takes row r of
       // plane p+1 from the staging registers (loaded during the previous step),
       // which then receive row r of plane p+2
       st.w[0][iprev][r] = st.pf[PH % SF_PFD][r];
-      if (load_next) st.pf[PH % SF_PFD][r] = sf_load_row(cx, p + 1 + SF_PFD, r);
+      SF_LOAD_ROW_IF(load_next, st.pf[PH % SF_PFD][r], p + 1 + SF_PFD, r);
     }
 #elif SF_SPREAD_LOADS
     if constexpr (S == 1) {
       // row r of the input window's "prev" slot is dead now: it receives row r of
       // input plane p+1 -- loads are spread over stage 1 instead of issued in a burst
-      if (load_next) st.w[0][iprev][r] = sf_load_row(cx, p + 1, r);
+      SF_LOAD_ROW_IF(load_next, st.w[0][iprev][r], p + 1, r);
     }
 #endif
     if constexpr (S == SF_T) {
       // last stage of the group: write interior, in-domain points
       // SF_EXPERIMENT 1: timing-only build without the output stores (invalid results)
       if (SF_EXPERIMENT == 1) asm volatile("" ::"v"(o));
+#if SF_BUFFER_IO
+      {
+        // always issued: a plane that is not stored has a resource of zero records,
+        // rows and lanes that are not stored an offset outside the plane
+        char* base = reinterpret_cast<char*>(out) + (long long)(q + cx.halo) * (long long)SF_PLANE_BYTES;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            base, 0, (SF_EXPERIMENT != 1 && store_plane) ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_u4, o), rs, cx.st_off[r], 0, (SF_NT & 1) ? 2 : 0);
+      }
+      if (false) {
+#else
       if (SF_EXPERIMENT != 1 && store_plane && ((cx.store_mask >> r) & 1u)) {
+#endif
         // wave-uniform plane base (SGPR pair) + 32-bit in-plane offset
         sf_t* plane = out + (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2);
 #if SF_NT & 1
@@ -434,9 +536,9 @@ __device__ __forceinline__ void sf_aux_preload(sf_state& st, const sf_ctx& cx, c
 #endif
 
 __device__ __forceinline__ void sf_load_plane(const sf_t* __restrict__ in, const sf_ctx& cx,
-                                              const int p, sf_vec (&dst)[SF_RJ]) {
+                                              const int p, sf_vec (&dst)[SF_RJ], const bool enabled = true) {
 #pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) dst[r] = sf_load_row(cx, p, r);
+  for (int r = 0; r < SF_RJ; ++r) SF_LOAD_ROW_IF(enabled, dst[r], p, r);
 }
 
 // One step (input plane p) at phase PH.
@@ -465,7 +567,7 @@ template <int PH>
 __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __restrict__ in,
                                         sf_t* __restrict__ out, const sf_scalars& sc,
                                         const sf_ctx& cx, const int p, const int p_end SF_STAMP_ARGS) {
-  constexpr int icur = (PH + 1) % 3;
+  constexpr int icur = (PH + 1) % SF_SLOTS;
 #if SF_REVERSE == 2
   // the plane loaded during the previous step (between its last and its first
   // stage) enters the window as plane "next"; this is the step's only wait on
@@ -480,11 +582,13 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
 #pragma unroll
   for (int s = 0; s < SF_T; ++s)
 #pragma unroll
-    for (int w = 0; w < 3; ++w)
+    for (int w = 0; w < SF_SLOTS; ++w)
 #pragma unroll
       for (int r = 0; r < SF_RJ; ++r) {
         // (SF_REVERSE 1: the input plane still in flight must not be touched here)
         if (SF_REVERSE == 1 && s == 0 && w == (PH + 2) % 3) continue;
+        // (SF_RING4: nor the fourth slot -- in flight for the input, dead otherwise)
+        if (SF_RING4 && w == (PH + 3) % 4) continue;
         asm volatile("" : "+v"(st.w[s][w][r]));
       }
 #endif
@@ -519,17 +623,15 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
   sf_later_stages_desc<SF_T, PH>(st, lds, sc, out, cx, p);
   SF_STAMP_AT(3);
 #if SF_REVERSE == 2
-  if (p + SF_PFD < p_end) {
 #pragma unroll
-    for (int r = 0; r < SF_RJ; ++r) st.pf[PH % SF_PFD][r] = sf_load_row(cx, p + SF_PFD, r);
-  }
+  for (int r = 0; r < SF_RJ; ++r) SF_LOAD_ROW_IF(p + SF_PFD < p_end, st.pf[PH % SF_PFD][r], p + SF_PFD, r);
   SF_STAMP_AT(2);
   sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
   SF_STAMP_AT(1);
 #else
   sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
   SF_STAMP_AT(1);
-  if (p + 1 < p_end) sf_load_plane(in, cx, p + 1, st.w[0][PH % 3]);
+  sf_load_plane(in, cx, p + 1, st.w[0][PH % 3], p + 1 < p_end);
   SF_STAMP_AT(2);
 #endif
   if (SF_USE_LDS && !SF_LDS_DB) __syncthreads();
@@ -537,7 +639,10 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
 #endif
   // stage 1 consumes input plane p (slot "next" of the input window) and frees
   // slot "prev", which receives input plane p+1
-#if SF_PREFETCH2
+#if SF_RING4
+  sf_stage_step<1, PH>(st, lds, sc, out, cx, p, p + 2 < p_end);
+  SF_STAMP_AT(1);
+#elif SF_PREFETCH2
   sf_stage_step<1, PH>(st, lds, sc, out, cx, p, p + 1 + SF_PFD < p_end);
   SF_STAMP_AT(1);
 #elif SF_SPREAD_LOADS
@@ -546,7 +651,7 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
 #else
   sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
   SF_STAMP_AT(1);
-  if (p + 1 < p_end) sf_load_plane(in, cx, p + 1, st.w[0][PH % 3]);
+  sf_load_plane(in, cx, p + 1, st.w[0][PH % 3], p + 1 < p_end);
 #endif
   SF_STAMP_AT(2);
   sf_later_stages<2, PH>(st, lds, sc, out, cx, p);
@@ -631,11 +736,20 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     if (!(tk >= SF_HK && tk < SF_TKH - SF_HK && cx.kvec_in)) cx.store_mask = 0;
   }
 
+#if SF_BUFFER_IO
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    const unsigned off = (unsigned)(((cx.j0 + r) * SF_N2 + cx.k0) * (int)sizeof(sf_t));
+    cx.ld_off[r] = (((cx.jmask >> r) & 1u) && cx.kvec_in) ? off : SF_OOB;
+    cx.st_off[r] = ((cx.store_mask >> r) & 1u) ? off : SF_OOB;
+  }
+#endif
+
   sf_state st;
 #pragma unroll
   for (int s = 0; s < SF_T; ++s)
 #pragma unroll
-    for (int w = 0; w < 3; ++w)
+    for (int w = 0; w < SF_SLOTS; ++w)
 #pragma unroll
       for (int r = 0; r < SF_RJ; ++r) st.w[s][w][r] = (sf_vec)(sf_t)0;
 
@@ -646,7 +760,10 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 #if SF_REVERSE != 2
   sf_load_plane(in, cx, p_begin, st.w[0][2]);  // slot "next" of phase 0
 #endif
-#if SF_PREFETCH2 || SF_REVERSE == 2
+#if SF_RING4
+  // the plane after the one stage 1 starts with is already in flight (fourth slot)
+  sf_load_plane(in, cx, p_begin + 1, st.w[0][3], p_begin + 1 < p_end);
+#elif SF_PREFETCH2 || SF_REVERSE == 2
   // fill the prefetch ring: the planes after the one stage 1 starts with
   // (SF_REVERSE 2: including that one)
 #pragma unroll
@@ -654,10 +771,8 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     const int pd = p_begin + d + (SF_REVERSE == 2 ? 0 : 1);
 #pragma unroll
     for (int r = 0; r < SF_RJ; ++r) st.pf[d][r] = (sf_vec)(sf_t)0;
-    if (pd < p_end) {
 #pragma unroll
-      for (int r = 0; r < SF_RJ; ++r) st.pf[d][r] = sf_load_row(cx, pd, r);
-    }
+    for (int r = 0; r < SF_RJ; ++r) SF_LOAD_ROW_IF(pd < p_end, st.pf[d][r], pd, r);
   }
 #endif
 
@@ -679,13 +794,18 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   // the trip always runs three steps: up to two surplus steps past p_end
   // compute planes nobody stores (loads and stores are range-guarded), which
   // keeps the loop body free of control flow between the phases
-  for (int p = p_begin; p < p_last; p += 3) {
+  // (SF_RING4: four steps, up to three surplus ones)
+  for (int p = p_begin; p < p_last; p += SF_SLOTS) {
     sf_step<0>(st, lds_all + image, in, out, sc, cx, p, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
     sf_step<1>(st, lds_all + image, in, out, sc, cx, p + 1, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
     sf_step<2>(st, lds_all + image, in, out, sc, cx, p + 2, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
+#if SF_RING4
+    sf_step<3>(st, lds_all + image, in, out, sc, cx, p + 3, p_end SF_STAMP_PASS);
+    if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
+#endif
   }
 #if SF_STAMP
   if (cx.lane == 0) {
