@@ -559,10 +559,34 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
   return out;
 }
 
+// Values outside an option's range are the caller's mistake and are reported;
+// (a shape no kernel can serve is not: that group falls back to the generic kernel)
+static void validate_options(const sf_plan& pl) {
+  struct Range {
+    const char* key;
+    long long lo, hi;
+  };
+  static const Range ranges[] = {{"k1.pf2", 0, 2}, {"k1.rev", 0, 2},  {"k1.dpp", 0, 4},   {"k1.bio", 0, 1},
+                                 {"k1.ul", 0, 1},  {"k1.db", 0, 1},   {"k1.nt", 0, 3},    {"k1.auxpre", 0, 2},
+                                 {"graph", 0, 1}};
+  for (const Range& r : ranges) {
+    if (!pl.opt.kv.count(r.key)) continue;
+    const long long v = pl.opt.get(r.key, r.lo);
+    if (v < r.lo || v > r.hi)
+      throw Error(SF_ERR_INVALID, std::string("option ") + r.key + " must lie in [" + std::to_string(r.lo) + ", " +
+                                      std::to_string(r.hi) + "]");
+  }
+  if (pl.opt.kv.count("k1.vk") && pl.opt.get("k1.vk", 4) != 2 && pl.opt.get("k1.vk", 4) != 4)
+    throw Error(SF_ERR_INVALID, "k1.vk must be 2 or 4");
+  if (pl.opt.kv.count("k1.pfd") && pl.opt.get("k1.pfd", 1) != 1 && pl.opt.get("k1.pfd", 1) != 3)
+    throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
+}
+
 static void build_plan(sf_plan& pl) {
   const Program& P = pl.P;
   const int K = (int)P.kernels.size();
   pl.profile = pl.opt.get("profile", 0) != 0;
+  validate_options(pl);
 
   // slab of the stream dimension owned by this plan
   pl.n_local = P.n[0];

@@ -114,3 +114,31 @@ def test_planner_shapes_for_the_benchmark_configurations(tmp_path):
 
     c5 = _describe(tmp_path, programs.diffusion_advection_laplacian((512, 512, 512)))
     assert "1 launches" in c5 and "star T=3" in c5
+
+
+def test_memory_instruction_modes_compile_clean(tmp_path):
+    """Branch-free buffer loads/stores (k1.bio) and the four-slot input ring
+    (k1.pf2=2): the generated kernels compile for gfx950 without spills, and the
+    2-D and f64 defaults use them."""
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    import stencilflow_amd as sf
+
+    def plan_of(prog, options=None):
+        path = programs.write_program(prog, str(tmp_path / "p.json"))
+        return Plan(lower(sf.KernelChainGraph(path)), options=options)
+
+    for opts in ({"k1.bio": 1}, {"k1.pf2": 2}, {"k1.bio": 1, "k1.pf2": 2, "k1.ul": 1}):
+        with plan_of(programs.jacobi3d((64, 64, 128), 4), opts) as plan:
+            text, src = plan.describe(), plan.kernel_source(0)
+            assert "star T=2" in text and "spill 0 scratch 0" in text, text
+            assert "#define SF_BUFFER_IO %d" % opts.get("k1.bio", 0) in src
+            assert "#define SF_PREFETCH2 %d" % opts.get("k1.pf2", 1) in src
+    with plan_of(programs.jacobi2d((256, 512), 4)) as plan:
+        src = plan.kernel_source(0)
+        assert "#define SF_BUFFER_IO 1" in src and "#define SF_PREFETCH2 2" in src and "#define SF_REVERSE 0" in src
+    with plan_of(programs.diffusion_advection_laplacian((32, 64, 128))) as plan:
+        assert "#define SF_BUFFER_IO 1" in plan.kernel_source(0)
+    with pytest.raises(ValueError):
+        plan_of(programs.jacobi3d((64, 64, 128), 4), {"k1.pf2": 3})
+

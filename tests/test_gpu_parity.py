@@ -146,6 +146,13 @@ def test_jacobi3d_chain_random(tmp_path, shape, fuse):
     {"fuse": 1, "k1.pf2": 1, "k1.li": 5},
     {"fuse": 3, "k1.pf2": 1, "k1.spread": 0},
     {"fuse": 2, "k1.spread": 0, "k1.db": 0},
+    {"fuse": 2, "k1.bio": 1},
+    {"fuse": 2, "k1.bio": 1, "k1.pf2": 2},
+    {"fuse": 3, "k1.pf2": 2},
+    {"fuse": 1, "k1.bio": 1, "k1.pf2": 0, "k1.li": 5},
+    {"fuse": 2, "k1.bio": 1, "k1.rev": 1},
+    {"fuse": 2, "k1.bio": 1, "k1.rev": 2, "k1.pfd": 3},
+    {"fuse": 2, "k1.ul": 1, "k1.pf2": 2},
     {"generic_only": 1},
 ])
 def test_jacobi3d_tile_shapes(tmp_path, options):
@@ -157,6 +164,48 @@ def test_jacobi3d_tile_shapes(tmp_path, options):
     want = npo.run_reference(prog, {"a": x})["b3"]
     got, _ = _run_gpu(path, {"a": x}, options=options)
     assert np.array_equal(got["b3"], want)
+
+
+@pytest.mark.parametrize("shape", [(20, 33, 64), (6, 5, 520), (70, 3, 8), (9, 30, 512)])
+@pytest.mark.parametrize("options", [
+    {"fuse": 1, "k1.bio": 1},
+    {"fuse": 2, "k1.bio": 1, "k1.pf2": 2},
+    {"fuse": 3, "k1.bio": 1, "k1.pf2": 1},
+])
+def test_buffer_io_nonzero_boundary(tmp_path, shape, options):
+    """Branch-free buffer loads return 0 outside a plane; a boundary constant
+    other than +0 must still come out of the padding select (partial tiles,
+    k-tiled rows, planes outside the domain, surplus steps of the unrolled loop)."""
+    stages = 5
+    rng = np.random.default_rng(SEED + 11)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    prog = programs.jacobi3d(shape, stages, bc_value=-0.75)
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, {"a": x})["b%d" % (stages - 1)]
+    got, desc = _run_gpu(path, {"a": x}, options=options)
+    assert "star" in desc
+    assert np.array_equal(got["b%d" % (stages - 1)], want)
+
+
+@pytest.mark.parametrize("options", [
+    {"k1.rev": 1},
+    {"k1.bio": 0},
+    {"k1.bio": 0, "k1.pf2": 1},
+    {"k1.bio": 1, "k1.pf2": 0},
+    {"k1.rev": 2, "k1.pfd": 3},
+])
+def test_jacobi2d_step_orders(tmp_path, options):
+    """The 2-D kernel's other step orders and input schemes (the default is
+    stage-1-first with the four-slot input ring and buffer loads/stores)."""
+    shape, stages = (333, 264), 8
+    rng = np.random.default_rng(SEED + 12)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    prog = programs.jacobi2d(shape, stages, bc_value=0.5)
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, {"a": x})["b7"]
+    got, desc = _run_gpu(path, {"a": x}, options=options)
+    assert "star" in desc
+    assert np.array_equal(got["b7"], want)
 
 
 def test_integer_bc_literal_f32_accumulation(tmp_path):
