@@ -304,6 +304,10 @@ template <int S>
 __device__ __forceinline__ typename sf_stage<S>::aux_row sf_aux_row(const sf_ctx& cx, const int q, const int r) {
   const bool plane_ok = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G) && (q + cx.halo >= 0) &&
                         q >= cx.cb - (SF_T - S) && q < cx.ce + (SF_T - S);
+#if SF_BUFFER_IO
+  // never under a branch: a plane this stage does not evaluate has zero records
+  return sf_stage<S>::load_aux_bio(cx.aux, (long long)(q + cx.halo), plane_ok, cx.ld_off[r], SF_PLANE_BYTES);
+#endif
   return sf_stage<S>::load_aux(
       cx.aux, (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2) + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0),
       plane_ok && ((cx.jmask >> r) & 1u) && cx.kvec_in);

@@ -399,17 +399,18 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   // input planes: 0 = loaded into the window slot stage 1 has just freed, 1 = into
   // staging registers a step earlier and copied, 2 = four-slot input ring (two
   // steps to land, no copy; the step loop is unrolled by 4)
-  base.prefetch2 = base.reverse ? 0 : (int)pl.opt.get("k1.pf2", base.noj ? 2 : 1);
+  // (defaults: the ring for 2-D and f32 3-D -- C2 +10 %, C3 +1.7 %, hotspot chains
+  // +1 % with k1.bio; staging registers for f64, whose ring needs a smaller tile)
+  base.prefetch2 = base.reverse ? 0 : (int)pl.opt.get("k1.pf2", (base.noj || dt == DT::F32) ? 2 : 1);
   if (base.prefetch2 < 0 || base.prefetch2 > 2) throw Error(SF_ERR_INVALID, "k1.pf2 must be 0, 1 or 2");
   base.uniform_loads = (int)pl.opt.get("k1.ul", 0);
   // planes through buffer instructions (out-of-range offsets instead of branches
   // around loads and stores); a plane must stay well below the 2 GiB offset range
   const double plane_bytes = (double)P.n[1] * (double)P.n[2] * (double)size_of(dt);
   // Measured (profiles/r01_sweep_17_buffer_io.log): 2-D +10 % (with the step order
-  // and input ring above), f64 3-D +3.7 %, f32 3-D unchanged (default stays off)
-  base.buffer_io = plane_bytes <= 1024.0 * 1024 * 1024
-                       ? (int)pl.opt.get("k1.bio", (base.noj || dt == DT::F64) ? 1 : 0)
-                       : 0;
+  // and input ring above), f64 3-D +1..4 %, f32 3-D jacobi +1.7 % with the ring,
+  // f32 3-D chains with auxiliary fields (hotspot) +38 %
+  base.buffer_io = plane_bytes <= 1024.0 * 1024 * 1024 ? (int)pl.opt.get("k1.bio", 1) : 0;
   base.pfd = (int)pl.opt.get("k1.pfd", 1);
   if (base.pfd != 1 && base.pfd != 3) throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
   if ((base.prefetch2 != 1 && base.reverse != 2) || base.prefetch2 == 2) base.pfd = 1;

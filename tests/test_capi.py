@@ -128,12 +128,12 @@ def test_memory_instruction_modes_compile_clean(tmp_path):
         path = programs.write_program(prog, str(tmp_path / "p.json"))
         return Plan(lower(sf.KernelChainGraph(path)), options=options)
 
-    for opts in ({"k1.bio": 1}, {"k1.pf2": 2}, {"k1.bio": 1, "k1.pf2": 2, "k1.ul": 1}):
+    for opts in ({}, {"k1.bio": 0}, {"k1.pf2": 1}, {"k1.bio": 0, "k1.pf2": 0, "k1.ul": 1}):
         with plan_of(programs.jacobi3d((64, 64, 128), 4), opts) as plan:
             text, src = plan.describe(), plan.kernel_source(0)
             assert "star T=2" in text and "spill 0 scratch 0" in text, text
-            assert "#define SF_BUFFER_IO %d" % opts.get("k1.bio", 0) in src
-            assert "#define SF_PREFETCH2 %d" % opts.get("k1.pf2", 1) in src
+            assert "#define SF_BUFFER_IO %d" % opts.get("k1.bio", 1) in src
+            assert "#define SF_PREFETCH2 %d" % opts.get("k1.pf2", 2) in src
     with plan_of(programs.jacobi2d((256, 512), 4)) as plan:
         src = plan.kernel_source(0)
         assert "#define SF_BUFFER_IO 1" in src and "#define SF_PREFETCH2 2" in src and "#define SF_REVERSE 0" in src

@@ -153,6 +153,9 @@ def test_jacobi3d_chain_random(tmp_path, shape, fuse):
     {"fuse": 2, "k1.bio": 1, "k1.rev": 1},
     {"fuse": 2, "k1.bio": 1, "k1.rev": 2, "k1.pfd": 3},
     {"fuse": 2, "k1.ul": 1, "k1.pf2": 2},
+    {"fuse": 2, "k1.bio": 0},
+    {"fuse": 3, "k1.bio": 0, "k1.pf2": 1},
+    {"fuse": 2, "k1.bio": 0, "k1.pf2": 0, "k1.ul": 1},
     {"generic_only": 1},
 ])
 def test_jacobi3d_tile_shapes(tmp_path, options):

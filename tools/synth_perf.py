@@ -2,7 +2,7 @@
 """GPU: throughput of programs from the workload generator (the reference's
 bin/synthesize.py conventions: integer boundary literals -> float32 sums,
 coefficient 1/n, optional extra fields) at benchmark size.
-usage: synth_perf.py [--size 512] [--stages 16]"""
+usage: synth_perf.py [--size 512] [--stages 16] [--only hotspot] [--opts "k1.bio=1"]"""
 import argparse
 import json
 import os
@@ -22,6 +22,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--stages", type=int, default=16)
+    ap.add_argument("--only", default="", help="run the cases whose label contains this text")
+    ap.add_argument("--opts", default="", help="plan options, e.g. k1.bio=1;k1.pf2=2")
     args = ap.parse_args()
     n, st = args.size, args.stages
     cases = [
@@ -37,10 +39,12 @@ def main():
     rng = np.random.default_rng(5)
     with tempfile.TemporaryDirectory() as tmp:
         for label, pos, kw in cases:
+            if args.only and args.only not in label:
+                continue
             prog, _ = programs.synthesize(*pos, **kw)
             path = programs.write_program(prog, os.path.join(tmp, "p.json"))
             chain = sf.KernelChainGraph(path)
-            plan = Plan(lower(chain))
+            plan = Plan(lower(chain), options=args.opts or None)
             if plan.scalar_names:
                 plan.set_scalars([0.1] * len(plan.scalar_names))
             shape = prog["dimensions"]
@@ -59,7 +63,7 @@ def main():
             cells = float(np.prod(shape)) * ops
             bpu = 8.0 if dtype == np.float32 else 16.0
             kinds = plan.describe().count("[star"), plan.describe().count("[point]")
-            print(json.dumps({"case": label, "dims": shape, "operators": ops, "launches": plan.num_launches,
+            print(json.dumps({"case": label, "opts": args.opts, "dims": shape, "operators": ops, "launches": plan.num_launches,
                               "star/point launches": kinds, "ms": round(ms, 3),
                               "Mcells/s": round(cells / ms / 1e3), "frac_8TB": round(cells * bpu / (ms * 1e-3) / 8e12, 3),
                               "first": plan.describe().splitlines()[1].strip()[:110]}), flush=True)
