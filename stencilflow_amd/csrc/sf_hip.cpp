@@ -12,6 +12,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -810,7 +811,8 @@ static void build_plan(sf_plan& pl) {
       const bool nts = pl.opt.get("generic.nt", out_bytes >= 256.0 * 1024 * 1024 ? 1 : 0) != 0;
       const int ppt = (int)std::max<long long>(1, std::min<long long>(8, pl.opt.get("generic.ppt", 1)));
       GenericKernelSource g =
-          vec ? gen_generic_vec(P, st.kernels[0], xcd, nts, ppt, pl.opt.get("generic.fast", 0) != 0)
+          vec ? gen_generic_vec(P, st.kernels[0], xcd, nts, ppt, pl.opt.get("generic.fast", 0) != 0,
+                                pl.opt.get("generic.bio", 0) != 0)
               : gen_generic(P, st.kernels[0], xcd, nts);
       st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
       if (vec) {
@@ -1147,7 +1149,14 @@ int sf_plan_create(const char* sfir_text, int device, const char* options, sf_pl
   if (!sfir_text || !out_plan) throw Error(SF_ERR_INVALID, "null argument");
   std::unique_ptr<sf_plan> pl(new sf_plan);
   pl->P = parse_sfir(sfir_text);
-  pl->opt = Options(options);
+  // SF_HIP_OPTIONS (same syntax) supplies site-wide defaults; the caller's options
+  // take precedence key by key
+  {
+    const char* env = std::getenv("SF_HIP_OPTIONS");
+    pl->opt = Options(env && *env ? env : nullptr);
+    const Options own(options);
+    for (auto& kv : own.kv) pl->opt.kv[kv.first] = kv.second;
+  }
   pl->device = device;
   build_plan(*pl);
   *out_plan = pl.release();

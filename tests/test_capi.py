@@ -142,3 +142,21 @@ def test_memory_instruction_modes_compile_clean(tmp_path):
     with pytest.raises(ValueError):
         plan_of(programs.jacobi3d((64, 64, 128), 4), {"k1.pf2": 3})
 
+
+def test_environment_options_and_generic_buffer_loads(tmp_path, monkeypatch):
+    """SF_HIP_OPTIONS supplies defaults that the caller's options override key by
+    key; generic.bio=1 turns the generic kernel's guarded loads into buffer loads."""
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    import stencilflow_amd as sf
+    path = programs.write_program(programs.jacobi3d((16, 32, 64), 2), str(tmp_path / "p.json"))
+    sfir = lower(sf.KernelChainGraph(path))
+    monkeypatch.setenv("SF_HIP_OPTIONS", "generic_only=1;generic.bio=1")
+    with Plan(sfir) as plan:
+        assert "[point]" in plan.describe()
+        assert "raw_buffer_load_b128" in plan.kernel_source(0)
+    with Plan(sfir, options={"generic_only": 0}) as plan:
+        assert "[star" in plan.describe()
+    monkeypatch.delenv("SF_HIP_OPTIONS")
+    with Plan(sfir, options={"generic_only": 1}) as plan:
+        assert "[point]" in plan.describe()
