@@ -174,26 +174,53 @@ def main():
         import datetime
         from stencilflow_amd.distributed import SlabRunner, TorchDistExchanger
         import torch.distributed as dist
-        # gloo is the control plane (barriers, the max over ranks) and the spare
-        # halo transport; the halos themselves travel over RCCL (backend "nccl")
-        # if a handshake with both neighbours succeeds on EVERY rank.
+        # gloo is the control plane (barriers, the max over ranks) and the last
+        # resort; the halos travel over RCCL (backend "nccl") if a handshake with
+        # both neighbours succeeds on EVERY rank, else through pinned host memory
+        # shared by the ranks (ShmExchanger: DMA copies, flags raised and awaited
+        # by the streams), else through gloo.  SF_BENCH_TRANSPORT=rccl|shm|gloo
+        # starts the ladder at that rung (tests).
+        from stencilflow_amd.distributed import ShmExchanger
         dist.init_process_group("gloo")
-        ok, why = 1, ""
-        try:
-            rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
-            exchanger = TorchDistExchanger(rank, world, group=rccl, staging="device")
-            exchanger.handshake(torch.device("cuda", local_rank))
-        except Exception as exc:  # noqa: BLE001 -- any transport failure selects the spare
-            ok, why = 0, "{}: {}".format(type(exc).__name__, str(exc).splitlines()[0][:120] if str(exc) else "")
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            transport = "RCCL send/recv on device buffers"
-        else:
-            exchanger = TorchDistExchanger(rank, world, staging="host")
-            exchanger.handshake()
-            transport = "gloo through pinned host buffers (RCCL handshake failed on some rank{})".format(
-                ": " + why if why else "")
+        first = os.environ.get("SF_BENCH_TRANSPORT", "rccl")
+        ladder = ["rccl", "shm", "gloo"]
+        ladder = ladder[ladder.index(first):] if first in ladder else ladder
+        session = [None]
+        if rank == 0:
+            session[0] = "{}_{}".format(os.getpid(), int(time.time() * 1e3) & 0xffffff)
+        dist.broadcast_object_list(session, src=0)
+        exchanger, transport, why = None, None, []
+        for rung in ladder:
+            ok, msg, candidate = 1, "", None
+            try:
+                if rung == "rccl":
+                    rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+                    candidate = TorchDistExchanger(rank, world, group=rccl, staging="device")
+                    candidate.handshake(torch.device("cuda", local_rank))
+                elif rung == "shm":
+                    candidate = ShmExchanger(rank, world, session[0], device=local_rank)
+                    candidate.handshake()
+                else:
+                    candidate = TorchDistExchanger(rank, world, staging="host")
+                    candidate.handshake()
+            except Exception as exc:  # noqa: BLE001 -- any transport failure selects the next rung
+                ok = 0
+                msg = "{}: {}".format(type(exc).__name__, str(exc).splitlines()[0][:120] if str(exc) else "")
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                exchanger = candidate
+                transport = {"rccl": "RCCL send/recv on device buffers",
+                             "shm": "pinned host memory shared by the ranks, stream-ordered flags",
+                             "gloo": "gloo through pinned host buffers"}[rung]
+                break
+            why.append("{} handshake failed on some rank{}".format(rung, ": " + msg if msg else ""))
+            if candidate is not None and hasattr(candidate, "close"):
+                candidate.close()
+        if exchanger is None:
+            raise SystemExit("no halo transport works: " + "; ".join(why))
+        if why:
+            transport += " (" + "; ".join(why) + ")"
         runner = SlabRunner(sfir, shape, rank, world, device=local_rank,
                             options=options, exchanger=exchanger)
         runner.upload([synthetic(runner.local_shape, rank)])
@@ -203,6 +230,8 @@ def main():
 
         def sync():
             runner.synchronize()
+            if hasattr(exchanger, "check"):
+                exchanger.check()  # a halo wait that timed out must not pass for a result
             dist.barrier()
     else:
         plan = Plan(sfir, device=local_rank, options=options)

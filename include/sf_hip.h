@@ -160,6 +160,32 @@ int sf_plan_buffer_info(const sf_plan* plan, int buffer_id, void** device_ptr,
 int sf_plan_input_buffer(const sf_plan* plan, int index);
 int sf_plan_output_buffer(const sf_plan* plan, int index);
 
+/* ---- halo transport through host memory shared by the ranks of one node ----
+ * The primitives of the spare transport of the slab decomposition (used when
+ * RCCL cannot connect the ranks): a rank copies the planes it sends into a
+ * pinned buffer that its neighbour has mapped too (POSIX shared memory), raises
+ * a flag word in that buffer from its stream, and the neighbour's stream waits
+ * for the flag before copying the planes into its ghost planes.  Everything is
+ * stream-ordered on both sides; no host thread takes part after enqueueing.
+ * (The reference moves data between devices with SMI streams and MPI barriers,
+ * stencilflow/sdfg_generator.py:782-1000, bin/run_distributed_program.py:283-299.) */
+/* Pin `bytes` of host memory at `ptr` (e.g. an mmap of /dev/shm) for device
+ * access / undo it.  *device_ptr receives the address kernels must use for the
+ * range (flag words); copies take either address. */
+int sf_host_register(void* ptr, size_t bytes, void** device_ptr);
+int sf_host_unregister(void* ptr);
+/* dst <- src on `stream` (either side may be pinned host or device memory). */
+int sf_copy_async(void* dst, const void* src, size_t bytes, void* stream);
+/* Store `value` to the flag word (system scope) once everything enqueued on
+ * `stream` before it has completed. */
+int sf_flag_set(void* stream, unsigned int* flag, unsigned int value);
+/* Hold `stream` until the flag word has reached `value` (counting comparison:
+ * *flag - value >= 0 as a signed difference).  After `timeout_ms` the wait gives
+ * up, stores 1 to *status (pinned host or device memory, may be NULL) and lets
+ * the stream continue: a waiting kernel always terminates. */
+int sf_flag_wait(void* stream, const unsigned int* flag, unsigned int value,
+                 unsigned int timeout_ms, unsigned int* status);
+
 #ifdef __cplusplus
 }
 #endif

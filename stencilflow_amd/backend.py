@@ -78,6 +78,11 @@ API = [
      [_P, _I, _PP, ctypes.POINTER(ctypes.c_size_t), _IP]),
     ("sf_plan_input_buffer", _I, [_P, _I]),
     ("sf_plan_output_buffer", _I, [_P, _I]),
+    ("sf_host_register", _I, [_P, _Z, _PP]),
+    ("sf_host_unregister", _I, [_P]),
+    ("sf_copy_async", _I, [_P, _P, _Z, _P]),
+    ("sf_flag_set", _I, [_P, _P, ctypes.c_uint]),
+    ("sf_flag_wait", _I, [_P, _P, ctypes.c_uint, ctypes.c_uint, _P]),
 ]
 
 

@@ -1386,3 +1386,79 @@ int sf_plan_output_buffer(const sf_plan* p, int i) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- flag kernels
+// One lane each.  The flag lives in pinned host memory that several processes
+// have mapped: system-scope atomics, so that neither side's caches hold it.
+static __global__ void sf_flag_set_kernel(unsigned int* flag, unsigned int value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static __global__ void sf_flag_wait_kernel(const unsigned int* flag, unsigned int value,
+                                           unsigned long long timeout_ticks, unsigned int* status) {
+  const unsigned long long t0 = wall_clock64();  // constant-rate counter (100 MHz)
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
+    __builtin_amdgcn_s_sleep(64);
+    if (wall_clock64() - t0 > timeout_ticks) {  // never spin forever
+      if (status) __hip_atomic_store(status, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+}
+
+extern "C" {
+
+int sf_host_register(void* ptr, size_t bytes, void** device_ptr) {
+  SF_API_BEGIN
+  if (!ptr || bytes == 0) throw sf::Error(SF_ERR_INVALID, "sf_host_register: null range");
+  SF_HIP_CHECK(hipHostRegister(ptr, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+  if (device_ptr) {
+    void* dev = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dev, ptr, 0);
+    if (e != hipSuccess) {
+      (void)hipHostUnregister(ptr);
+      throw sf::Error(SF_ERR_DEVICE, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+    }
+    *device_ptr = dev;
+  }
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_host_unregister(void* ptr) {
+  SF_API_BEGIN
+  if (!ptr) return SF_OK;
+  SF_HIP_CHECK(hipHostUnregister(ptr));
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_copy_async(void* dst, const void* src, size_t bytes, void* stream) {
+  SF_API_BEGIN
+  if ((!dst || !src) && bytes) throw sf::Error(SF_ERR_INVALID, "sf_copy_async: null pointer");
+  if (bytes) SF_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, (hipStream_t)stream));
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_flag_set(void* stream, unsigned int* flag, unsigned int value) {
+  SF_API_BEGIN
+  if (!flag) throw sf::Error(SF_ERR_INVALID, "sf_flag_set: null flag");
+  hipLaunchKernelGGL(sf_flag_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, value);
+  SF_HIP_CHECK(hipGetLastError());
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_flag_wait(void* stream, const unsigned int* flag, unsigned int value, unsigned int timeout_ms,
+                 unsigned int* status) {
+  SF_API_BEGIN
+  if (!flag) throw sf::Error(SF_ERR_INVALID, "sf_flag_wait: null flag");
+  const unsigned long long ticks = (unsigned long long)std::max(1u, timeout_ms) * 100000ull;
+  hipLaunchKernelGGL(sf_flag_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, value, ticks, status);
+  SF_HIP_CHECK(hipGetLastError());
+  return SF_OK;
+  SF_API_END
+}
+
+}  // extern "C"

@@ -22,6 +22,9 @@ is delegated to an *exchanger*:
 * ``TorchDistExchanger(staging="host")``   -- the same protocol staged through
   host memory (works with ``gloo``; used to test the multi-rank path on a
   single GPU and on CPU tensors);
+* ``ShmExchanger`` -- pinned host memory shared by the ranks of the node, flags
+  raised and awaited by the streams themselves (spare transport of ``bench.py``;
+  works with all ranks on one GPU, which is how it is tested);
 * ``LocalExchanger`` -- ranks living in one process (tests).
 """
 
@@ -166,6 +169,214 @@ class TorchDistExchanger:
             if self.rank + 1 < self.world:
                 off, size = regions["recv_up"]
                 tensor[off:off + size].copy_(stage["recv_up"])
+
+
+class ShmExchanger:
+    """Neighbour exchange through pinned host memory shared by the ranks of one
+    node -- the spare transport when RCCL cannot connect them, and the one that
+    can be exercised with several ranks on a single GPU.
+
+    Every rank owns an *outbox* per exchanged buffer (a POSIX shared-memory file
+    that both neighbours map and pin): two slots per direction and a page of
+    flag words.  Exchange number ``n`` of a buffer uses slot ``n % 2``:
+
+    sender    wait ``ack[dir][slot] >= n - 2`` (the neighbour is done with the
+              slot's previous content), copy the planes device -> slot, raise
+              ``ready[dir][slot] = n``;
+    receiver  wait ``ready[dir][slot] >= n`` in the neighbour's outbox, copy slot ->
+              ghost planes, raise ``ack[dir][slot] = n`` there.
+
+    All of it is enqueued on a communication stream of the rank (copies by DMA,
+    flags by one-lane kernels, ``sf_flag_set`` / ``sf_flag_wait`` of the C ABI);
+    the compute stream only waits for that stream's event in ``finish``.  Over
+    PCIe 5 the 2 x 8 MiB of a C4 exchange take ~0.4 ms per direction pair and hide
+    behind the three launches that need no halo.  A wait gives up after
+    ``timeout_ms`` and marks the rank's status word; ``check`` raises then.
+    """
+
+    reserved_cus = 0  # copies run on the DMA engines
+    FLAG_BYTES = 4096
+    # flag word index: ready[dir][slot] = dir * 2 + slot, ack[dir][slot] = 4 + dir * 2 + slot,
+    # status = 8   (dir 0 = towards the lower neighbour, 1 = towards the upper)
+
+    def __init__(self, rank, world, session, device=0, timeout_ms=20000, barrier=None):
+        import ctypes
+        import torch
+        from .backend import load_library
+        self.rank, self.world = rank, world
+        self.session, self.device = str(session), device
+        self.timeout_ms = int(timeout_ms)
+        self._barrier = barrier
+        self._lib = load_library()
+        self._ct = ctypes
+        self._torch = torch
+        self._boxes = {}   # key -> dict(own=..., lower=..., upper=..., count=0, slot_bytes=...)
+        self._stream = self._recv_stream = None
+        self._closed = False
+
+    # ------------------------------------------------------------ plumbing
+    def _check(self, status):
+        if status != 0:
+            raise RuntimeError("shared-memory halo transport: " +
+                               (self._lib.sf_last_error() or b"").decode())
+
+    def _path(self, key, rank):
+        return "/dev/shm/sf_halo_{}_{}_{}".format(self.session, key, rank)
+
+    def _map(self, path, size, create):
+        import mmap
+        import os
+        fd = os.open(path, os.O_RDWR | (os.O_CREAT | os.O_EXCL if create else 0), 0o600)
+        try:
+            if create:
+                os.ftruncate(fd, size)
+            mm = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
+        addr = self._ct.addressof(self._ct.c_char.from_buffer(mm))
+        dev = self._ct.c_void_p()
+        self._check(self._lib.sf_host_register(self._ct.c_void_p(addr), size, self._ct.byref(dev)))
+        # `addr`: host address (copies, unregistering); `dev`: what kernels dereference (flags)
+        return {"mm": mm, "addr": addr, "dev": dev.value or addr, "size": size}
+
+    def _sync_ranks(self):
+        if self._barrier is not None:
+            self._barrier()
+        else:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def _open(self, key, slot_bytes):
+        """Create this rank's outbox for `key`, then map both neighbours' (collective)."""
+        import os
+        slot = (int(slot_bytes) + 4095) // 4096 * 4096
+        size = self.FLAG_BYTES + 4 * slot
+        with self._torch.cuda.device(self.device):
+            own = self._map(self._path(key, self.rank), size, create=True)
+            self._sync_ranks()
+            box = {"own": own, "slot": slot, "count": 0, "lower": None, "upper": None}
+            if self.rank > 0:
+                box["lower"] = self._map(self._path(key, self.rank - 1), size, create=False)
+            if self.rank < self.world - 1:
+                box["upper"] = self._map(self._path(key, self.rank + 1), size, create=False)
+            self._sync_ranks()
+        os.unlink(self._path(key, self.rank))  # the mappings keep the memory alive
+        self._boxes[key] = box
+        return box
+
+    @staticmethod
+    def _flag(box_part, index):
+        return box_part["dev"] + 4 * index
+
+    def _slot(self, box, part, direction, slot):
+        return part["addr"] + self.FLAG_BYTES + (direction * 2 + slot) * box["slot"]
+
+    # ------------------------------------------------------------ protocol
+    def handshake(self, device=None):
+        """One small exchange with both neighbours; every rank checks what arrived."""
+        torch = self._torch
+        if self.world == 1:
+            return
+        dev = torch.device("cuda", self.device)
+        n_local, plane = 4, 256
+        buf = torch.zeros((n_local + 2) * plane, dtype=torch.uint8, device=dev)
+        buf[plane:(n_local + 1) * plane] = self.rank + 1
+        regions = halo_regions(n_local, 1, 1, plane)
+        for _ in range(3):  # both slots and the first reuse of one
+            self.finish(self.start(buf, regions, key="handshake"))
+        torch.cuda.synchronize(dev)
+        self.check()
+        lo, hi = int(buf[0]), int(buf[-1])
+        if lo != (self.rank if self.rank > 0 else 0):
+            raise RuntimeError("shared-memory halo transport handshake: wrong data from the lower neighbour")
+        if hi != (self.rank + 2 if self.rank < self.world - 1 else 0):
+            raise RuntimeError("shared-memory halo transport handshake: wrong data from the upper neighbour")
+
+    def start(self, tensor, regions, key=None):
+        torch, ct, lib = self._torch, self._ct, self._lib
+        if self.world == 1:
+            return None
+        size = max(regions["send_down"][1], regions["send_up"][1])
+        box = self._boxes.get(key)
+        if box is None:
+            box = self._open(key, size)
+        elif size > box["slot"]:
+            raise ValueError("halo of {} bytes exceeds the outbox slot of buffer {!r}".format(size, key))
+        if self._stream is None:
+            # sends (device -> host) and receives (host -> device) on streams of their
+            # own: PCIe moves both directions at once
+            self._stream = torch.cuda.Stream(device=self.device)
+            self._recv_stream = torch.cuda.Stream(device=self.device)
+        box["count"] += 1
+        n, slot = box["count"], box["count"] % 2
+        comm, comm_in = self._stream, self._recv_stream
+        now = torch.cuda.current_stream(self.device)
+        comm.wait_stream(now)  # the planes to send are final
+        comm_in.wait_stream(now)  # the ghost planes are no longer read
+        raw = ct.c_void_p(comm.cuda_stream)
+        base = tensor.data_ptr()
+        status = ct.c_void_p(self._flag(box["own"], 8))
+        peers = ((0, box["lower"], "send_down", "recv_down"), (1, box["upper"], "send_up", "recv_up"))
+        # sends first: a rank never holds its own sends behind a wait for data
+        for direction, peer, send, _ in peers:
+            if peer is None:
+                continue
+            off, nbytes = regions[send]
+            if n > 2:
+                self._check(lib.sf_flag_wait(raw, ct.c_void_p(self._flag(box["own"], 4 + direction * 2 + slot)),
+                                             n - 2, self.timeout_ms, status))
+            self._check(lib.sf_copy_async(ct.c_void_p(self._slot(box, box["own"], direction, slot)),
+                                          ct.c_void_p(base + off), nbytes, raw))
+            self._check(lib.sf_flag_set(raw, ct.c_void_p(self._flag(box["own"], direction * 2 + slot)), n))
+        raw = ct.c_void_p(comm_in.cuda_stream)
+        for direction, peer, _, recv in peers:
+            if peer is None:
+                continue
+            off, nbytes = regions[recv]
+            # the neighbour's outbox towards us: its direction is the opposite one
+            their = 1 - direction
+            self._check(lib.sf_flag_wait(raw, ct.c_void_p(self._flag(peer, their * 2 + slot)), n,
+                                         self.timeout_ms, status))
+            self._check(lib.sf_copy_async(ct.c_void_p(base + off),
+                                          ct.c_void_p(self._slot(box, peer, their, slot)), nbytes, raw))
+            self._check(lib.sf_flag_set(raw, ct.c_void_p(self._flag(peer, 4 + their * 2 + slot)), n))
+        done = (torch.cuda.Event(), torch.cuda.Event())
+        done[0].record(comm)
+        done[1].record(comm_in)
+        return done
+
+    def finish(self, handle):
+        if handle is not None:
+            now = self._torch.cuda.current_stream(self.device)
+            now.wait_event(handle[0])
+            now.wait_event(handle[1])
+
+    def check(self):
+        """Raise if a wait of this rank has timed out (call after synchronising)."""
+        import struct
+        for key, box in self._boxes.items():
+            (status, ) = struct.unpack_from("I", box["own"]["mm"], 4 * 8)
+            if status:
+                raise RuntimeError("shared-memory halo transport: a neighbour of rank {} did not "
+                                   "answer within {} ms (buffer {!r})".format(self.rank, self.timeout_ms, key))
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        try:
+            self._torch.cuda.synchronize(self.device)
+        except Exception:  # noqa: BLE001 -- shutting down
+            pass
+        for box in self._boxes.values():
+            for part in (box["own"], box["lower"], box["upper"]):
+                if part is None:
+                    continue
+                try:
+                    self._lib.sf_host_unregister(self._ct.c_void_p(part["addr"]))
+                except Exception:  # noqa: BLE001
+                    pass
+        self._boxes = {}
 
 
 class LocalExchanger:

@@ -123,29 +123,34 @@ def test_decomposed_chain_protocol_gloo(tmp_path, world, fuse):
     _spawn(_chain_worker, world, (18, 6, 8), 5, fuse, str(tmp_path))
 
 
-def _gpu_worker(rank, world, port, shape, stages, overlap, groups):
+def _gpu_worker(rank, world, port, shape, stages, overlap, groups, transport="gloo"):
     import torch
     sys.path.insert(0, ROOT)
     import stencilflow_amd as sf
     from oracle import numpy_oracle as npo
     from stencilflow_amd import programs
-    from stencilflow_amd.distributed import SlabRunner, TorchDistExchanger
+    from stencilflow_amd.distributed import ShmExchanger, SlabRunner, TorchDistExchanger
     from stencilflow_amd.lowering import lower
     import tempfile
     _init(rank, world, port)
+    if transport == "shm":
+        exchanger = ShmExchanger(rank, world, "t{}".format(port), device=0)
+        exchanger.handshake()
+    else:
+        exchanger = TorchDistExchanger(rank, world, staging="host")
     rng = np.random.default_rng(11)
     x = rng.uniform(-1, 1, shape).astype(np.float32)
     prog = programs.jacobi3d(shape, stages, bc_value=0.25)
     with tempfile.TemporaryDirectory() as tmp:
         path = programs.write_program(prog, os.path.join(tmp, "p.json"))
         sfir = lower(sf.KernelChainGraph(path))
-    runner = SlabRunner(sfir, shape, rank, world, device=0,
-                        exchanger=TorchDistExchanger(rank, world,
-                                                     staging="host"),
+    runner = SlabRunner(sfir, shape, rank, world, device=0, exchanger=exchanger,
                         overlap=overlap, groups_per_exchange=groups)
     runner.upload([x[runner.lo:runner.hi]])
     runner.execute()
     runner.synchronize()
+    if transport == "shm":
+        exchanger.check()
     out = np.zeros(runner.local_shape, np.float32)
     runner.download([out])
     want = npo.run_reference(prog, {"a": x})["b%d" % (stages - 1)]
@@ -163,6 +168,15 @@ def test_two_processes_one_gpu_host_staged(overlap, groups):
     _spawn(_gpu_worker, 2, (36, 20, 64), 9, overlap, groups)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,overlap,groups", [(2, True, 4), (3, True, 4), (3, False, 2), (2, True, 1)])
+def test_processes_on_one_gpu_shared_memory_transport(world, overlap, groups):
+    """The spare transport of bench.py: halos through pinned host memory that the
+    ranks share, flags raised and awaited by the streams (ShmExchanger); one of
+    three ranks has two neighbours.  Results bit for bit against the oracle."""
+    _spawn(_gpu_worker, world, (48, 20, 64), 19, overlap, groups, "shm")
+
+
 def _handshake_worker(rank, world, port):
     dist = _init(rank, world, port)
     from stencilflow_amd.distributed import TorchDistExchanger
@@ -178,15 +192,18 @@ def test_transport_handshake_gloo(world):
 
 
 @pytest.mark.gpu
-def test_bench_three_ranks_on_one_gpu_falls_back_to_gloo():
+@pytest.mark.parametrize("first,expect", [("rccl", "shared by the ranks"), ("gloo", "gloo")])
+def test_bench_three_ranks_on_one_gpu_falls_back(first, expect):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one
     rank per process), with all ranks (one of them with two neighbours) pointed
     at this box's only GPU: the RCCL handshake cannot succeed there (several
     ranks, one device), so the run must
-    select the spare transport on every rank and still print its JSON line."""
+    select the spare transport (shared host memory) on every rank and still print
+    its JSON line; started at its last rung, the ladder uses gloo."""
     import json
     import subprocess
-    env = dict(os.environ, SF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, SF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               SF_BENCH_TRANSPORT=first)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
@@ -198,5 +215,5 @@ def test_bench_three_ranks_on_one_gpu_falls_back_to_gloo():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 3 and rec["steps"] == 2 and rec["value"] > 0
     assert rec["scaling"] == "weak" and "slab3" in rec["config"]["decomposition"]
-    assert "gloo" in rec["config"]["decomposition"]
+    assert expect in rec["config"]["decomposition"], rec["config"]["decomposition"]
     assert "192x64x64" in rec["config"]["workload"]
