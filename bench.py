@@ -221,8 +221,11 @@ def main():
             raise SystemExit("no halo transport works: " + "; ".join(why))
         if why:
             transport += " (" + "; ".join(why) + ")"
+        # the host-memory transport needs about two interior launches to hide an
+        # exchange: it is started a launch ahead (tools/slab_overhead.py: +4 %)
         runner = SlabRunner(sfir, shape, rank, world, device=local_rank,
-                            options=options, exchanger=exchanger)
+                            options=options, exchanger=exchanger,
+                            early_exchange=isinstance(exchanger, ShmExchanger))
         runner.upload([synthetic(runner.local_shape, rank)])
 
         def step():

@@ -442,7 +442,7 @@ class SlabRunner:
 
     def __init__(self, sfir_text, global_shape, rank, world, device=0,
                  options=None, exchanger=None, halo=None, overlap=True,
-                 groups_per_exchange=4):
+                 groups_per_exchange=4, early_exchange=False):
         import torch
         self.torch = torch
         self.rank, self.world, self.device = rank, world, device
@@ -508,6 +508,8 @@ class SlabRunner:
         self.is_chain = all(len(i) == 1 for i in self.inputs) and all(
             self.inputs[s][0] == self.outputs[s - 1] for s in range(1, n))
         self._valid = 0
+        self._early = None  # (step, handles) of an exchange started a launch ahead
+        self.early_exchange = bool(early_exchange)
 
     def _buffer_tensor(self, buf):
         if buf not in self._tensors:
@@ -541,6 +543,7 @@ class SlabRunner:
         _, d = self.steps[s]
         if s == 0:
             self._valid = 0
+            self._early = None
         with torch.cuda.stream(self.stream):
             if self.world == 1:
                 self.plan.execute_step(s, 0, raw)
@@ -548,39 +551,63 @@ class SlabRunner:
             if self.is_chain and d <= self._valid:
                 # deep halo still good: recompute the ghost planes that remain
                 ext = self._valid - d
-                self.plan.execute_step_ranges(
-                    s, -ext if self.has_lower else 0,
-                    n + (ext if self.has_upper else 0), stream=raw)
+                lo_ext = ext if self.has_lower else 0
+                hi_ext = ext if self.has_upper else 0
+                nxt = s + 1
+                if (self.early_exchange and self.overlap and nxt < len(self.steps)
+                        and self.steps[nxt][1] > ext and n >= 2 * H):
+                    # The NEXT launch needs fresh halos.  What it will send are this
+                    # launch's planes next to the slab boundaries: compute those first
+                    # (one two-range launch), start the exchange, and let it run beside
+                    # the interior of this launch AND the interior of the next one --
+                    # two launches (~0.4 ms on C4) instead of one to hide the transfer.
+                    lo_cut = H if self.has_lower else 0
+                    hi_cut = n - H if self.has_upper else n
+                    self.plan.execute_step_ranges(s, -lo_ext, lo_cut, hi_cut, n + hi_ext, stream=raw)
+                    buf = self.inputs[nxt][0]
+                    tensor, plane_bytes, _ = self._buffer_tensor(buf)
+                    self._early = (nxt, [self.exchanger.start(tensor, halo_regions(n, H, H, plane_bytes),
+                                                              key=buf)])
+                    self._launch_beside_exchange(s, lo_cut, hi_cut, raw)
+                    self._valid = ext
+                    return None
+                self.plan.execute_step_ranges(s, -lo_ext, n + hi_ext, stream=raw)
                 self._valid = ext
                 return None
             if d == 0:
                 self.plan.execute_step(s, 0, raw)
                 return None
             depth = H if self.is_chain else d
-            handles = []
-            for buf in (self._slabbed_inputs(s) if not self.is_chain
-                        else [self.inputs[s][0]]):
-                tensor, plane_bytes, _ = self._buffer_tensor(buf)
-                regions = halo_regions(n, H, depth, plane_bytes)
-                # the transfer waits for everything queued so far (the planes it
-                # sends were produced by the previous launch) ...
-                handles.append(self.exchanger.start(tensor, regions, key=buf))
+            if self._early is not None and self._early[0] == s:
+                handles, self._early = self._early[1], None  # started beside the previous launch
+            else:
+                handles = []
+                for buf in (self._slabbed_inputs(s) if not self.is_chain
+                            else [self.inputs[s][0]]):
+                    tensor, plane_bytes, _ = self._buffer_tensor(buf)
+                    regions = halo_regions(n, H, depth, plane_bytes)
+                    # the transfer waits for everything queued so far (the planes it
+                    # sends were produced by the previous launch) ...
+                    handles.append(self.exchanger.start(tensor, regions, key=buf))
             if self.overlap:
-                # ... and runs beside the interior of this launch, which leaves a
-                # few compute units to the exchange's copy kernels: its blocks
-                # run ~200 us and hold nearly all registers of their unit, so a
-                # copy kernel would otherwise queue behind them
-                reserve = getattr(self.exchanger, "reserved_cus", 0)
-                if reserve:
-                    self.plan.set_reserved_cus(reserve)
-                try:
-                    self.plan.execute_step_ranges(
-                        s, d if self.has_lower else 0,
-                        n - (d if self.has_upper else 0), stream=raw)
-                finally:
-                    if reserve:
-                        self.plan.set_reserved_cus(0)
+                # ... and runs beside the interior of this launch
+                self._launch_beside_exchange(s, d if self.has_lower else 0,
+                                             n - (d if self.has_upper else 0), raw)
             return (handles, depth)
+
+    def _launch_beside_exchange(self, s, i_begin, i_end, raw):
+        """Launch planes [i_begin, i_end) of step ``s`` while a halo exchange is in
+        flight: the launch leaves a few compute units to the exchange's copy
+        kernels -- its blocks run ~200 us and hold nearly all registers of their
+        unit, so a copy kernel would otherwise queue behind them."""
+        reserve = getattr(self.exchanger, "reserved_cus", 0)
+        if reserve:
+            self.plan.set_reserved_cus(reserve)
+        try:
+            self.plan.execute_step_ranges(s, i_begin, i_end, stream=raw)
+        finally:
+            if reserve:
+                self.plan.set_reserved_cus(0)
 
     def step_end(self, s, handle):
         if handle is None:

@@ -123,7 +123,7 @@ def test_decomposed_chain_protocol_gloo(tmp_path, world, fuse):
     _spawn(_chain_worker, world, (18, 6, 8), 5, fuse, str(tmp_path))
 
 
-def _gpu_worker(rank, world, port, shape, stages, overlap, groups, transport="gloo"):
+def _gpu_worker(rank, world, port, shape, stages, overlap, groups, transport="gloo", early=False):
     import torch
     sys.path.insert(0, ROOT)
     import stencilflow_amd as sf
@@ -145,7 +145,7 @@ def _gpu_worker(rank, world, port, shape, stages, overlap, groups, transport="gl
         path = programs.write_program(prog, os.path.join(tmp, "p.json"))
         sfir = lower(sf.KernelChainGraph(path))
     runner = SlabRunner(sfir, shape, rank, world, device=0, exchanger=exchanger,
-                        overlap=overlap, groups_per_exchange=groups)
+                        overlap=overlap, groups_per_exchange=groups, early_exchange=early)
     runner.upload([x[runner.lo:runner.hi]])
     runner.execute()
     runner.synchronize()
@@ -169,12 +169,13 @@ def test_two_processes_one_gpu_host_staged(overlap, groups):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,overlap,groups", [(2, True, 4), (3, True, 4), (3, False, 2), (2, True, 1)])
-def test_processes_on_one_gpu_shared_memory_transport(world, overlap, groups):
+@pytest.mark.parametrize("world,overlap,groups,early", [(2, True, 4, False), (3, True, 4, True),
+                                                        (3, False, 2, False), (2, True, 2, True)])
+def test_processes_on_one_gpu_shared_memory_transport(world, overlap, groups, early):
     """The spare transport of bench.py: halos through pinned host memory that the
     ranks share, flags raised and awaited by the streams (ShmExchanger); one of
     three ranks has two neighbours.  Results bit for bit against the oracle."""
-    _spawn(_gpu_worker, world, (48, 20, 64), 19, overlap, groups, "shm")
+    _spawn(_gpu_worker, world, (48, 20, 64), 19, overlap, groups, "shm", early)
 
 
 def _handshake_worker(rank, world, port):

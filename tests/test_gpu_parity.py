@@ -331,7 +331,8 @@ def test_full_size_properties():
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("groups", [1, 2, 4])
-def test_slab_decomposition_in_process(tmp_path, world, overlap, groups):
+@pytest.mark.parametrize("early", [False, True])
+def test_slab_decomposition_in_process(tmp_path, world, overlap, groups, early):
     """Slab-decomposed execution (one plan per rank, halos copied between the
     ranks' device buffers by the driver) equals the undivided run bit for bit.
     All ranks share this GPU; the transport is the only part not covered."""
@@ -354,7 +355,7 @@ def test_slab_decomposition_in_process(tmp_path, world, overlap, groups):
             v.reserved_cus = 32
     runners = [SlabRunner(sfir, shape, r, world, options={"fuse": 2},
                           exchanger=views[r], overlap=overlap,
-                          groups_per_exchange=groups)
+                          groups_per_exchange=groups, early_exchange=early)
                for r in range(world)]
     assert runners[0].is_chain and runners[0].halo == 2 * groups
     for r in runners:

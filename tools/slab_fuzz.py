@@ -48,10 +48,13 @@ def run_seed(seed, tmp):
     split = "i" if len(dims) == 3 else "j"  # iterator of the outermost axis
     exch = LocalExchanger(world)
     fuse = int(rng.integers(1, 4))
-    label = {"seed": seed, "world": world, "groups": groups, "overlap": overlap, "dims": dims, "fuse": fuse}
+    early = bool(seed % 2)  # exchange started a launch ahead (SlabRunner early_exchange)
+    label = {"seed": seed, "world": world, "groups": groups, "overlap": overlap, "dims": dims, "fuse": fuse,
+             "early": early}
     try:
         runners = [SlabRunner(sfir, tuple(dims), r, world, options={"fuse": fuse},
-                              exchanger=exch.for_rank(r), overlap=overlap, groups_per_exchange=groups)
+                              exchanger=exch.for_rank(r), overlap=overlap, groups_per_exchange=groups,
+                              early_exchange=early)
                    for r in range(world)]
     except ValueError as exc:
         if "too thin" in str(exc):

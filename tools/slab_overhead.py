@@ -33,11 +33,13 @@ def main():
         path = programs.write_program(programs.jacobi3d(shape, stages), os.path.join(tmp, "p.json"))
         sfir = lower(sf.KernelChainGraph(path))
     x = np.random.default_rng(0).random((512, 512, 512), dtype=np.float32)
-    for overlap, groups, reserve in ((True, 1, 0), (True, 2, 0), (True, 4, 0), (True, 4, 16), (True, 4, 32),
-                                     (True, 8, 0), (True, 8, 32), (False, 4, 0)):
+    for overlap, groups, reserve, early in ((True, 1, 0, False), (True, 2, 0, False), (True, 4, 0, False),
+                                            (True, 4, 32, False), (True, 4, 0, True), (True, 4, 32, True),
+                                            (True, 8, 32, False), (True, 8, 32, True), (False, 4, 0, False)):
         ex = Null()
         ex.reserved_cus = reserve
-        r = SlabRunner(sfir, shape, 0, 2, exchanger=ex, overlap=overlap, groups_per_exchange=groups)
+        r = SlabRunner(sfir, shape, 0, 2, exchanger=ex, overlap=overlap, groups_per_exchange=groups,
+                       early_exchange=early)
         r.upload([x])
         r.execute(); r.synchronize()
         t = time.perf_counter()
@@ -47,8 +49,8 @@ def main():
         r.execute()
         host = time.perf_counter() - t
         r.synchronize()
-        print("slab runner overlap=%s groups/exchange=%d reserved CUs=%d halo=%d: %.3f ms per chain (%.1f us per group), host enqueue %.3f ms" % (
-            overlap, groups, reserve, r.halo, dt * 1e3, dt * 1e6 / len(r.steps), host * 1e3))
+        print("slab runner overlap=%s groups/exchange=%d reserved CUs=%d early=%s halo=%d: %.3f ms per chain (%.1f us per group), host enqueue %.3f ms" % (
+            overlap, groups, reserve, early, r.halo, dt * 1e3, dt * 1e6 / len(r.steps), host * 1e3))
         r.close()
     with tempfile.TemporaryDirectory() as tmp:
         path = programs.write_program(programs.jacobi3d((512, 512, 512), stages), os.path.join(tmp, "p.json"))
