@@ -221,11 +221,28 @@ def main():
             raise SystemExit("no halo transport works: " + "; ".join(why))
         if why:
             transport += " (" + "; ".join(why) + ")"
-        # the host-memory transport needs about two interior launches to hide an
-        # exchange: it is started a launch ahead (tools/slab_overhead.py: +4 %)
         runner = SlabRunner(sfir, shape, rank, world, device=local_rank,
-                            options=options, exchanger=exchanger,
-                            early_exchange=isinstance(exchanger, ShmExchanger))
+                            options=options, exchanger=exchanger)
+        runner.upload([synthetic(runner.local_shape, rank)])
+        # An exchange hides behind the interior of ONE launch unless it is started a
+        # launch ahead (two interiors of cover for +4 % of driver overhead,
+        # tools/slab_overhead.py).  Measured here, untimed, decided alike on all
+        # ranks: one exchange alone against one launch group of the chain.
+        t_exchange = runner.measure_exchange()
+        runner.execute()
+        runner.synchronize()
+        t0 = time.perf_counter()
+        runner.execute()
+        runner.synchronize()
+        t_launch = (time.perf_counter() - t0) / max(1, len(runner.steps))
+        both = torch.tensor([t_exchange, t_launch], dtype=torch.float64)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)
+        t_exchange, t_launch = float(both[0]), float(both[1])
+        env_early = os.environ.get("SF_BENCH_EARLY_EXCHANGE")
+        runner.early_exchange = (env_early == "1") if env_early in ("0", "1") else t_exchange > 0.85 * t_launch
+        transport += "; exchange alone {:.0f} us, launch group {:.0f} us -> {}".format(
+            t_exchange * 1e6, t_launch * 1e6,
+            "started a launch ahead" if runner.early_exchange else "started with the launch that needs it")
         runner.upload([synthetic(runner.local_shape, rank)])
 
         def step():

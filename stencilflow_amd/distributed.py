@@ -633,6 +633,26 @@ class SlabRunner:
                                               stream=raw)
             self._valid = ext if self.is_chain else 0
 
+    def measure_exchange(self, repeats=5):
+        """Seconds one full-depth halo exchange of the chain's field takes with
+        nothing beside it (collective: every rank calls it).  Overwrites ghost
+        planes only; the next chain execution exchanges them again."""
+        import time
+        if self.world == 1 or not self.is_chain:
+            return 0.0
+        torch = self.torch
+        buf = self.inputs[0][0]
+        tensor, plane_bytes, _ = self._buffer_tensor(buf)
+        regions = halo_regions(self.n_local, self.halo, self.halo, plane_bytes)
+        with torch.cuda.stream(self.stream):
+            self.exchanger.finish(self.exchanger.start(tensor, regions, key=buf))  # connections, outboxes
+            self.stream.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(repeats):
+                self.exchanger.finish(self.exchanger.start(tensor, regions, key=buf))
+            self.stream.synchronize()
+        return (time.perf_counter() - t0) / repeats
+
     def execute(self):
         """One execution of the whole chain (asynchronous on ``self.stream``)."""
         for s in range(len(self.steps)):
