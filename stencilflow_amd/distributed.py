@@ -78,13 +78,19 @@ class TorchDistExchanger:
     # device-side (RCCL) exchange; host staging copies by DMA and needs none
     RESERVED_CUS = 32
 
-    def __init__(self, rank, world, group=None, staging="device"):
+    def __init__(self, rank, world, group=None, staging="device", self_loop=False):
         import torch.distributed as dist
         self.dist = dist
         self.rank, self.world, self.group = rank, world, group
         self.staging = staging
         self._host = {}
         self.reserved_cus = self.RESERVED_CUS if staging == "device" else 0
+        # self_loop (tests and measurements on a one-GPU box): both neighbours are
+        # this very rank -- every send is received by the sender itself, in issue
+        # order (send_down lands in recv_down, send_up in recv_up).  The transport
+        # (RCCL kernels, streams, aliased buffers) is the real one; only the wire
+        # is missing.
+        self.self_loop = bool(self_loop)
 
     def handshake(self, device=None):
         """One small exchange with both neighbours: creates the transport's
@@ -112,6 +118,12 @@ class TorchDistExchanger:
         dist = self.dist
         ops = []
         lo_peer, hi_peer = self.rank - 1, self.rank + 1
+        if self.self_loop:
+            me = dist.get_rank()
+            return [dist.P2POp(dist.irecv, as_tensor("recv_down"), me, self.group),
+                    dist.P2POp(dist.irecv, as_tensor("recv_up"), me, self.group),
+                    dist.P2POp(dist.isend, as_tensor("send_down"), me, self.group),
+                    dist.P2POp(dist.isend, as_tensor("send_up"), me, self.group)]
         # post receives first, then sends; one pair per neighbour
         if lo_peer >= 0:
             ops.append(dist.P2POp(dist.irecv, as_tensor("recv_down"), lo_peer,

@@ -218,3 +218,41 @@ def test_bench_three_ranks_on_one_gpu_falls_back(first, expect):
     assert rec["scaling"] == "weak" and "slab3" in rec["config"]["decomposition"]
     assert expect in rec["config"]["decomposition"], rec["config"]["decomposition"]
     assert "192x64x64" in rec["config"]["workload"]
+
+
+def _rccl_self_worker(rank, world, port):
+    import datetime
+    import torch
+    sys.path.insert(0, ROOT)
+    from stencilflow_amd.distributed import (TorchDistExchanger, alias_device_buffer, halo_regions)
+    dist = _init(rank, world, port)
+    torch.cuda.set_device(0)
+    rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+    n_local, halo, depth, plane = 12, 4, 4, 1 << 16
+    raw = torch.zeros((n_local + 2 * halo) * plane, dtype=torch.uint8, device="cuda")
+    view = raw.view(n_local + 2 * halo, plane)
+    for p in range(n_local):
+        view[halo + p] = 100 + p
+    tensor = alias_device_buffer(raw.data_ptr(), raw.numel(), 0)  # as SlabRunner aliases plan buffers
+    ex = TorchDistExchanger(1, 3, group=rccl, staging="device", self_loop=True)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        view[halo] += 1  # queued before the exchange: the transfer must see it
+        for _ in range(3):
+            ex.finish(ex.start(tensor, halo_regions(n_local, halo, depth, plane), key=0))
+        stream.synchronize()
+    got = view[:, 0].cpu().tolist()
+    # send_down (first owned planes) came back into the lower ghost planes, send_up into the upper
+    assert got[:halo] == [101, 101, 102, 103], got
+    assert got[halo + n_local:] == [100 + n_local - depth + d for d in range(depth)], got
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_exchanger_sends_to_itself():
+    """What a one-GPU box can exercise of the RCCL transport: the exchanger's
+    batched send/recv on an "nccl" group created under the gloo default group,
+    on tensors aliasing raw device memory, ordered against a side stream -- with
+    the rank itself as both neighbours (TorchDistExchanger self_loop)."""
+    _spawn(_rccl_self_worker, 1)
