@@ -137,12 +137,19 @@ def main():
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    # test hook for a one-GPU box: this single process plays rank 1 of 3 (two
+    # neighbours) of the decomposed run and every halo it sends comes back to
+    # itself -- through the same transport ladder, RCCL first (the data are not a
+    # stencil solution; never used for records, the JSON line says so)
+    self_loop = world == 1 and os.environ.get("SF_BENCH_SELF_LOOP") == "1"
+    slab_rank, slab_world = (1, 3) if self_loop else (rank, world)
+    multi = slab_world > 1
 
     if args.workload != "c3" and world > 1:
         raise SystemExit("only the c3 workload is slab-decomposed by bench.py")
     if args.workload == "c3":
         n = args.size or 512
-        shape = (n * world, n, n)
+        shape = (n * slab_world, n, n)
         prog = programs.jacobi3d(shape, args.stages)
         np_dtype, dtype_name, bpu = np.float32, "f32", 8.0
         label = ("jacobi3d {}x{}x{} float32, {}-operator chain, constant BC 0.0, "
@@ -170,7 +177,7 @@ def main():
         sfir = lower(chain)
 
     transport = None
-    if world > 1:
+    if multi:
         import datetime
         from stencilflow_amd.distributed import SlabRunner, TorchDistExchanger
         import torch.distributed as dist
@@ -181,7 +188,12 @@ def main():
         # by the streams), else through gloo.  SF_BENCH_TRANSPORT=rccl|shm|gloo
         # starts the ladder at that rung (tests).
         from stencilflow_amd.distributed import ShmExchanger
-        dist.init_process_group("gloo")
+        if self_loop:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29657")
+            dist.init_process_group("gloo", rank=0, world_size=1)
+        else:
+            dist.init_process_group("gloo")
         first = os.environ.get("SF_BENCH_TRANSPORT", "rccl")
         ladder = ["rccl", "shm", "gloo"]
         ladder = ladder[ladder.index(first):] if first in ladder else ladder
@@ -195,13 +207,16 @@ def main():
             try:
                 if rung == "rccl":
                     rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
-                    candidate = TorchDistExchanger(rank, world, group=rccl, staging="device")
+                    candidate = TorchDistExchanger(slab_rank, slab_world, group=rccl, staging="device",
+                                                   self_loop=self_loop)
                     candidate.handshake(torch.device("cuda", local_rank))
                 elif rung == "shm":
+                    if self_loop:
+                        raise RuntimeError("the shared-memory transport has no self-loop mode")
                     candidate = ShmExchanger(rank, world, session[0], device=local_rank)
                     candidate.handshake()
                 else:
-                    candidate = TorchDistExchanger(rank, world, staging="host")
+                    candidate = TorchDistExchanger(slab_rank, slab_world, staging="host", self_loop=self_loop)
                     candidate.handshake()
             except Exception as exc:  # noqa: BLE001 -- any transport failure selects the next rung
                 ok = 0
@@ -221,7 +236,9 @@ def main():
             raise SystemExit("no halo transport works: " + "; ".join(why))
         if why:
             transport += " (" + "; ".join(why) + ")"
-        runner = SlabRunner(sfir, shape, rank, world, device=local_rank,
+        if self_loop:
+            transport += " -- SELF-LOOP TEST: rank 1 of 3, halos sent to the rank itself"
+        runner = SlabRunner(sfir, shape, slab_rank, slab_world, device=local_rank,
                             options=options, exchanger=exchanger)
         runner.upload([synthetic(runner.local_shape, rank)])
         # An exchange hides behind the interior of ONE launch unless it is started a
@@ -273,7 +290,7 @@ def main():
     # afterwards so the timed steps start from the same synthetic data.
     step()
     sync()
-    if world > 1:
+    if multi:
         runner.upload([synthetic(runner.local_shape, rank)])
     else:
         plan.upload([synthetic(shape, dtype=np_dtype)])
@@ -285,20 +302,21 @@ def main():
     kernel_ms = 0.0
     for _ in range(args.steps):
         step()
-        if world == 1:
+        if not multi:
             # HIP events bracket the launches of this step on the plan's stream
             plan.synchronize()
             kernel_ms += plan.elapsed_ms()
     sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # control plane (gloo)
         elapsed = float(t.item())
 
-    cells = float(np.prod(shape)) * args.stages * args.steps
+    # (self-loop test: the one rank present updates its own slab only)
+    cells = float(np.prod(runner.local_shape if self_loop else shape)) * args.stages * args.steps
     result = {
         "metric": "Mcells/s (updates) and achieved HBM GB/s vs roofline, "
                   "jacobi3d 512^3 f32" if args.workload == "c3" else
@@ -317,11 +335,11 @@ def main():
         "config": {
             "workload": label,
             "decomposition": ("slab{} (halo {} planes, one exchange per {} launches, {})".format(
-                world, runner.halo, runner.halo // max(1, runner.steps[0][1]), transport)
-                if world > 1 else "single"),
+                slab_world, runner.halo, runner.halo // max(1, runner.steps[0][1]), transport)
+                if multi else "single"),
         },
     }
-    if world == 1:
+    if not multi:
         stats = plan.kernel_stats()
         launches = plan.num_launches * args.steps
         name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"])
@@ -345,7 +363,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(shape, budget_s=args.cpu_seconds)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         dist.destroy_process_group()
 

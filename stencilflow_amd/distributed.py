@@ -109,9 +109,10 @@ class TorchDistExchanger:
             w.wait()
         if self.staging == "device":
             torch.cuda.synchronize()
-        if self.rank > 0 and int(bufs["recv_down"][0]) != self.rank - 1:
+        lower, upper = (self.rank, self.rank) if self.self_loop else (self.rank - 1, self.rank + 1)
+        if (self.rank > 0 or self.self_loop) and int(bufs["recv_down"][0]) != lower:
             raise RuntimeError("halo transport handshake: wrong data from the lower neighbour")
-        if self.rank < self.world - 1 and int(bufs["recv_up"][255]) != self.rank + 1:
+        if (self.rank < self.world - 1 or self.self_loop) and int(bufs["recv_up"][255]) != upper:
             raise RuntimeError("halo transport handshake: wrong data from the upper neighbour")
 
     def _ops(self, buf, regions, as_tensor):

@@ -256,3 +256,26 @@ def test_rccl_exchanger_sends_to_itself():
     on tensors aliasing raw device memory, ordered against a side stream -- with
     the rank itself as both neighbours (TorchDistExchanger self_loop)."""
     _spawn(_rccl_self_worker, 1)
+
+
+@pytest.mark.gpu
+def test_bench_self_loop_selects_rccl():
+    """bench.py's multi-rank path end to end on one GPU with the RCCL rung of the
+    transport ladder: one process as rank 1 of 3, every halo sent to the rank
+    itself (SF_BENCH_SELF_LOOP=1)."""
+    import json
+    import subprocess
+    env = dict(os.environ, SF_BENCH_SELF_LOOP="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+           "--size", "64", "--stages", "24"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    deco = rec["config"]["decomposition"]
+    assert "slab3" in deco and "RCCL send/recv" in deco and "SELF-LOOP TEST" in deco, deco
+    assert rec["value"] > 0 and "roofline" not in rec
