@@ -236,30 +236,46 @@ def main():
             raise SystemExit("no halo transport works: " + "; ".join(why))
         if why:
             transport += " (" + "; ".join(why) + ")"
-        if self_loop:
-            transport += " -- SELF-LOOP TEST: rank 1 of 3, halos sent to the rank itself"
-        runner = SlabRunner(sfir, shape, slab_rank, slab_world, device=local_rank,
-                            options=options, exchanger=exchanger)
-        runner.upload([synthetic(runner.local_shape, rank)])
-        # An exchange hides behind the interior of ONE launch unless it is started a
-        # launch ahead (two interiors of cover for +4 % of driver overhead,
-        # tools/slab_overhead.py).  Measured here, untimed, decided alike on all
-        # ranks: one exchange alone against one launch group of the chain.
-        t_exchange = runner.measure_exchange()
+        # The schedule is chosen by measurement, alike on all ranks.  With halos twice
+        # as deep an exchange is needed every 8 launches instead of every 4, which
+        # saves 2.5 % when real RCCL copy kernels run beside the compute kernel
+        # (tools/rccl_overlap_probe.py: 218.4 against 224.1 us per launch group) --
+        # if a 16-plane exchange still fits beside ONE interior launch.  If even the
+        # 8-plane exchange does not, it is started a launch ahead (two interiors of
+        # cover for +4 % of driver overhead, tools/slab_overhead.py).
+        def build(groups):
+            r = SlabRunner(sfir, shape, slab_rank, slab_world, device=local_rank, options=options,
+                           exchanger=exchanger, groups_per_exchange=groups)
+            r.upload([synthetic(r.local_shape, rank)])
+            return r
+
+        def agreed(*values):
+            t = torch.tensor(values, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return [float(v) for v in t]
+
+        runner = build(8)
+        deep = runner.halo
+        t_deep, t_half = agreed(runner.measure_exchange(), runner.measure_exchange(depth=max(1, deep // 2)))
         runner.execute()
         runner.synchronize()
         t0 = time.perf_counter()
         runner.execute()
         runner.synchronize()
-        t_launch = (time.perf_counter() - t0) / max(1, len(runner.steps))
-        both = torch.tensor([t_exchange, t_launch], dtype=torch.float64)
-        dist.all_reduce(both, op=dist.ReduceOp.MAX)
-        t_exchange, t_launch = float(both[0]), float(both[1])
+        (t_launch, ) = agreed((time.perf_counter() - t0) / max(1, len(runner.steps)))
+        env_groups = os.environ.get("SF_BENCH_GROUPS")
+        groups = int(env_groups) if env_groups in ("4", "8") else (8 if t_deep <= 0.85 * t_launch else 4)
+        if groups != 8:
+            runner.close()
+            runner = build(groups)
+        t_exchange = t_deep if groups == 8 else t_half
         env_early = os.environ.get("SF_BENCH_EARLY_EXCHANGE")
         runner.early_exchange = (env_early == "1") if env_early in ("0", "1") else t_exchange > 0.85 * t_launch
-        transport += "; exchange alone {:.0f} us, launch group {:.0f} us -> {}".format(
-            t_exchange * 1e6, t_launch * 1e6,
+        transport += "; exchange alone {:.0f} us ({} planes) / {:.0f} us ({} planes), launch group {:.0f} us -> {}".format(
+            t_deep * 1e6, deep, t_half * 1e6, max(1, deep // 2), t_launch * 1e6,
             "started a launch ahead" if runner.early_exchange else "started with the launch that needs it")
+        if self_loop:
+            transport += " -- SELF-LOOP TEST: rank 1 of 3, halos sent to the rank itself"
         runner.upload([synthetic(runner.local_shape, rank)])
 
         def step():

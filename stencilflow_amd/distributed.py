@@ -646,17 +646,18 @@ class SlabRunner:
                                               stream=raw)
             self._valid = ext if self.is_chain else 0
 
-    def measure_exchange(self, repeats=5):
-        """Seconds one full-depth halo exchange of the chain's field takes with
-        nothing beside it (collective: every rank calls it).  Overwrites ghost
-        planes only; the next chain execution exchanges them again."""
+    def measure_exchange(self, repeats=5, depth=None):
+        """Seconds one halo exchange of the chain's field (``depth`` planes per
+        direction, default the full halo) takes with nothing beside it
+        (collective: every rank calls it).  Overwrites ghost planes only; the
+        next chain execution exchanges them again."""
         import time
         if self.world == 1 or not self.is_chain:
             return 0.0
         torch = self.torch
         buf = self.inputs[0][0]
         tensor, plane_bytes, _ = self._buffer_tensor(buf)
-        regions = halo_regions(self.n_local, self.halo, self.halo, plane_bytes)
+        regions = halo_regions(self.n_local, self.halo, min(self.halo, depth or self.halo), plane_bytes)
         with torch.cuda.stream(self.stream):
             self.exchanger.finish(self.exchanger.start(tensor, regions, key=buf))  # connections, outboxes
             self.stream.synchronize()

@@ -46,13 +46,18 @@ def main():
         path = programs.write_program(programs.jacobi3d(shape, stages), os.path.join(tmp, "p.json"))
         sfir = lower(sf.KernelChainGraph(path))
     x = np.random.default_rng(0).random((512, 512, 512), dtype=np.float32)
-    cases = [("no transport", None, 0, False), ("no transport, 32 CUs reserved", None, 32, False),
-             ("RCCL to self", "rccl", 32, False), ("RCCL to self, no CUs reserved", "rccl", 0, False),
-             ("RCCL to self, started a launch ahead", "rccl", 32, True)]
-    for label, kind, reserve, early in cases:
+    cases = [("no transport", None, 0, False, 4), ("no transport, 32 CUs reserved", None, 32, False, 4),
+             ("RCCL to self", "rccl", 32, False, 4), ("RCCL to self, no CUs reserved", "rccl", 0, False, 4),
+             ("RCCL to self, 8 CUs reserved", "rccl", 8, False, 4),
+             ("RCCL to self, 16 CUs reserved", "rccl", 16, False, 4),
+             ("RCCL to self, started a launch ahead", "rccl", 32, True, 4),
+             ("RCCL to self, exchange per 8 launches", "rccl", 32, False, 8),
+             ("RCCL to self, exchange per 8, 16 CUs", "rccl", 16, False, 8),
+             ("RCCL to self, exchange per 2 launches", "rccl", 32, False, 2)]
+    for label, kind, reserve, early, groups in cases:
         ex = Null() if kind is None else TorchDistExchanger(1, 3, group=rccl, staging="device", self_loop=True)
         ex.reserved_cus = reserve
-        r = SlabRunner(sfir, shape, 1, 3, exchanger=ex, early_exchange=early)
+        r = SlabRunner(sfir, shape, 1, 3, exchanger=ex, early_exchange=early, groups_per_exchange=groups)
         r.upload([x])
         t_ex = r.measure_exchange() if kind else 0.0
         r.execute(); r.synchronize()
