@@ -321,8 +321,10 @@ static void star_finish_cfg(StarCfg& c, const Program& P, int T) {
 
 // chunk length along the stream axis for `range` planes: whole block waves
 static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_out = nullptr,
-                             int reserved_cus = 0) {
-  const int tiles = c.NJT * c.NKT;
+                             int reserved_cus = 0, int ranges = 1) {
+  // (`ranges`: plane ranges of this length served by the one launch -- the two
+  // slab boundaries of a split step -- whose blocks share the block slots)
+  const int tiles = c.NJT * c.NKT * std::max(1, ranges);
   const int slots = std::max(1, 256 - reserved_cus) * std::max(1, star_blocks_per_cu(c, dt));
   double best = 1e30;
   int best_li = range;
@@ -364,9 +366,9 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
 }
 
 // chunk length used for a launch over `range` planes (options k1.li / k2.li pin it)
-static long long star_chunk_length(const sf_plan& pl, const StarCfg& c, DT dt, int range) {
+static long long star_chunk_length(const sf_plan& pl, const StarCfg& c, DT dt, int range, int ranges = 1) {
   long long li = pl.opt.get(c.noj ? "k2.li" : "k1.li", 0);
-  if (li <= 0) li = star_chunk_planes(c, dt, range, nullptr, pl.reserved_cus);
+  if (li <= 0) li = star_chunk_planes(c, dt, range, nullptr, pl.reserved_cus, ranges);
   if (li > range) li = range;
   return std::max<long long>(li, 1);
 }
@@ -961,7 +963,8 @@ static void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, i
     // chunking of the stream axis: whole block waves (star_chunk_planes)
     const int range1 = std::max(0, i_end - i_begin), range2 = second ? i_end2 - i_begin2 : 0;
     const int tiles = c.NJT * c.NKT;
-    const long long li = star_chunk_length(pl, c, P.kernels[st.kernels[0]].dt, std::max(range1, range2));
+    const long long li = star_chunk_length(pl, c, P.kernels[st.kernels[0]].dt, std::max(range1, range2),
+                                           (range1 > 0 && range2 > 0) ? 2 : 1);
     int nch1 = (int)((range1 + li - 1) / li);
     const int nch2 = (int)((range2 + li - 1) / li);
     int li_i = (int)li;
