@@ -102,6 +102,8 @@ def main():
         for seed in range(args.first, args.first + args.seeds):
             status, detail = run_seed(seed, tmp)
             count[status] += 1
+            if (seed - args.first + 1) % 50 == 0:  # a long run must keep writing
+                print("# %d seeds, %d failures so far" % (seed - args.first + 1, count["fail"]), flush=True)
             if status == "fail":
                 print(json.dumps(detail), flush=True)
     print("programs run: %d (skipped %d), failures: %d" % (count["ok"] + count["fail"], count["skip"], count["fail"]))

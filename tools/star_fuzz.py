@@ -60,6 +60,8 @@ def main():
                 continue
             desc = plan.describe()
             nstar += desc.count("[star")
+            if (seed - args.first + 1) % 100 == 0:  # a long run must keep writing
+                print("# %d programs, %d failures so far" % (seed - args.first + 1, nfail), flush=True)
             nlaunch += plan.num_launches
             if plan.scalar_names:
                 plan.set_scalars([scal[n] for n in plan.scalar_names])
