@@ -27,8 +27,16 @@ def counter_means(root, counter):
 def main():
     tag, out_path = sys.argv[1], sys.argv[2]
     result = {}
-    for wl in ("c3", "c2"):
+    if os.path.exists(out_path):  # keep the entries of workloads not profiled this time
+        try:
+            with open(out_path) as f:
+                result = json.load(f)
+        except (OSError, ValueError):
+            result = {}
+    for wl in ("c3", "c2", "c5"):
         root = "gpurun_out/prof_%s_%s" % (tag, wl)
+        if not os.path.isdir(root):
+            continue
         fetch, write = counter_means(root, "FETCH_SIZE"), counter_means(root, "WRITE_SIZE")
         for kernel in fetch:
             if kernel not in write:

@@ -8,7 +8,7 @@
 set -u
 tag=${1:-r01}
 export TMPDIR=/tmp
-for wl in c3 c2; do
+for wl in ${SF_PROFILE_WORKLOADS:-c3 c2 c5}; do
   out=gpurun_out/prof_${tag}_$wl
   rm -rf $out; mkdir -p $out
   args="bench.py --workload $wl --steps 1 --warmup 0 --stages 100 --no-cpu-baseline"
