@@ -85,6 +85,7 @@ typedef unsigned sf_u4 __attribute__((ext_vector_type(4)));
 #define SF_PLANE_ELEMS ((long long)SF_N1 * (long long)SF_N2)
 #define SF_PLANE_BYTES ((unsigned)(SF_PLANE_ELEMS * (long long)sizeof(sf_t)))
 #define SF_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format (gfx9 / CDNA) */
+typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 
 #if SF_REVERSE  // loads are issued at the end of the step: no staging registers
 #undef SF_PREFETCH2
@@ -229,6 +230,37 @@ __device__ __forceinline__ T sf_neighbour_lane_or(T x, T edge) {
   }
 }
 
+// One vector (8, 16 or 32 bytes: 2 floats / 4 floats or 2 doubles / 4 doubles) through a
+// buffer resource; `off` outside the resource: the load returns 0, the store is dropped.
+template <typename V, int aux>
+__device__ __forceinline__ V sf_buf_load(const __amdgpu_buffer_rsrc_t rs, const unsigned off) {
+  if constexpr (sizeof(V) == 8) {
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, aux));
+  } else if constexpr (sizeof(V) == 16) {
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, aux));
+  } else {
+    static_assert(sizeof(V) == 32, "vector of 8, 16 or 32 bytes");
+    struct { sf_u4 lo, hi; } two;
+    two.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, aux);
+    two.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u, 0, aux);  // (SF_OOB + 16 is outside too)
+    return __builtin_bit_cast(V, two);
+  }
+}
+template <typename V, int aux>
+__device__ __forceinline__ void sf_buf_store(const V v, const __amdgpu_buffer_rsrc_t rs, const unsigned off) {
+  if constexpr (sizeof(V) == 8) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sf_u2, v), rs, off, 0, aux);
+  } else if constexpr (sizeof(V) == 16) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_u4, v), rs, off, 0, aux);
+  } else {
+    static_assert(sizeof(V) == 32, "vector of 8, 16 or 32 bytes");
+    struct Two { sf_u4 lo, hi; };
+    const Two two = __builtin_bit_cast(Two, v);
+    __builtin_amdgcn_raw_buffer_store_b128(two.lo, rs, off, 0, aux);
+    __builtin_amdgcn_raw_buffer_store_b128(two.hi, rs, off + 16u, 0, aux);
+  }
+}
+
 // Is row r of input plane p inside the global domain (and inside what this chunk reads)?
 __device__ __forceinline__ bool sf_row_ok(const sf_ctx& cx, const int p, const int r) {
   const bool plane_in = (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
@@ -248,7 +280,7 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, con
   const char* base = reinterpret_cast<const char*>(cx.in) + (long long)(p + cx.halo) * (long long)SF_PLANE_BYTES;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(base), 0, plane_ok ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
-  sf_vec v = __builtin_bit_cast(sf_vec, __builtin_amdgcn_raw_buffer_load_b128(rs, cx.ld_off[r], 0, (SF_NT & 2) ? 2 : 0));
+  sf_vec v = sf_buf_load<sf_vec, (SF_NT & 2) ? 2 : 0>(rs, cx.ld_off[r]);
   if constexpr (!sf_stage<1>::bc_zero) {
     const bool ok = plane_ok && cx.ld_off[r] != SF_OOB;
 #pragma unroll
@@ -454,7 +486,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
         char* base = reinterpret_cast<char*>(out) + (long long)(q + cx.halo) * (long long)SF_PLANE_BYTES;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             base, 0, (SF_EXPERIMENT != 1 && store_plane) ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_u4, o), rs, cx.st_off[r], 0, (SF_NT & 1) ? 2 : 0);
+        sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
       }
       if (false) {
 #else
