@@ -230,11 +230,13 @@ __device__ __forceinline__ T sf_neighbour_lane_or(T x, T edge) {
   }
 }
 
-// One vector (8, 16 or 32 bytes: 2 floats / 4 floats or 2 doubles / 4 doubles) through a
+// One vector (4, 8, 16 or 32 bytes: 1 float / 2 floats or 1 double / 4 floats or 2 doubles / 4 doubles) through a
 // buffer resource; `off` outside the resource: the load returns 0, the store is dropped.
 template <typename V, int aux>
 __device__ __forceinline__ V sf_buf_load(const __amdgpu_buffer_rsrc_t rs, const unsigned off) {
-  if constexpr (sizeof(V) == 8) {
+  if constexpr (sizeof(V) == 4) {
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, aux));
+  } else if constexpr (sizeof(V) == 8) {
     return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, aux));
   } else if constexpr (sizeof(V) == 16) {
     return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, aux));
@@ -248,7 +250,9 @@ __device__ __forceinline__ V sf_buf_load(const __amdgpu_buffer_rsrc_t rs, const 
 }
 template <typename V, int aux>
 __device__ __forceinline__ void sf_buf_store(const V v, const __amdgpu_buffer_rsrc_t rs, const unsigned off) {
-  if constexpr (sizeof(V) == 8) {
+  if constexpr (sizeof(V) == 4) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, aux);
+  } else if constexpr (sizeof(V) == 8) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sf_u2, v), rs, off, 0, aux);
   } else if constexpr (sizeof(V) == 16) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_u4, v), rs, off, 0, aux);
@@ -625,7 +629,9 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
         if (SF_REVERSE == 1 && s == 0 && w == (PH + 2) % 3) continue;
         // (SF_RING4: nor the fourth slot -- in flight for the input, dead otherwise)
         if (SF_RING4 && w == (PH + 3) % 4) continue;
-        asm volatile("" : "+v"(st.w[s][w][r]));
+        // (a one-element vector is not a register operand: name its element)
+        if constexpr (SF_VK == 1) asm volatile("" : "+v"(st.w[s][w][r][0]));
+        else asm volatile("" : "+v"(st.w[s][w][r]));
       }
 #endif
   // publish the rows / columns other threads need of every stage's current plane

@@ -379,10 +379,12 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   base.T = T;
   // one 16-byte vector per row and lane: 4 floats or 2 doubles
   base.VK = (int)pl.opt.get("k1.vk", dt == DT::F64 ? 2 : 4);
-  if (base.VK != 2 && base.VK != 4) throw Error(SF_ERR_INVALID, "k1.vk must be 2 or 4");
-  // rows of 4m+2 floats: 8-byte vectors keep the program on the star kernel
-  // (slower per point than 16-byte vectors, several times faster than the generic kernel)
-  if (!pl.opt.kv.count("k1.vk") && base.VK == 4 && P.n[2] % 4 != 0 && P.n[2] % 2 == 0) base.VK = 2;
+  if (base.VK != 1 && base.VK != 2 && base.VK != 4) throw Error(SF_ERR_INVALID, "k1.vk must be 1, 2 or 4");
+  // rows that do not hold whole 16-byte vectors: 8-byte vectors (rows of 4m+2 floats)
+  // or single elements (odd rows) keep the program on the star kernel -- slower per
+  // point than 16-byte vectors, several times faster than the generic kernel
+  if (!pl.opt.kv.count("k1.vk"))
+    while (base.VK > 1 && P.n[2] % base.VK != 0) base.VK /= 2;
   if (P.n[2] % base.VK != 0) throw Error(SF_ERR_INVALID, "innermost extent must be a multiple of k1.vk");
   base.n0g = P.n[0];
   base.n1 = P.n[1];
@@ -583,8 +585,9 @@ static void validate_options(const sf_plan& pl) {
       throw Error(SF_ERR_INVALID, std::string("option ") + r.key + " must lie in [" + std::to_string(r.lo) + ", " +
                                       std::to_string(r.hi) + "]");
   }
-  if (pl.opt.kv.count("k1.vk") && pl.opt.get("k1.vk", 4) != 2 && pl.opt.get("k1.vk", 4) != 4)
-    throw Error(SF_ERR_INVALID, "k1.vk must be 2 or 4");
+  if (pl.opt.kv.count("k1.vk") && pl.opt.get("k1.vk", 4) != 1 && pl.opt.get("k1.vk", 4) != 2 &&
+      pl.opt.get("k1.vk", 4) != 4)
+    throw Error(SF_ERR_INVALID, "k1.vk must be 1, 2 or 4");
   if (pl.opt.kv.count("k1.pfd") && pl.opt.get("k1.pfd", 1) != 1 && pl.opt.get("k1.pfd", 1) != 3)
     throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
 }
@@ -628,8 +631,8 @@ static void build_plan(sf_plan& pl) {
   else if (P.kernels[0].dt == DT::F64) fuse_default = 3;
   const int fuse = (int)std::max<long long>(1, pl.opt.get("fuse", fuse_default));
   const bool generic_only = pl.opt.get("generic_only", 0) != 0;
-  // (rows must hold whole vectors: 16 bytes, or 8 for rows of 4m+2 floats)
-  const bool star_ok_dims = (P.nd >= 2) && (P.n[2] % 2 == 0) && P.n[0] > 1;
+  // (any row length: the vector width follows it, rank_star_cfgs)
+  const bool star_ok_dims = (P.nd >= 2) && P.n[0] > 1;
 
   // ---- group kernels into launches
   std::map<std::string, StarChoice> star_memo;
