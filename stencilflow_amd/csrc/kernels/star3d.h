@@ -340,13 +340,16 @@ template <int S>
 __device__ __forceinline__ typename sf_stage<S>::aux_row sf_aux_row(const sf_ctx& cx, const int q, const int r) {
   const bool plane_ok = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G) && (q + cx.halo >= 0) &&
                         q >= cx.cb - (SF_T - S) && q < cx.ce + (SF_T - S);
+  const bool row_ok = ((cx.jmask >> r) & 1u) != 0;
 #if SF_BUFFER_IO
   // never under a branch: a plane this stage does not evaluate has zero records
-  return sf_stage<S>::load_aux_bio(cx.aux, (long long)(q + cx.halo), plane_ok, cx.ld_off[r], SF_PLANE_BYTES);
+  // (fields lacking dimensions are indexed by the dimensions they have, under a guard)
+  return sf_stage<S>::load_aux_bio(cx.aux, (long long)(q + cx.halo), plane_ok, cx.ld_off[r], SF_PLANE_BYTES,
+                                   cx.j0 + r, cx.k0, row_ok, cx.kvec_in);
 #endif
   return sf_stage<S>::load_aux(
       cx.aux, (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2) + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0),
-      plane_ok && ((cx.jmask >> r) & 1u) && cx.kvec_in);
+      plane_ok && row_ok && cx.kvec_in, (long long)(q + cx.halo), cx.j0 + r, cx.k0, plane_ok, row_ok, cx.kvec_in);
 }
 
 // One stage of the fused group at one step: reads the source window of stage

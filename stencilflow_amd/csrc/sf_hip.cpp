@@ -17,6 +17,7 @@
 #include <fstream>
 #include <memory>
 #include <mutex>
+#include <set>
 
 #include "codegen.hpp"
 
@@ -646,6 +647,7 @@ static void build_plan(sf_plan& pl) {
     }
     if (star) {
       std::vector<int> group{k};
+      std::set<std::string> group_aux(shape.aux.begin(), shape.aux.end());
       while ((int)group.size() < fuse && k + (int)group.size() < K) {
         const int cur = group.back(), nxt = cur + 1;
         const Kernel& kc = P.kernels[cur];
@@ -661,6 +663,11 @@ static void build_plan(sf_plan& pl) {
           for (int g : group)
             if (P.kernels[g].name == f) aux_ok = false;
         if (!aux_ok) break;
+        // one launch takes kMaxStarAux auxiliary pointers
+        std::set<std::string> all_aux = group_aux;
+        all_aux.insert(nshape.aux.begin(), nshape.aux.end());
+        if ((int)all_aux.size() > kMaxStarAux) break;
+        group_aux.swap(all_aux);
         group.push_back(nxt);
       }
       // longest prefix of the group for which a clean kernel exists

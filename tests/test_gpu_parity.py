@@ -212,6 +212,53 @@ def test_jacobi2d_step_orders(tmp_path, options):
     assert np.array_equal(got["b7"], want)
 
 
+def _lower_dim_aux_program(shape, dtype="float32"):
+    """A chain whose operators also read fields lacking dimensions at the point
+    itself: a [j,k] map, an [i] profile, a [k] row, a [j] column, an [i,k] sheet."""
+    bc = {"type": "constant", "value": 0.5}
+    return {
+        "inputs": {
+            "a": {"data": "constant:1.0", "data_type": dtype},
+            "c2": {"data": "constant:1.0", "data_type": dtype, "input_dims": ["j", "k"]},
+            "p1": {"data": "constant:1.0", "data_type": dtype, "input_dims": ["i"]},
+            "r1": {"data": "constant:1.0", "data_type": dtype, "input_dims": ["k"]},
+            "q1": {"data": "constant:1.0", "data_type": "float64", "input_dims": ["j"]},
+            "ik": {"data": "constant:1.0", "data_type": dtype, "input_dims": ["i", "k"]},
+        },
+        "outputs": ["b2"],
+        "dimensions": list(shape),
+        "program": {
+            "b0": {"computation_string": "b0 = 0.25 * (a[i-1,j,k] + a[i+1,j,k]) + c2[j,k] * a[i,j,k] + p1[i]",
+                   "boundary_conditions": {"a": bc, "c2": bc, "p1": bc}, "data_type": dtype},
+            "b1": {"computation_string": "b1 = b0[i,j-1,k] + b0[i,j+1,k] - r1[k] * b0[i,j,k] + q1[j]",
+                   "boundary_conditions": {"b0": bc, "r1": bc, "q1": bc}, "data_type": dtype},
+            "b2": {"computation_string": "b2 = (b1[i,j,k-1] + b1[i,j,k+1]) * ik[i,k]",
+                   "boundary_conditions": {"b1": bc, "ik": bc}, "data_type": dtype},
+        },
+    }
+
+
+@pytest.mark.parametrize("shape", [(12, 20, 64), (9, 7, 130), (6, 33, 37)])
+@pytest.mark.parametrize("options", [{"fuse": 3}, {"fuse": 2}, {"fuse": 1, "k1.bio": 0}])
+def test_star_chain_with_lower_dimensional_auxiliary_fields(tmp_path, shape, options):
+    """Fields lacking dimensions ride along as auxiliary fields of the fused star
+    kernel (indexed by the dimensions they have; one value per vector where the
+    contiguous dimension is missing)."""
+    prog = _lower_dim_aux_program(shape)
+    rng = np.random.default_rng(SEED + 21)
+    ins = {"a": rng.uniform(-1, 1, shape).astype(np.float32),
+           "c2": rng.uniform(-1, 1, shape[1:]).astype(np.float32),
+           "p1": rng.uniform(-1, 1, shape[:1]).astype(np.float32),
+           "r1": rng.uniform(-1, 1, shape[2:]).astype(np.float32),
+           "q1": rng.uniform(-1, 1, shape[1:2]),
+           "ik": rng.uniform(-1, 1, (shape[0], shape[2])).astype(np.float32)}
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, inputs=ins)["b2"]
+    got, desc = _run_gpu(path, ins, options=options)
+    assert "[star" in desc and "[point]" not in desc, desc
+    assert np.array_equal(got["b2"], want)
+
+
 def test_integer_bc_literal_f32_accumulation(tmp_path):
     shape = (16, 24, 64)
     rng = np.random.default_rng(SEED + 2)
@@ -432,6 +479,41 @@ def test_slab_dag_program_in_process(tmp_path):
         got_e[r.lo:r.hi], got_d[r.lo:r.hi] = pe, pd
         r.close()
     assert np.array_equal(got_d, want["d"]) and np.array_equal(got_e, want["e"])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_star_chain_with_lower_dimensional_auxiliary_fields(tmp_path, world):
+    """The same under slab decomposition: [i] and [i,k] fields are split with the
+    slabs, [j,k], [k] and [j] fields are whole on every rank."""
+    from stencilflow_amd.distributed import (LocalExchanger, SlabRunner, run_lockstep)
+    from stencilflow_amd.lowering import lower
+    shape = (30, 14, 66)
+    prog = _lower_dim_aux_program(shape)
+    rng = np.random.default_rng(SEED + 22)
+    ins = {"a": rng.uniform(-1, 1, shape).astype(np.float32),
+           "c2": rng.uniform(-1, 1, shape[1:]).astype(np.float32),
+           "p1": rng.uniform(-1, 1, shape[:1]).astype(np.float32),
+           "r1": rng.uniform(-1, 1, shape[2:]).astype(np.float32),
+           "q1": rng.uniform(-1, 1, shape[1:2]),
+           "ik": rng.uniform(-1, 1, (shape[0], shape[2])).astype(np.float32)}
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, inputs=ins)["b2"]
+    sfir = lower(sf.KernelChainGraph(path))
+    exch = LocalExchanger(world)
+    runners = [SlabRunner(sfir, shape, r, world, exchanger=exch.for_rank(r)) for r in range(world)]
+    assert "[star" in runners[0].plan.describe()
+    split = {"a", "p1", "ik"}  # fields with the outermost dimension
+    for r in runners:
+        r.upload([np.ascontiguousarray(ins[n][r.lo:r.hi]) if n in split else ins[n]
+                  for n in r.plan.input_names])
+    run_lockstep(runners)
+    got = np.zeros(shape, np.float32)
+    for r in runners:
+        part = np.zeros(r.local_shape, np.float32)
+        r.download([part])
+        got[r.lo:r.hi] = part
+        r.close()
+    assert np.array_equal(got, want)
 
 
 def test_full_size_jacobi2d_properties():
