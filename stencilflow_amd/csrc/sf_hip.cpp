@@ -93,6 +93,8 @@ struct Step {
   int generic_ppt = 1;                // planes per thread of a generic step
   int halo_buf = -1, halo_depth = 0;  // what must be exchanged before the step
   std::string note;
+  std::vector<std::pair<StarCfg, int>> alts;  // autotune candidates (tile shape, compiled kernel)
+  std::string sig;                            // steps with the same signature share the choice
 };
 
 }  // namespace sf
@@ -124,6 +126,7 @@ struct sf_plan {
   long long n_local = 0, goff = 0;
   int halo = 0;
   std::string description;
+  bool autotuned = false;
   void* debug_buffer = nullptr;  // diagnostic builds (option stamp=1): 8 x uint64
   // per-launch profiling events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -513,6 +516,10 @@ struct StarChoice {
   bool ok = false;
   StarCfg cfg;
   int ck = -1;
+  // option autotune=<k>: the first k clean candidates in ranked order (the first is
+  // cfg / ck); they are timed on the device before the first execution
+  std::vector<std::pair<StarCfg, int>> alts;
+  std::string sig;
 };
 
 static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& memo,
@@ -559,12 +566,16 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
                    ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs,
                    k.agprs, k.spills, k.scratch);
     if (bad == 0 || (pinned && pl.opt.get("allow_spills", 0) != 0)) {
-      out.ok = true;
-      out.cfg = ranked[ci];
-      out.ck = ck;
-      break;
+      if (!out.ok) {
+        out.ok = true;
+        out.cfg = ranked[ci];
+        out.ck = ck;
+      }
+      out.alts.push_back({ranked[ci], ck});
+      if (pinned || (long long)out.alts.size() >= std::max<long long>(1, pl.opt.get("autotune", 0))) break;
     }
   }
+  out.sig = sig;
   memo[sig] = out;
   return out;
 }
@@ -578,7 +589,7 @@ static void validate_options(const sf_plan& pl) {
   };
   static const Range ranges[] = {{"k1.pf2", 0, 2}, {"k1.rev", 0, 2},  {"k1.dpp", 0, 4},   {"k1.bio", 0, 1},
                                  {"k1.ul", 0, 1},  {"k1.db", 0, 1},   {"k1.nt", 0, 3},    {"k1.auxpre", 0, 2},
-                                 {"graph", 0, 1}};
+                                 {"graph", 0, 1},  {"autotune", 0, 8}};
   for (const Range& r : ranges) {
     if (!pl.opt.kv.count(r.key)) continue;
     const long long v = pl.opt.get(r.key, r.lo);
@@ -682,6 +693,8 @@ static void build_plan(sf_plan& pl) {
         st.kernels = group;
         st.cfg = choice.cfg;
         st.ck = choice.ck;
+        st.alts = choice.alts;
+        st.sig = choice.sig;
       } else {
         st.kernels.push_back(k);
       }
@@ -1074,8 +1087,88 @@ static void download(sf_plan& pl, void* const* host_outputs) {
   SF_HIP_CHECK(hipStreamSynchronize(pl.stream));
 }
 
+// Option autotune=<k>: before the first launch, time the first k clean tile shapes
+// of every fused group on the device (one warm-up and two timed launches each, on
+// the plan's own buffers: inputs are only read, everything written is written
+// again by the execution that follows) and keep the fastest.  Results do not
+// depend on the tile shape (tools/config_fuzz.py), only the time does.
+static void autotune(sf_plan& pl) {
+  if (pl.autotuned) return;
+  if (pl.opt.get("autotune", 0) <= 1) {
+    pl.autotuned = true;
+    return;
+  }
+  if (pl.P.num_scalar_inputs > 0 && !pl.scalars_set) return;  // not yet launchable
+  pl.autotuned = true;
+  const bool profile = pl.profile;
+  pl.profile = false;
+  std::map<std::string, std::pair<StarCfg, int>> best;
+  std::ostringstream note;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  SF_HIP_CHECK(hipEventCreate(&e0));
+  SF_HIP_CHECK(hipEventCreate(&e1));
+  try {
+    for (auto& st : pl.steps) {
+      if (!st.star || st.alts.size() < 2) continue;
+      if (!best.count(st.sig)) {
+        double best_ms = 1e30;
+        note << "  autotune";
+        for (auto& alt : st.alts) {
+          Step probe = st;
+          probe.cfg = alt.first;
+          probe.ck = alt.second;
+          // warm-up launch, timed to size the measurement: about 3 ms of launches,
+          // at least 3 (short launches are noisy), best of two rounds
+          launch_step(pl, probe, 0, pl.stream);
+          SF_HIP_CHECK(hipEventRecord(e0, pl.stream));
+          launch_step(pl, probe, 0, pl.stream);
+          SF_HIP_CHECK(hipEventRecord(e1, pl.stream));
+          SF_HIP_CHECK(hipEventSynchronize(e1));
+          float one = 0;
+          SF_HIP_CHECK(hipEventElapsedTime(&one, e0, e1));
+          const int reps = (int)std::min(100.0, std::max(3.0, 3.0 / std::max(1e-3, (double)one)));
+          float ms = 1e30f;
+          for (int round = 0; round < 2; ++round) {
+            SF_HIP_CHECK(hipEventRecord(e0, pl.stream));
+            for (int i = 0; i < reps; ++i) launch_step(pl, probe, 0, pl.stream);
+            SF_HIP_CHECK(hipEventRecord(e1, pl.stream));
+            SF_HIP_CHECK(hipEventSynchronize(e1));
+            float t = 0;
+            SF_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            ms = std::min(ms, t / (float)reps);
+          }
+          note << " " << pl.kernels[alt.second].name << " [" << alt.first.BX << "x" << alt.first.BY << " rows "
+               << alt.first.RJ << "] " << ms << " ms;";
+          if (ms < best_ms) {
+            best_ms = ms;
+            best[st.sig] = alt;
+          }
+        }
+        note << " -> " << pl.kernels[best[st.sig].second].name << "\n";
+      }
+      const auto& pick = best[st.sig];
+      if (pick.second != st.ck) {
+        pl.kernels[pick.second].updates_per_launch = pl.kernels[st.ck].updates_per_launch;
+        pl.kernels[pick.second].alg_bytes_per_launch = pl.kernels[st.ck].alg_bytes_per_launch;
+      }
+      st.cfg = pick.first;
+      st.ck = pick.second;
+    }
+  } catch (...) {
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    pl.profile = profile;
+    throw;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  pl.profile = profile;
+  pl.description += note.str();
+}
+
 static void execute(sf_plan& pl, int repetitions) {
   ensure_device(pl);
+  autotune(pl);
   if (repetitions < 0) throw Error(SF_ERR_INVALID, "negative repetition count");
   for (auto& k : pl.kernels) {
     k.launches = 0;
@@ -1363,6 +1456,7 @@ int sf_plan_execute_step(sf_plan* plan, int step, int part, void* stream) {
   if (!plan || step < 0 || step >= (int)plan->steps.size() || part < 0 || part > 3)
     throw Error(SF_ERR_INVALID, "bad step or part");
   ensure_device(*plan);
+  autotune(*plan);
   launch_step(*plan, plan->steps[step], part, stream ? (hipStream_t)stream : plan->stream);
   return SF_OK;
   SF_API_END
@@ -1372,6 +1466,7 @@ int sf_plan_execute_step_ranges(sf_plan* plan, int step, int i_begin, int i_end,
   SF_API_BEGIN
   if (!plan || step < 0 || step >= (int)plan->steps.size()) throw Error(SF_ERR_INVALID, "bad step");
   ensure_device(*plan);
+  autotune(*plan);
   launch_ranges(*plan, plan->steps[step], i_begin, i_end, i_begin2, i_end2,
                 stream ? (hipStream_t)stream : plan->stream);
   return SF_OK;

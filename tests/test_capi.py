@@ -160,3 +160,20 @@ def test_environment_options_and_generic_buffer_loads(tmp_path, monkeypatch):
     monkeypatch.delenv("SF_HIP_OPTIONS")
     with Plan(sfir, options={"generic_only": 1}) as plan:
         assert "[point]" in plan.describe()
+
+
+def test_autotune_compiles_alternative_tile_shapes(tmp_path):
+    """autotune=<k>: the first k clean tile shapes of a fused group are compiled at
+    plan creation (they are timed on the device before the first execution)."""
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    import stencilflow_amd as sf
+    path = programs.write_program(programs.jacobi3d((96, 200, 256), 4), str(tmp_path / "p.json"))
+    sfir = lower(sf.KernelChainGraph(path))
+    with Plan(sfir) as plan:
+        base = len(plan.kernel_names())
+    with Plan(sfir, options={"autotune": 3}) as plan:
+        names = plan.kernel_names()
+        assert len(names) == base + 2 and all(n.startswith("sf_star3d_f32_t2") for n in names), names
+    with pytest.raises(ValueError):
+        Plan(sfir, options={"autotune": 99})

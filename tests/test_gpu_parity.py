@@ -259,6 +259,20 @@ def test_star_chain_with_lower_dimensional_auxiliary_fields(tmp_path, shape, opt
     assert np.array_equal(got["b2"], want)
 
 
+@pytest.mark.parametrize("shape,stages", [((40, 70, 260), 5), ((333, 264), 8)])
+def test_autotuned_tile_shapes(tmp_path, shape, stages):
+    """autotune=3 times three tile shapes per fused group before the first launch
+    and keeps the fastest; the result does not depend on which one wins."""
+    rng = np.random.default_rng(SEED + 31)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    prog = (programs.jacobi3d if len(shape) == 3 else programs.jacobi2d)(shape, stages, bc_value=0.25)
+    path = _write(tmp_path, prog)
+    want = npo.run_reference(prog, {"a": x})["b%d" % (stages - 1)]
+    got, desc = _run_gpu(path, {"a": x}, options={"autotune": 3})
+    assert "autotune" in desc and " -> sf_star" in desc, desc
+    assert np.array_equal(got["b%d" % (stages - 1)], want)
+
+
 def test_integer_bc_literal_f32_accumulation(tmp_path):
     shape = (16, 24, 64)
     rng = np.random.default_rng(SEED + 2)

@@ -90,7 +90,9 @@ def main():
                 "frac_8TB": round(cells * bpu / ms / 1e6 / 8000, 4),
                 "launches": plan.num_launches, "check": same,
                 "compile_s": round(tc, 2),
-                "sched": plan.describe().splitlines()[1].strip()[:160]}), flush=True)
+                "sched": plan.describe().splitlines()[1].strip()[:160],
+                "autotune": [l.strip()[:400] for l in plan.describe().splitlines() if l.strip().startswith("autotune")][:2]}),
+                flush=True)
             plan.close()
         except Exception as exc:  # keep sweeping
             print(json.dumps({"opt": o, "error": str(exc)[:300]}), flush=True)
