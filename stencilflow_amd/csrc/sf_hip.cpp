@@ -580,6 +580,40 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
   return out;
 }
 
+// One line of sf_plan_describe per launch.
+static void describe_step(std::ostringstream& desc, const sf_plan& pl, const Step& st) {
+  const Program& P = pl.P;
+  const DT dt = P.kernels[st.kernels[0]].dt;
+  const CompiledKernel& ck = pl.kernels[st.ck];
+  desc << "  launch " << ck.name << ": ";
+  for (int k : st.kernels) desc << P.kernels[k].name << " ";
+  if (st.star)
+    desc << "[star T=" << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
+         << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " chunk "
+         << star_chunk_length(pl, st.cfg, dt, (int)pl.n_local) << " lds " << star_lds_bytes(st.cfg, dt)
+         << " B]";
+  else
+    desc << "[point]";
+  desc << " in";
+  for (int b : st.in_bufs) desc << " b" << b;
+  desc << " out b" << st.out_buf << " {vgpr " << ck.vgprs << " agpr " << ck.agprs << " spill " << ck.spills
+       << " scratch " << ck.scratch << "}\n";
+}
+
+// The whole description: header line, one line per launch (long chains: the first ones).
+static std::string describe_plan(const sf_plan& pl) {
+  const Program& P = pl.P;
+  std::ostringstream desc;
+  desc << "program " << P.name << ": dims " << P.n[0] << "x" << P.n[1] << "x" << P.n[2] << ", "
+       << P.kernels.size() << " operators, " << pl.steps.size() << " launches, " << pl.buffers.size()
+       << " device buffers\n";
+  for (auto& st : pl.steps) {
+    if (desc.tellp() > 16384) break;  // long chains: describe the first launches only
+    describe_step(desc, pl, st);
+  }
+  return desc.str();
+}
+
 // Values outside an option's range are the caller's mistake and are reported;
 // (a shape no kernel can serve is not: that group falls back to the generic kernel)
 static void validate_options(const sf_plan& pl) {
@@ -805,10 +839,6 @@ static void build_plan(sf_plan& pl) {
 
   // ---- generate + compile kernels
   const double cells = (double)pl.n_local * (double)P.n[1] * (double)P.n[2];
-  std::ostringstream desc;
-  desc << "program " << P.name << ": dims " << P.n[0] << "x" << P.n[1] << "x" << P.n[2] << ", "
-       << K << " operators, " << pl.steps.size() << " launches, " << pl.buffers.size()
-       << " device buffers\n";
   for (auto& st : pl.steps) {
     const DT dt = P.kernels[st.kernels[0]].dt;
     if (st.star) {
@@ -875,22 +905,8 @@ static void build_plan(sf_plan& pl) {
     pl.max_updates_per_launch = std::max(pl.max_updates_per_launch, ck.updates_per_launch);
     ck.alg_bytes_per_launch = 0;
     for (int k : st.kernels) ck.alg_bytes_per_launch += cells * 2.0 * (double)size_of(P.kernels[k].dt);
-    if (desc.tellp() > 16384) continue;  // long chains: describe the first launches only
-    desc << "  launch " << ck.name << ": ";
-    for (int k : st.kernels) desc << P.kernels[k].name << " ";
-    if (st.star)
-      desc << "[star T=" << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
-           << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " chunk "
-           << star_chunk_length(pl, st.cfg, dt, (int)pl.n_local) << " lds " << star_lds_bytes(st.cfg, dt)
-           << " B]";
-    else
-      desc << "[point]";
-    desc << " in";
-    for (int b : st.in_bufs) desc << " b" << b;
-    desc << " out b" << st.out_buf << " {vgpr " << ck.vgprs << " agpr " << ck.agprs << " spill " << ck.spills
-         << " scratch " << ck.scratch << "}\n";
   }
-  pl.description = desc.str();
+  pl.description = describe_plan(pl);
   pl.scalar_values.assign(P.num_scalar_inputs, 0.0);
 }
 
@@ -1163,7 +1179,7 @@ static void autotune(sf_plan& pl) {
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   pl.profile = profile;
-  pl.description += note.str();
+  pl.description = describe_plan(pl) + note.str();  // the launches as they run now, then the timings
 }
 
 static void execute(sf_plan& pl, int repetitions) {
