@@ -5,11 +5,29 @@ configs[2]) on N MI355X.
     python bench.py --gpus N --steps K --warmup W
 
 One *step* = one execution of the whole 1000-operator chain on a synthetic
-grid resident in HBM.  N > 1 (launched by torch.distributed.run, one rank per
-GPU) runs the slab-decomposed configuration configs[3]: (512*N) x 512 x 512,
-split along the outermost axis, halos exchanged over RCCL -- per-GPU work is
-fixed, so scaling is weak.  Rank 0 prints ONE JSON line (contract: task
-description; fields `roofline` and `cpu_baseline` are added at N = 1).
+grid resident in HBM.  N > 1 runs the slab-decomposed configuration configs[3]:
+(512*N) x 512 x 512, split along the outermost axis, one rank per GPU, halos
+exchanged over RCCL -- per-GPU work is fixed, so scaling is weak.  Started under
+torch.distributed.run the process is one of the N ranks; started as a plain
+command with --gpus N > 1 it launches the N ranks itself (before anything
+touches a GPU), relays rank 0's line and fails unless N ranks really took part
+(the role of `mpirun -n N bin/run_distributed_program.py` in the reference,
+bin/run_distributed_program.py:98-100,283-299).  Rank 0 prints ONE JSON line
+(contract: task description; `roofline` and `cpu_baseline` are added at N = 1).
+
+`roofline` (N = 1) describes the dominant kernel:
+  achieved / frac   HBM bytes one launch moves / its average duration (HIP events
+                    on the plan's stream), against the 8 TB/s peak; the bytes are
+                    the rocprofv3 PMC traffic of profiles/hbm_traffic.json when
+                    that was measured for exactly this code object (`basis`
+                    "pmc"), else the compulsory minimum, one read and one write of
+                    the field (`basis` "compulsory") -- never above 1;
+  traffic           the PMC bytes per launch, or null without a matching record;
+  algorithmic_*     2 * sizeof(dtype) per cell update x the updates
+                    of a launch.  A launch fuses `fused_operators` operators, so
+                    this figure counts bytes that never travel and may exceed the
+                    peak: it is the chain's speed-up over unfused sweeps, not a
+                    bandwidth.
 """
 
 import argparse
@@ -37,15 +55,17 @@ def synthetic(shape, rank=0, dtype=np.float32):
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    """HBM bytes per launch of exactly this code object (kernel name including
+    the hash of its generated source) from the committed rocprofv3 PMC passes
     (profiles/hbm_traffic.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE,
-    collected in their own --pmc runs of this command), or None."""
+    collected in their own --pmc runs of this command by tools/profile_round.sh),
+    or None: counters of another code object say nothing about this one."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
             table = json.load(f)
-        return float(table[kernel.rsplit("_", 1)[0]]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+        return float(table[kernel]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
@@ -102,6 +122,63 @@ def cpu_baseline(shape, block=8, budget_s=12.0):
     }
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this
+    script under torch.distributed.run (fresh child processes -- the parent never
+    initialises a GPU and nothing is re-exec'ed), pass their output through and
+    check that the line rank 0 printed reports N ranks.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if out.lstrip().startswith("{"):
+            line = out
+    code = proc.wait()
+    if code != 0:
+        print("bench.py: the {}-rank launch failed with exit code {}".format(n, code), file=sys.stderr)
+        return code
+    try:
+        result = json.loads(line)
+        ranks = result["n_gpus"] if "n_gpus" in result else result["ranks"]
+        connected = result.get("config", {}).get("ranks", result.get("ranks"))
+    except (TypeError, ValueError, KeyError):
+        print("bench.py: the launch printed no result line", file=sys.stderr)
+        return 1
+    if ranks != n or connected != n:
+        print("bench.py: asked for {} ranks, the result line reports n_gpus {} with {} ranks connected".format(
+            n, ranks, connected), file=sys.stderr)
+        return 1
+    return 0
+
+
+def launch_check(args):
+    """--launch-check: the ranks meet on the control plane (gloo) and are counted."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    ranks, world = int(t.item()), dist.get_world_size()
+    if dist.get_rank() == 0:
+        print(json.dumps({"launch_check": True, "ranks": ranks, "world_size": world,
+                          "n_gpus": args.gpus, "config": {"ranks": ranks, "transport": "none (rendezvous only)"}}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ranks == args.gpus else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,7 +193,23 @@ def main():
     ap.add_argument("--options", type=str, default="")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank joins the control group "
+                    "(gloo), the ranks are counted and rank 0 prints the count; "
+                    "no GPU is touched (tests of the launcher)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process only launches the ranks
+        # (it has not imported torch or touched a GPU) and relays rank 0's line
+        raise SystemExit(launch_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("--gpus {} does not match WORLD_SIZE {}".format(args.gpus, world))
+    if args.launch_check:
+        raise SystemExit(launch_check(args))
 
     import torch
     import stencilflow_amd as sf
@@ -126,9 +219,6 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # test hook: all ranks on device 0 with the exchange staged through gloo
@@ -223,7 +313,10 @@ def main():
                 msg = "{}: {}".format(type(exc).__name__, str(exc).splitlines()[0][:120] if str(exc) else "")
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            count = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(count, op=dist.ReduceOp.SUM)
             if int(flag.item()) == 1:
+                ranks_connected, rung_used = int(count.item()), rung
                 exchanger = candidate
                 transport = {"rccl": "RCCL send/recv on device buffers",
                              "shm": "pinned host memory shared by the ranks, stream-ordered flags",
@@ -234,6 +327,8 @@ def main():
                 candidate.close()
         if exchanger is None:
             raise SystemExit("no halo transport works: " + "; ".join(why))
+        if ranks_connected != world:
+            raise SystemExit("{} of {} ranks connected over {}".format(ranks_connected, world, rung_used))
         if why:
             transport += " (" + "; ".join(why) + ")"
         # The schedule is chosen by measurement, alike on all ranks.  With halos twice
@@ -374,26 +469,37 @@ def main():
             "decomposition": ("slab{} (halo {} planes, one exchange per {} launches, {})".format(
                 slab_world, runner.halo, runner.halo // max(1, runner.steps[0][1]), transport)
                 if multi else "single"),
+            "ranks": ranks_connected if multi else 1,
+            "transport": rung_used if multi else "none (single GPU)",
         },
     }
     if not multi:
         stats = plan.kernel_stats()
         launches = plan.num_launches * args.steps
         name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"])
-        alg = cells * bpu / launches  # 2 * sizeof(dtype) per cell update
+        fused = args.stages / plan.num_launches  # operators evaluated per launch
         avg_s = kernel_ms * 1e-3 / launches
-        achieved = alg / avg_s
+        # bytes a launch must move whatever it fuses: the field once in, once out
+        compulsory = float(np.prod(shape)) * bpu
+        alg = cells * bpu / launches  # SURVEY §8(d): 2 * sizeof(dtype) per cell update
+        traffic = measured_traffic(name)
+        moved = traffic if traffic is not None else compulsory
         result["roofline"] = {
             "bound": "hbm",
             "kernel": name,
-            "achieved": achieved / 1e9,
+            "achieved": moved / avg_s / 1e9,
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK,
-            "traffic": measured_traffic(name),
-            "algorithmic_bytes_per_launch": alg,
+            "frac": moved / avg_s / HBM_PEAK,
+            "basis": "pmc" if traffic is not None else "compulsory",
+            "traffic": traffic,
+            "compulsory_bytes_per_launch": compulsory,
             "avg_launch_us": avg_s * 1e6,
             "launches": launches,
+            "fused_operators": fused,
+            "algorithmic_bytes_per_launch": alg,
+            "algorithmic_achieved": alg / avg_s / 1e9,
+            "algorithmic_frac": alg / avg_s / HBM_PEAK,
         }
         result["config"]["schedule"] = plan.describe().splitlines()[1].strip()
         if not args.no_cpu_baseline and rank == 0 and args.workload == "c3":

@@ -2,7 +2,12 @@
 """Command line of the driver.  Flag names, defaults and the positional
 arguments are those of the reference's bin/run_program.py (:12-37) so existing
 invocations keep working; flags that only steer the FPGA toolchain are accepted
-and ignored.  Extra: ``-device``, ``-options`` (backend tuning overrides)."""
+and ignored.  Extra: ``-device``, ``-options`` (backend tuning overrides) and
+``-reference-checker module:function`` (or ``$SF_REFERENCE_CHECKER``): the CPU
+checker ``-compare-to-reference`` compares against.  The product ships none --
+results never come from a CPU path -- so the flag needs one named explicitly,
+e.g. ``-reference-checker tests.reference_provider:reference_outputs`` in a
+checkout of this repository."""
 import argparse
 import os
 import sys
@@ -23,6 +28,8 @@ VALUED = [
     ("log-level", dict(type=int, choices=[0, 1, 2, 3], default=1)),
     ("device", dict(type=int, default=0)),
     ("options", dict(type=str, default=None, help="e.g. 'fuse=2;k1.rj=5'")),
+    ("reference-checker", dict(type=str, default=os.environ.get("SF_REFERENCE_CHECKER"),
+                               help="module:function(stencil_file, input_arrays) -> {output: ndarray}")),
 ]
 
 
@@ -40,10 +47,10 @@ def build_parser():
 def main(argv=None):
     args = vars(build_parser().parse_args(argv))
     args["log_level"] = stencilflow_amd.LogLevel(args["log_level"])
-    if args["compare_to_reference"]:
-        # the CPU checker lives with the tests, not in the product
-        from tests.reference_provider import register
-        register()
+    checker = args.pop("reference_checker")
+    if checker:
+        from stencilflow_amd.run_program import load_reference_backend
+        load_reference_backend(checker)
     return stencilflow_amd.run_program(**args)
 
 

@@ -60,6 +60,16 @@ int sf_plan_create(const char* sfir_text, int device, const char* options,
 
 int sf_plan_destroy(sf_plan* plan);
 
+/* Code objects are cached in the process and on disk ($SF_HIP_CACHE_DIR, default
+ * ~/.cache/stencilflow_amd; "off" disables; the role of the reference's
+ * `-use-cached-sdfg`, stencilflow/run_program.py:69-73,83-88).  Counters of this
+ * process since it loaded the library: objects taken from disk, objects
+ * compiled, and cached objects that were rejected by the loader and rebuilt.
+ * `drop_process_level` != 0 also empties the in-process level, so that the next
+ * plan goes to disk again (tests).  Any pointer may be NULL. */
+int sf_code_cache_stats(long* disk_hits, long* compiled, long* rebuilt,
+                        int drop_process_level);
+
 /* Introspection: the argument lists `sf_plan_run` expects, in order.
  * Arrays first (program order), then nothing else: 0-D inputs are scalars. */
 int sf_plan_num_inputs(const sf_plan* plan);   /* array inputs   */

@@ -44,6 +44,7 @@ API = [
     ("sf_device_count", _I, []),
     ("sf_plan_create", _I, [_S, _I, _S, _PP]),
     ("sf_plan_destroy", _I, [_P]),
+    ("sf_code_cache_stats", _I, [ctypes.POINTER(ctypes.c_long)] * 3 + [_I]),
     ("sf_plan_num_inputs", _I, [_P]),
     ("sf_plan_num_scalars", _I, [_P]),
     ("sf_plan_num_outputs", _I, [_P]),
@@ -126,6 +127,14 @@ def _check(status):
         return status
     msg = load_library().sf_last_error().decode()
     raise _STATUS_EXC.get(status, RuntimeError)(msg)
+
+
+def code_cache_stats(drop_process_level=False):
+    """(objects taken from the on-disk cache, objects compiled, cached objects the
+    loader rejected and that were rebuilt) in this process so far."""
+    vals = [ctypes.c_long(0) for _ in range(3)]
+    _check(load_library().sf_code_cache_stats(*[ctypes.byref(v) for v in vals], 1 if drop_process_level else 0))
+    return tuple(v.value for v in vals)
 
 
 def _options_text(options):
@@ -306,9 +315,11 @@ class Plan:
         return buf.value, depth.value
 
     def step_inputs(self, step):
-        ids = (ctypes.c_int * 16)()
-        n = _check(self._lib.sf_plan_step_inputs(self._h, step, ids, 16))
-        return [ids[i] for i in range(min(n, 16))]
+        # the call returns how many buffers the step reads: size the array from that
+        n = _check(self._lib.sf_plan_step_inputs(self._h, step, None, 0))
+        ids = (ctypes.c_int * max(1, n))()
+        n = _check(self._lib.sf_plan_step_inputs(self._h, step, ids, n))
+        return [ids[i] for i in range(n)]
 
     def step_output(self, step):
         return _check(self._lib.sf_plan_step_output(self._h, step))

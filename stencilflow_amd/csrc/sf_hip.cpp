@@ -12,6 +12,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -67,6 +68,7 @@ struct CompiledKernel {
   double updates_per_launch = 0, alg_bytes_per_launch = 0;
   // from the code object's amdhsa metadata (msgpack note)
   int vgprs = -1, agprs = -1, sgprs = -1, spills = -1, scratch = -1, lds = -1;
+  bool from_disk = false;  // the code object came from the on-disk cache
 };
 
 struct Buffer {
@@ -210,14 +212,60 @@ static std::string disk_cache_path(const std::string& key) {
   const size_t slash = dir.rfind('/');
   if (slash != std::string::npos && slash > 0) ::mkdir(dir.substr(0, slash).c_str(), 0755);
   if (::mkdir(dir.c_str(), 0755) != 0 && errno != EEXIST) return "";
-  int major = 0, minor = 0;
+  // the compiler that would produce this object: hipRTC major.minor, the HIP
+  // runtime's full version number (patch level included) and the build id of the
+  // ROCm headers this library was compiled against
+  int major = 0, minor = 0, runtime = 0;
   hiprtcVersion(&major, &minor);
+  (void)hipRuntimeGetVersion(&runtime);
   const std::string salted = key + "\nhiprtc " + std::to_string(major) + "." + std::to_string(minor) +
+                             " runtime " + std::to_string(runtime) + " build " + HIP_VERSION_GITHASH +
                              "\ngfx950 -O3 -std=c++17 -ffp-contract=off";
   char name[40];
   std::snprintf(name, sizeof name, "%016llx%08x", (unsigned long long)fnv1a(salted), (unsigned)salted.size());
   return dir + "/" + name + ".co";
 }
+
+// Cache file = 24-byte header {magic "SFCO0002", payload bytes, FNV-1a of the
+// payload} + the code object.  A file that is truncated, damaged or of another
+// format is deleted and the kernel recompiled.
+static const char kCacheMagic[9] = "SFCO0002";
+
+static bool read_cache_file(const std::string& path, std::vector<char>& code) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::vector<char> blob((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  f.close();
+  bool ok = blob.size() > 24 && std::memcmp(blob.data(), kCacheMagic, 8) == 0;
+  if (ok) {
+    uint64_t size = 0, hash = 0;
+    std::memcpy(&size, blob.data() + 8, 8);
+    std::memcpy(&hash, blob.data() + 16, 8);
+    ok = size == blob.size() - 24 && size > 4 && std::memcmp(blob.data() + 24, "\177ELF", 4) == 0 &&
+         hash == fnv1a(std::string(blob.data() + 24, blob.size() - 24));
+  }
+  if (!ok) {
+    std::remove(path.c_str());  // stale or corrupt: never hand it to the loader
+    return false;
+  }
+  code.assign(blob.begin() + 24, blob.end());
+  return true;
+}
+
+static void write_cache_file(const std::string& path, const std::vector<char>& code) {
+  const std::string tmp = path + "." + std::to_string((long)getpid());
+  std::ofstream f(tmp, std::ios::binary);
+  if (!f) return;
+  const uint64_t size = code.size(), hash = fnv1a(std::string(code.data(), code.size()));
+  f.write(kCacheMagic, 8);
+  f.write(reinterpret_cast<const char*>(&size), 8);
+  f.write(reinterpret_cast<const char*>(&hash), 8);
+  f.write(code.data(), (std::streamsize)code.size());
+  f.close();
+  if (!f || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+}
+
+static std::atomic<long> g_cache_hits{0}, g_cache_misses{0}, g_cache_recompiles{0};
 
 static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& source) {
   auto it = pl.kernel_by_source.find(source);
@@ -238,24 +286,14 @@ static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::stri
   if (!cached) {
     // second level: code objects on disk, keyed by source, name and hipRTC version
     const std::string path = disk_cache_path(key);
-    if (!path.empty()) {
-      std::ifstream f(path, std::ios::binary);
-      if (f) {
-        k.code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-        cached = !k.code.empty();
-      }
-    }
-    if (!cached) {
+    if (!path.empty()) cached = read_cache_file(path, k.code);
+    if (cached) {
+      k.from_disk = true;
+      ++g_cache_hits;
+    } else {
       compile_kernel(k);
-      if (!path.empty()) {
-        const std::string tmp = path + "." + std::to_string((long)getpid());
-        std::ofstream f(tmp, std::ios::binary);
-        if (f) {
-          f.write(k.code.data(), (std::streamsize)k.code.size());
-          f.close();
-          if (std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
-        }
-      }
+      ++g_cache_misses;
+      if (!path.empty()) write_cache_file(path, k.code);
     }
     std::lock_guard<std::mutex> lock(g_code_cache_mutex);
     g_code_cache[key] = k.code;
@@ -898,7 +936,11 @@ static void build_plan(sf_plan& pl) {
       st.halo_depth = depth;
       st.halo_buf = hb;
     }
-    if (pl.halo > 0 && st.halo_depth > pl.halo)
+    // a rank with a neighbour reads `halo_depth` planes of that neighbour's slab:
+    // they must exist in the local buffers (halo = 0 is only valid for a slab that
+    // touches both ends of the global domain)
+    const bool has_neighbour = pl.goff > 0 || pl.goff + pl.n_local < P.n[0];
+    if (has_neighbour && st.halo_buf >= 0 && st.halo_depth > pl.halo)
       throw Error(SF_ERR_INVALID, "slab halo is shallower than a launch's reach; raise the halo");
     CompiledKernel& ck = pl.kernels[st.ck];
     ck.updates_per_launch = cells * (double)st.kernels.size();
@@ -928,8 +970,32 @@ static void ensure_device(sf_plan& pl) {
   SF_HIP_CHECK(hipEventCreate(&pl.ev_begin));
   SF_HIP_CHECK(hipEventCreate(&pl.ev_end));
   for (auto& k : pl.kernels) {
-    SF_HIP_CHECK(hipModuleLoadData(&k.mod, k.code.data()));
-    SF_HIP_CHECK(hipModuleGetFunction(&k.fn, k.mod, k.name.c_str()));
+    hipError_t e = hipModuleLoadData(&k.mod, k.code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&k.fn, k.mod, k.name.c_str());
+    if (e != hipSuccess && k.from_disk) {
+      // a cached object the loader rejects (built by another compiler patch level
+      // ...): drop it from both cache levels, recompile once and try again
+      (void)hipGetLastError();
+      if (k.mod) (void)hipModuleUnload(k.mod);
+      k.mod = nullptr;
+      k.fn = nullptr;
+      const std::string key = k.name + "\n" + k.source;
+      const std::string path = disk_cache_path(key);
+      if (!path.empty()) std::remove(path.c_str());
+      compile_kernel(k);
+      ++g_cache_recompiles;
+      k.from_disk = false;
+      read_metadata(k);
+      {
+        std::lock_guard<std::mutex> lock(g_code_cache_mutex);
+        g_code_cache[key] = k.code;
+      }
+      if (!path.empty()) write_cache_file(path, k.code);
+      e = hipModuleLoadData(&k.mod, k.code.data());
+      if (e == hipSuccess) e = hipModuleGetFunction(&k.fn, k.mod, k.name.c_str());
+    }
+    if (e != hipSuccess)
+      throw Error(SF_ERR_DEVICE, "loading code object of " + k.name + ": " + hipGetErrorString(e));
   }
   for (auto& b : pl.buffers) {
     SF_HIP_CHECK(hipMalloc(&b.d, b.bytes()));
@@ -976,6 +1042,18 @@ static void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, i
     throw Error(SF_ERR_INVALID, "plane range outside the slab and its halo");
   const bool second = i_begin2 < i_end2;
   if (i_begin >= i_end && !second) return;
+  // the planes a range READS must exist too: on a side with a neighbouring slab
+  // the launch reaches `halo_depth` planes beyond the range it writes
+  if (st.halo_buf >= 0 && st.halo_depth > 0) {
+    const int reach = st.halo_depth;
+    const bool lower_neighbour = pl.goff > 0, upper_neighbour = pl.goff + pl.n_local < P.n[0];
+    const int firsts[2] = {i_begin, i_begin2}, lasts[2] = {i_end, i_end2};
+    for (int r = 0; r < 2; ++r) {
+      if (firsts[r] >= lasts[r]) continue;
+      if ((lower_neighbour && firsts[r] - reach < lo_limit) || (upper_neighbour && lasts[r] + reach > hi_limit))
+        throw Error(SF_ERR_INVALID, "plane range reads beyond the halo of a slab with a neighbour");
+    }
+  }
   if (P.num_scalar_inputs > 0 && !pl.scalars_set)
     throw Error(SF_ERR_STATE, "the program has 0-D inputs: call sf_plan_set_scalars first");
   CompiledKernel& ck = pl.kernels[st.ck];
@@ -1312,6 +1390,17 @@ int sf_plan_destroy(sf_plan* plan) {
   SF_API_END
 }
 
+int sf_code_cache_stats(long* disk_hits, long* compiled, long* rebuilt, int drop_process_level) {
+  if (disk_hits) *disk_hits = sf::g_cache_hits.load();
+  if (compiled) *compiled = sf::g_cache_misses.load();
+  if (rebuilt) *rebuilt = sf::g_cache_recompiles.load();
+  if (drop_process_level) {
+    std::lock_guard<std::mutex> lock(sf::g_code_cache_mutex);
+    sf::g_code_cache.clear();
+  }
+  return SF_OK;
+}
+
 int sf_plan_num_inputs(const sf_plan* p) { return p ? p->P.num_inputs : SF_ERR_INVALID; }
 int sf_plan_num_scalars(const sf_plan* p) { return p ? p->P.num_scalar_inputs : SF_ERR_INVALID; }
 int sf_plan_num_outputs(const sf_plan* p) { return p ? p->P.num_outputs : SF_ERR_INVALID; }
@@ -1459,8 +1548,7 @@ int sf_plan_step_halo(const sf_plan* p, int step, int* buffer_id, int* depth) {
 int sf_plan_step_inputs(const sf_plan* p, int step, int* buffer_ids, int capacity) {
   if (!p || step < 0 || step >= (int)p->steps.size()) return SF_ERR_INVALID;
   const auto& in = p->steps[step].in_bufs;
-  for (int i = 0; i < (int)in.size() && i < capacity; ++i)
-    if (buffer_ids) buffer_ids[i] = in[i];
+  for (int i = 0; buffer_ids && i < (int)in.size() && i < capacity; ++i) buffer_ids[i] = in[i];
   return (int)in.size();
 }
 int sf_plan_step_output(const sf_plan* p, int step) {

@@ -39,6 +39,19 @@ def set_reference_backend(fn):
     return prev
 
 
+def load_reference_backend(spec):
+    """Register the checker named ``module:function`` (the command line's
+    ``-reference-checker``).  Opt-in only: nothing is looked up by default."""
+    import importlib
+    module, _, attr = spec.partition(":")
+    if not module or not attr:
+        raise ValueError("reference checker must be given as module:function, got {!r}".format(spec))
+    fn = getattr(importlib.import_module(module), attr)
+    if not callable(fn):
+        raise ValueError("{} is not callable".format(spec))
+    return set_reference_backend(fn)
+
+
 class _Log:
     def __init__(self, level):
         self.level = level

@@ -1,0 +1,68 @@
+"""`python bench.py --gpus N` as a plain command: the process launches the N
+ranks itself before touching a GPU, relays rank 0's line and fails loudly when
+fewer than N ranks took part (the reference's counterpart
+is `mpirun -n N bin/run_distributed_program.py`,
+bin/run_distributed_program.py:98-100,283-299)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e,
+                          cwd=ROOT)
+
+
+def _line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_plain_command_launches_two_ranks_over_gloo():
+    """World 2 on CPU: self-launch, rendezvous on the gloo control plane, ranks
+    counted, rank 0's line relayed by the parent."""
+    r = _run(["--gpus", "2", "--launch-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _line(r.stdout)
+    assert rec["launch_check"] and rec["ranks"] == 2 and rec["world_size"] == 2 and rec["n_gpus"] == 2
+
+
+def test_gpus_must_match_the_world_a_launcher_made():
+    r = _run(["--gpus", "2", "--launch-check"], env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
+def test_plain_multi_gpu_command_never_degrades_to_one_gpu():
+    """Without GPUs the ranks cannot run; the plain command must then fail, not
+    print a one-GPU line (what round 1's bench.py did when WORLD_SIZE was unset)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("meant for the CPU-only container")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "32", "--stages", "8"])
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_plain_command_two_ranks_on_this_gpu():
+    """The whole N = 2 path from the plain command on a one-GPU box: both ranks on
+    device 0 (test hook), so RCCL cannot connect them and the ladder lands on the
+    shared-memory transport; the line must report 2 ranks, connected."""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64", "--stages", "24"],
+             env={"SF_BENCH_SINGLE_DEVICE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _line(r.stdout)
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks"] == 2
+    assert rec["config"]["transport"] in ("shm", "gloo", "rccl")
+    assert "128x64x64" in rec["config"]["workload"] and rec["value"] > 0

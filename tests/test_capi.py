@@ -46,7 +46,9 @@ def test_fusion_and_buffer_reuse(tmp_path):
         # input + output + two ping-pong temporaries (the reference keeps one
         # transient per stage, sdfg_generator.py:626-630)
         assert "4 device buffers" in plan.describe()
-        assert "__shfl_up" in plan.kernel_source(0)
+        # the innermost-dimension halo travels through the DPP data path
+        src = plan.kernel_source(0)
+        assert "#define SF_DPP 4" in src and "__builtin_amdgcn_update_dpp" in src
     with backend.Plan(lower(chain), options={"fuse": 3}) as plan:
         assert plan.num_launches == 4 and len(plan.kernel_names()) == 2
     c5 = programs.write_program(
@@ -177,3 +179,72 @@ def test_autotune_compiles_alternative_tile_shapes(tmp_path):
         assert len(names) == base + 2 and all(n.startswith("sf_star3d_f32_t2") for n in names), names
     with pytest.raises(ValueError):
         Plan(sfir, options={"autotune": 99})
+
+
+def _cache_files(directory):
+    return sorted(f for f in os.listdir(directory) if f.endswith(".co"))
+
+
+def test_code_object_cache_round_trip_and_damage(tmp_path, monkeypatch):
+    """The on-disk cache of compiled kernels (the role of `-use-cached-sdfg`,
+    reference run_program.py:69-73,83-88): a second plan of the same program takes
+    its objects from disk; a truncated, a garbled and a foreign file are deleted
+    and the kernel is compiled again -- never handed to the loader."""
+    cache = tmp_path / "cache"
+    monkeypatch.setenv("SF_HIP_CACHE_DIR", str(cache))
+    path = programs.write_program(programs.jacobi3d((24, 40, 72), 4, bc_value=0.375),
+                                  str(tmp_path / "cached.json"))
+    sfir = lower(sf.KernelChainGraph(path))
+
+    def plan_once():
+        backend.code_cache_stats(drop_process_level=True)
+        before = backend.code_cache_stats()
+        with backend.Plan(sfir, options={"fuse": 2}) as plan:
+            resources = plan.kernel_resources()
+        after = backend.code_cache_stats()
+        return after[0] - before[0], after[1] - before[1], resources
+
+    hits, compiled, first = plan_once()
+    assert hits == 0 and compiled >= 1
+    files = _cache_files(str(cache))
+    assert len(files) == compiled
+    hits, compiled2, second = plan_once()
+    assert hits == compiled and compiled2 == 0 and second == first  # same objects, read from disk
+    target = os.path.join(str(cache), files[0])
+    good = open(target, "rb").read()
+    for damaged in (good[:len(good) // 2],                       # truncated
+                    good[:64] + bytes(len(good) - 64),           # payload zeroed: digest mismatch
+                    b"not a code object at all"):                # foreign file
+        with open(target, "wb") as f:
+            f.write(damaged)
+        hits, compiled3, third = plan_once()
+        assert compiled3 == 1 and hits == len(files) - 1 and third == first
+        assert open(target, "rb").read() == good  # rewritten by the recompile
+
+
+def test_code_object_cache_can_be_switched_off(tmp_path, monkeypatch):
+    monkeypatch.setenv("SF_HIP_CACHE_DIR", "off")
+    path = programs.write_program(programs.jacobi2d((40, 72), 3, bc_value=0.625), str(tmp_path / "nc.json"))
+    backend.code_cache_stats(drop_process_level=True)
+    before = backend.code_cache_stats()
+    with backend.Plan(lower(sf.KernelChainGraph(path))):
+        pass
+    with backend.Plan(lower(sf.KernelChainGraph(path))):
+        pass
+    after = backend.code_cache_stats()
+    assert after[0] == before[0]  # nothing comes from disk
+
+
+def test_slab_halo_must_cover_the_reach_of_a_rank_with_neighbours(tmp_path):
+    """A slab that has a neighbour reads that neighbour's planes: a plan whose halo
+    is shallower than a launch's reach is refused (also halo = 0), while a slab
+    touching both ends of the domain needs none."""
+    path = programs.write_program(programs.jacobi3d((32, 16, 32), 4), str(tmp_path / "s.json"))
+    sfir = lower(sf.KernelChainGraph(path))
+    for slab in ("8:16:0", "8:16:1", "0:16:1", "16:32:0"):
+        with pytest.raises(ValueError, match="halo is shallower"):
+            backend.Plan(sfir, options={"fuse": 2, "slab": slab})
+    with backend.Plan(sfir, options={"fuse": 2, "slab": "8:16:2"}) as plan:
+        assert plan.num_launches == 2
+    with backend.Plan(sfir, options={"fuse": 2, "slab": "0:32:0"}) as plan:
+        assert plan.num_launches == 2

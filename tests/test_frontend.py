@@ -162,10 +162,38 @@ def test_thousand_stage_chain_is_linear_time(tmp_path):
     assert chain.algorithmic_bytes() == 512**3 * 1000 * 8
 
 
+def test_synthesize_reproduces_the_reference_generator(golden_dir, tmp_path):
+    """bin/synthesize.py of this repository writes, for the same command line, the
+    same file name and the same bytes as the reference's bin/synthesize.py
+    (:60-294) did: fixtures tests/golden/synthesize/*.json were written by the
+    reference generator itself (tests/golden/make_synthesize_fixtures.py) --
+    cross / box / diffusion / hotspot, 1-D / 2-D / 3-D, forks, fractional extra
+    fields, vectorize, and the 1000-stage C3 program (by digest)."""
+    import hashlib
+    import subprocess
+    import sys
+    root = os.path.dirname(golden_dir.rstrip("/"))
+    root = os.path.dirname(root)
+    with open(os.path.join(golden_dir, "synthesize", "index.json")) as f:
+        index = json.load(f)
+    assert len(index) >= 15
+    for case in index:
+        r = subprocess.run([sys.executable, os.path.join(root, "bin", "synthesize.py")] + case["args"],
+                           cwd=str(tmp_path), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.strip() == "Wrote synthetic stencil to: " + case["file"], case["args"]
+        with open(str(tmp_path / case["file"]), "rb") as f:
+            mine = f.read()
+        if "sha256" in case:
+            assert len(mine) == case["bytes"] and hashlib.sha256(mine).hexdigest() == case["sha256"], case["file"]
+        else:
+            with open(os.path.join(golden_dir, "synthesize", case["file"]), "rb") as f:
+                assert mine == f.read(), case["file"]
+
+
 def test_synthesize_conventions():
-    """Own workload generator follows bin/synthesize.py's conventions (checked
-    against the reference generator's output when this was written: identical
-    JSON for cross / box / diffusion / hotspot, forks, fractional extra fields)."""
+    """Spot checks of the generator's conventions as Python calls (the byte-level
+    comparison with the reference generator is the test above)."""
     from stencilflow_amd.programs import synthesize
     prog, name = synthesize("float32", 3, 0, 16, 16, 32, 1, 1, 1)
     assert name == "float32_3_0_16_16_32_1_1_1_0p0_2_2_cross_1.json"

@@ -1,0 +1,132 @@
+"""Vectors produced by the REFERENCE itself: its ``Simulator`` run on small
+float32 / mixed-dtype programs and on BASELINE.json's configs[0] (jacobi3d 32^3,
+8 operators, float32), captured by tests/golden/make_simulator_fixtures.py into
+tests/golden/simulator_vectors.json (+ raw ``c1_*.dat`` files).
+
+What they pin.  The Simulator evaluates an operator as
+``data_type(eval_expr(var_map, computation))`` on NumPy scalars and Python
+floats (reference stencilflow/kernel.py:700-709), i.e. with NumPy's typing of
+literals, while the reference's CPU program is DaCe-generated C++.  So
+
+* the oracle evaluated with NumPy's literal typing (``typing="nep50"``) must
+  reproduce every vector BIT FOR BIT -- this pins indexing, boundary selection,
+  operand order, chain mechanics and dtype casts of the float32 path on data
+  that come from the reference;
+* the oracle under its own contract (C++ typing: DESIGN.md §2) and the HIP
+  backend must agree with the vectors to within the tolerance BASELINE.json's
+  north_star states, 1e-6 relative -- measured against the largest magnitude of
+  the field (a single operator differs from NumPy's typing by at most one
+  float32 rounding of a sum; for results that cancel to ~0 "relative to the
+  result" is not meaningful);
+* programs whose arithmetic is exact in float32 (``*_exact``, the fork/join and
+  the float64 program) must agree bit for bit under both typings.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, numpy_oracle as npo
+
+TOL = 1e-6  # BASELINE.json north_star: "within 1e-6 relative for float32"
+BIT_EXACT_UNDER_BOTH_TYPINGS = {"f32_jacobi7_exact", "mixed_to_f64", "f32_box_exact", "f32_fork_join"}
+
+
+def _vectors(golden_dir):
+    with open(os.path.join(golden_dir, "simulator_vectors.json")) as f:
+        return json.load(f)
+
+
+def _names():
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "simulator_vectors.json")
+    with open(here) as f:
+        return sorted(json.load(f)["programs"])
+
+
+def _expected(entry):
+    dims = entry["program"]["dimensions"]
+    return {k: np.array(v["values"], dtype=v["dtype"]).reshape(dims) for k, v in entry["result"].items()}
+
+
+def _within_tolerance(expected, got):
+    scale = float(np.abs(expected).max())
+    return float(np.abs(expected.astype(np.float64) - got.astype(np.float64)).max()) <= TOL * scale
+
+
+def test_fixture_inventory(golden_dir):
+    v = _vectors(golden_dir)
+    assert "Simulator" in v["source"]
+    assert len(v["programs"]) >= 9 and "f32_chain8" in v["programs"]
+    assert set(v["large"]) == {"c1_file_input", "c1_random_input"}
+
+
+@pytest.mark.parametrize("name", _names())
+def test_oracle_reproduces_the_reference_simulator(golden_dir, name):
+    entry = _vectors(golden_dir)["programs"][name]
+    expected = _expected(entry)
+    weak = npo.run_reference(entry["program"], typing="nep50")
+    own = npo.run_reference(entry["program"])
+    compiled = c_oracle.CompiledReference(entry["program"]).run()
+    for out, exp in expected.items():
+        assert weak[out].dtype == exp.dtype
+        assert np.array_equal(weak[out], exp), (name, out)  # bit for bit
+        assert np.array_equal(own[out], compiled[out]), (name, out)  # NumPy == C restatement
+        if name in BIT_EXACT_UNDER_BOTH_TYPINGS:
+            assert np.array_equal(own[out], exp), (name, out)
+        else:
+            assert _within_tolerance(exp, own[out]), (name, out)
+
+
+def _c1(golden_dir, programs_dir, tag):
+    info = _vectors(golden_dir)["large"][tag]
+    expected = np.fromfile(os.path.join(golden_dir, info["output"]), np.float32).reshape(info["shape"])
+    inputs = None
+    if info["input"]:
+        inputs = {"a": np.fromfile(os.path.join(golden_dir, info["input"]), np.float32).reshape(info["shape"])}
+    path = os.path.join(programs_dir, "jacobi3d_32x32x32_8itr_8vec.json")
+    return path, inputs, expected
+
+
+@pytest.mark.parametrize("tag", ["c1_file_input", "c1_random_input"])
+def test_baseline_config0_against_the_reference_simulator(golden_dir, programs_dir, tag):
+    """BASELINE.json configs[0]: the reference's own jacobi3d_32x32x32_8itr_8vec.json."""
+    path, inputs, expected = _c1(golden_dir, programs_dir, tag)
+    weak = npo.run_reference(path, inputs=inputs, input_directory=programs_dir, typing="nep50")["b7"]
+    assert np.array_equal(weak, expected)  # bit for bit, 32768 values, 8 operators deep
+    own = npo.run_reference(path, inputs=inputs, input_directory=programs_dir)["b7"]
+    assert _within_tolerance(expected, own)
+    # at this depth the two typings also agree point by point (tests/test_rounding_envelope.py)
+    assert npo.max_rel_err(expected, own) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", _names())
+def test_hip_against_the_reference_simulator(golden_dir, tmp_path, name):
+    from tests.test_gpu_parity import _inputs_of, _run_gpu
+    entry = _vectors(golden_dir)["programs"][name]
+    path = str(tmp_path / (name + ".json"))
+    with open(path, "w") as f:
+        json.dump(entry["program"], f)
+    ins = _inputs_of(path)
+    got, _ = _run_gpu(path, ins)
+    own = npo.run_reference(path, inputs=ins)
+    for out, exp in _expected(entry).items():
+        assert got[out].dtype == exp.dtype
+        assert np.array_equal(got[out], own[out]), (name, out)  # HIP == oracle, bit for bit
+        if name in BIT_EXACT_UNDER_BOTH_TYPINGS:
+            assert np.array_equal(got[out], exp), (name, out)  # HIP == reference, bit for bit
+        else:
+            assert _within_tolerance(exp, got[out]), (name, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["c1_file_input", "c1_random_input"])
+@pytest.mark.parametrize("options", [None, {"fuse": 1}, {"generic_only": 1}])
+def test_hip_baseline_config0_against_the_reference_simulator(golden_dir, programs_dir, tag, options):
+    from tests.test_gpu_parity import _inputs_of, _run_gpu
+    path, inputs, expected = _c1(golden_dir, programs_dir, tag)
+    ins = inputs or _inputs_of(path, programs_dir)
+    got, _ = _run_gpu(path, ins, options=options)
+    assert _within_tolerance(expected, got["b7"])
+    assert npo.max_rel_err(expected, got["b7"]) <= TOL

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Fold the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh into the
 JSON bench.py reads for `roofline.traffic` (HBM bytes per launch of the dominant
-kernel, keyed by kernel-name prefix).  gfx950 correction per
+kernel, keyed by the FULL kernel name, which ends in the hash of the generated
+source: counters of one code object are never applied to another).  gfx950 correction per
 MI355X_MICROARCH.md (HBM / rocprofv3 section): counters are in KiB and
 FETCH_SIZE reports half of a wide coalesced read stream -> x2.
 usage: hbm_traffic.py <round-tag> <out.json>"""
@@ -41,8 +42,11 @@ def main():
         for kernel in fetch:
             if kernel not in write:
                 continue
-            prefix = re.sub(r"_[0-9a-f]{8}$", "", kernel)
-            result[prefix] = {
+            family = re.sub(r"_[0-9a-f]{8}$", "", kernel)
+            # one record per kernel family: a new code object replaces the old record
+            for old in [k for k in result if re.sub(r"_[0-9a-f]{8}$", "", k) == family]:
+                del result[old]
+            result[kernel] = {
                 "kernel": kernel,
                 "hbm_bytes_per_launch": fetch[kernel] * 1024.0 * 2.0 + write[kernel] * 1024.0,
                 "fetch_size_kb_reported": fetch[kernel],
