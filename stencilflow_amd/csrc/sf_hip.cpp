@@ -81,7 +81,8 @@ struct Buffer {
 };
 
 struct Step {
-  bool star = false;
+  bool star = false;     // plane-streaming launch (star3d.h or, with `compact`, compact3d.h)
+  bool compact = false;
   std::vector<int> kernels;    // program kernel indices fused in this launch
   int ck = -1;                 // compiled kernel
   std::vector<int> in_bufs;    // argument order
@@ -308,6 +309,12 @@ static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::stri
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static size_t star_lds_bytes(const StarCfg& c, DT dt) {
+  if (c.compact) {
+    // kernels/compact3d.h: per window a ring of images (first / last row of every
+    // thread row + the wave-edge columns of every row incl. two virtual waves)
+    const size_t win = (size_t)c.BY * 2 * c.BX * c.VK + (size_t)c.BY * c.RJ * (c.BX / 64 + 2) * 2;
+    return std::max<size_t>(1, (size_t)c.lds_images * win) * size_of(dt);
+  }
   const size_t rows = c.noj ? 0 : (size_t)c.T * c.BY * 2 * c.BX * c.VK;
   const size_t edge = (size_t)c.T * c.BY * c.RJ * (c.BX / 64 + ((c.dpp == 4 && c.BX > 64) ? 2 : 0)) * 2;
   return (rows + edge) * size_of(dt) * (c.lds_db ? 2 : 1);
@@ -329,6 +336,8 @@ static int star_regs_estimate(const StarCfg& c, DT dt) {
   // spills after all is rejected by select_star from its metadata.
   const int words = (dt == DT::F64) ? 2 : 1;
   const int P = c.RJ * c.VK;
+  if (c.compact)  // three live planes per window, one more in flight per loaded window, the gathered rows
+    return 3 * c.nwin * P * words + (1 + c.nwin - c.T) * P * words + 40 + 4 * P;
   return 3 * c.T * P * words + 20 + (33 * P) / 10 +
          ((c.prefetch2 || c.reverse == 2) ? P * words * c.pfd : 0);
 }
@@ -415,9 +424,10 @@ static long long star_chunk_length(const sf_plan& pl, const StarCfg& c, DT dt, i
   return std::max<long long>(li, 1);
 }
 
-static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
+static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, const StarCfg* proto = nullptr) {
   const Program& P = pl.P;
   StarCfg base;
+  if (proto) base = *proto;  // (compact kernels: windows and LDS images of the group)
   base.T = T;
   // one 16-byte vector per row and lane: 4 floats or 2 doubles
   base.VK = (int)pl.opt.get("k1.vk", dt == DT::F64 ? 2 : 4);
@@ -445,7 +455,7 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt) {
   // the memory operations in flight, a wave no longer drains them once per step,
   // and stage-1-first with the four-slot input ring overtakes it: C2 +10 %
   // (profiles/r01_sweep_17_buffer_io.log); k1.rev=1 remains available
-  base.reverse = (int)pl.opt.get("k1.rev", 0);
+  base.reverse = base.compact ? 1 : (int)pl.opt.get("k1.rev", 0);
   // input planes: 0 = loaded into the window slot stage 1 has just freed, 1 = into
   // staging registers a step earlier and copied, 2 = four-slot input ring (two
   // steps to land, no copy; the step loop is unrolled by 4)
@@ -618,6 +628,63 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
   return out;
 }
 
+// The same for a group of compact operators (kernels/compact3d.h).
+static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>& memo, const std::vector<int>& kernels,
+                                 DT dt) {
+  const Program& P = pl.P;
+  StarCfg probe;
+  probe.T = (int)kernels.size();
+  const std::string sig = "compact" + std::to_string(fnv1a(gen_compact(P, kernels, probe).source));
+  auto it = memo.find(sig);
+  if (it != memo.end()) return it->second;
+  const std::string prefix = std::string("sf_compact3d_") + short_of(dt) + "_t" + std::to_string(kernels.size());
+  StarChoice out;
+  std::vector<StarCfg> ranked;
+  try {
+    ranked = rank_star_cfgs(pl, (int)kernels.size(), dt, &probe);
+  } catch (const Error&) {
+    memo[sig] = out;
+    return out;
+  }
+  const bool pinned = pl.opt.kv.count("k1.bx") && pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj");
+  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
+  int rejected = 0;
+  for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {
+    StarKernelSource g = gen_compact(P, kernels, ranked[ci]);
+    int ck = -1;
+    try {
+      ck = intern_kernel(pl, prefix, g.source);
+    } catch (const Error& e) {
+      if (pinned || e.status != SF_ERR_COMPILE) throw;
+      if (pl.opt.get("debug", 0) != 0)
+        std::fprintf(stderr, "[sf_hip] compact candidate %zu/%zu rejected by the compiler: %.400s\n", ci + 1,
+                     ranked.size(), e.what());
+      ++rejected;
+      continue;
+    }
+    const CompiledKernel& k = pl.kernels[ck];
+    const int bad = std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs);
+    if (pl.opt.get("debug", 0) != 0)
+      std::fprintf(stderr,
+                   "[sf_hip] compact candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d "
+                   "scratch %d lds %d\n",
+                   ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs, k.agprs,
+                   k.spills, k.scratch, k.lds);
+    if (bad == 0 || (pinned && pl.opt.get("allow_spills", 0) != 0)) {
+      if (!out.ok) {
+        out.ok = true;
+        out.cfg = ranked[ci];
+        out.ck = ck;
+      }
+      out.alts.push_back({ranked[ci], ck});
+      if (pinned || (long long)out.alts.size() >= std::max<long long>(1, pl.opt.get("autotune", 0))) break;
+    }
+  }
+  out.sig = sig;
+  memo[sig] = out;
+  return out;
+}
+
 // One line of sf_plan_describe per launch.
 static void describe_step(std::ostringstream& desc, const sf_plan& pl, const Step& st) {
   const Program& P = pl.P;
@@ -626,7 +693,7 @@ static void describe_step(std::ostringstream& desc, const sf_plan& pl, const Ste
   desc << "  launch " << ck.name << ": ";
   for (int k : st.kernels) desc << P.kernels[k].name << " ";
   if (st.star)
-    desc << "[star T=" << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
+    desc << (st.compact ? "[compact windows " + std::to_string(st.cfg.nwin) + " T=" : std::string("[star T=")) << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
          << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " chunk "
          << star_chunk_length(pl, st.cfg, dt, (int)pl.n_local) << " lds " << star_lds_bytes(st.cfg, dt)
          << " B]";
@@ -771,7 +838,59 @@ static void build_plan(sf_plan& pl) {
         st.kernels.push_back(k);
       }
     } else {
-      st.kernels.push_back(k);
+      // compact operators (27-point neighbourhoods, one extra streamed field): 3-D programs
+      // only; an extra field needs its neighbours' planes, which a slab run does not
+      // exchange for program inputs -- such stages stay on the generic kernel there
+      const bool whole_domain = pl.halo == 0 && pl.n_local == P.n[0];
+      const bool compact_dims = P.nd == 3 && P.n[0] > 1 && P.n[1] > 1 && pl.opt.get("compact", 1) != 0;
+      CompactShape cshape;
+      bool compact = !generic_only && compact_dims && compact_eligible(P, P.kernels[k], &cshape) &&
+                     (cshape.extra.empty() || whole_domain);
+      if (compact) {
+        std::vector<int> group{k};
+        std::set<std::string> extras;
+        if (!cshape.extra.empty()) extras.insert(cshape.extra);
+        while ((int)group.size() < fuse && k + (int)group.size() < K) {
+          const int cur = group.back(), nxt = cur + 1;
+          const Kernel& kc = P.kernels[cur];
+          CompactShape nshape;
+          if (!compact_eligible(P, P.kernels[nxt], &nshape, kc.name)) break;
+          if (P.field(kc.name).role != Role::Temp) break;
+          if (consumers[kc.name] != 1) break;
+          if (P.kernels[nxt].dt != kc.dt) break;
+          if (!nshape.extra.empty()) {
+            if (!whole_domain) break;
+            bool produced_inside = false;
+            for (int g : group)
+              if (P.kernels[g].name == nshape.extra) produced_inside = true;
+            if (produced_inside) break;
+            std::set<std::string> all = extras;
+            all.insert(nshape.extra);
+            if ((int)all.size() > kMaxStarAux) break;
+            extras.swap(all);
+          }
+          group.push_back(nxt);
+        }
+        StarChoice choice;
+        while (!group.empty()) {
+          choice = select_compact(pl, star_memo, group, P.kernels[k].dt);
+          if (choice.ok) break;
+          group.pop_back();
+        }
+        if (choice.ok) {
+          st.star = true;
+          st.compact = true;
+          st.kernels = group;
+          st.cfg = choice.cfg;
+          st.ck = choice.ck;
+          st.alts = choice.alts;
+          st.sig = choice.sig;
+        } else {
+          st.kernels.push_back(k);
+        }
+      } else {
+        st.kernels.push_back(k);
+      }
     }
     k += (int)st.kernels.size();
     pl.steps.push_back(st);
@@ -801,7 +920,16 @@ static void build_plan(sf_plan& pl) {
   std::map<std::string, int> last_use; // field -> last step reading it
   auto step_reads = [&](const Step& st) {
     std::vector<std::string> r;
-    if (st.star) {
+    if (st.compact) {
+      // argument 0: the streamed field of the first stage; then the extra fields in
+      // first-use order (as gen_compact numbers them)
+      for (size_t si = 0; si < st.kernels.size(); ++si) {
+        CompactShape sh;
+        compact_eligible(P, P.kernels[st.kernels[si]], &sh, si == 0 ? std::string() : P.kernels[st.kernels[si - 1]].name);
+        if (si == 0) r.push_back(sh.primary);
+        if (!sh.extra.empty() && std::find(r.begin() + 1, r.end(), sh.extra) == r.end()) r.push_back(sh.extra);
+      }
+    } else if (st.star) {
       StarShape sh0;
       star_eligible(P, P.kernels[st.kernels[0]], &sh0);
       r.push_back(sh0.primary);  // argument 0: the streamed field
@@ -882,7 +1010,7 @@ static void build_plan(sf_plan& pl) {
     if (st.star) {
       if (star_lds_bytes(st.cfg, dt) > 160 * 1024)
         throw Error(SF_ERR_INVALID, "star kernel: tile needs more than 160 KiB of LDS");
-      StarKernelSource g = gen_star(P, st.kernels, st.cfg);
+      StarKernelSource g = st.compact ? gen_compact(P, st.kernels, st.cfg) : gen_star(P, st.kernels, st.cfg);
       st.scalars = g.scalars;
       st.scalar_offsets = g.scalar_offsets;
       st.scalars_bytes = g.scalars_bytes;

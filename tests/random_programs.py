@@ -264,3 +264,100 @@ def star_program(seed):
         if name not in text:
             del prog["inputs"][name]
     return prog
+
+
+# --- random chains of COMPACT operators (kernels/compact3d.h): any subset of the 27
+# offsets {-1,0,1}^3 of the previous stage, optionally a second full input field read
+# through such offsets, scalar / literal coefficients, int / float / shrink boundaries,
+# plain star stages in between; 3-D, awkward sizes; only + - * and selects ------------
+def compact_program(seed):
+    rng = np.random.default_rng(seed)
+    its = ["i", "j", "k"]
+    vk = int(rng.choice([4, 4, 4, 2, 1]))
+    dims = [int(rng.integers(3, 22)), int(rng.integers(3, 37)), vk * int(rng.integers(2, 36))]
+    if vk == 1 and dims[2] % 2 == 0:
+        dims[2] += 1
+    dtype = "float32" if rng.random() < 0.65 else "float64"
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": [],
+            "dimensions": dims, "program": {}}
+    extras = []
+    for n in range(int(rng.integers(0, 4))):
+        name = "e%d" % n
+        prog["inputs"][name] = {"data": "constant:0.5", "data_type": dtype}
+        extras.append(name)
+    scalars = []
+    for n in range(int(rng.integers(0, 3))):
+        name = "s%d" % n
+        prog["inputs"][name] = {"data": float(np.round(rng.uniform(-1, 1), 3)), "data_type": dtype,
+                                "input_dims": []}
+        scalars.append(name)
+
+    def access(field, off):
+        return "%s[%s]" % (field, ",".join(it if o == 0 else "%s%+d" % (it, o) for it, o in zip(its, off)))
+
+    def offsets(density, allow_diagonal=True):
+        offs = []
+        for di in (-1, 0, 1):
+            for dj in (-1, 0, 1):
+                for dk in (-1, 0, 1):
+                    nz = (di != 0) + (dj != 0) + (dk != 0)
+                    if nz > 1 and not allow_diagonal:
+                        continue
+                    if rng.random() < density:
+                        offs.append((di, dj, dk))
+        if not offs:
+            offs.append(tuple(int(v) for v in rng.integers(-1, 2, 3)))
+        return [offs[int(t)] for t in rng.permutation(len(offs))]
+
+    def bc():
+        kind = rng.random()
+        if kind < 0.1:
+            return {"type": "shrink"}
+        if kind < 0.35:
+            return {"type": "constant", "value": int(rng.integers(-1, 3))}
+        return {"type": "constant", "value": float(rng.choice(EXACT))}
+
+    stages = int(rng.integers(1, 7))
+    prev = "a"
+    for s in range(stages):
+        name = "b%d" % s
+        style = rng.random()
+        density = 1.0 if style < 0.2 else float(rng.uniform(0.15, 0.7))
+        fields = [(prev, offsets(density, allow_diagonal=style < 0.85))]
+        if extras and rng.random() < 0.5:
+            fields.append((str(rng.choice(extras)), offsets(float(rng.uniform(0.1, 0.5)), allow_diagonal=rng.random() < 0.6)))
+        terms = []
+        for f, offs in fields:
+            for off in offs:
+                r = rng.random()
+                if r < 0.6:
+                    terms.append(access(f, off))
+                elif r < 0.85 or not scalars:
+                    terms.append("%r*%s" % (float(np.round(rng.uniform(-1, 1), 4)), access(f, off)))
+                else:
+                    terms.append("%s*%s" % (rng.choice(scalars), access(f, off)))
+        terms = [terms[int(t)] for t in rng.permutation(len(terms))]
+        expr = terms[0]
+        for t in terms[1:]:
+            expr = "%s %s %s" % (expr, rng.choice(["+", "+", "-"]), t)
+            if rng.random() < 0.2:
+                expr = "(" + expr + ")"
+        if rng.random() < 0.6:
+            expr = "%r * (%s)" % (float(np.round(1.0 / max(1, len(terms)), 8)), expr)
+        if rng.random() < 0.1:
+            expr = "(%s) if %s > 0.0 else (%s - 0.5)" % (expr, access(prev, (0, 0, 0)), expr)
+        bcs = {f: bc() for f, _ in fields}
+        prog["program"][name] = {"computation_string": "%s = %s" % (name, expr),
+                                 "boundary_conditions": bcs, "data_type": dtype}
+        if s < stages - 1 and rng.random() < 0.1:
+            prog["outputs"].append(name)
+        prev = name
+    prog["outputs"].append(prev)
+    text = " ".join(k["computation_string"] for k in prog["program"].values())
+    for name in extras:
+        if (name + "[") not in text:
+            del prog["inputs"][name]
+    for name in scalars:
+        if name not in text:
+            del prog["inputs"][name]
+    return prog

@@ -109,3 +109,54 @@ def test_hip_matches_oracle_on_random_star_chains(seed, tmp_path):
         plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
         for n, got in zip(plan.output_names, outs):
             assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:400])
+
+
+COMPACT_CPU_SEEDS = list(range(0, 10))
+COMPACT_GPU_SEEDS = list(range(0, 64))
+
+
+def _compact_case(seed, tmp_path):
+    from tests.random_programs import compact_program
+    prog = compact_program(seed)
+    rng = np.random.default_rng(seed + 11)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    path = programs.write_program(prog, str(tmp_path / "p.json"))
+    return prog, ins, sf.KernelChainGraph(path), {"fuse": int(rng.integers(1, 4))}
+
+
+@pytest.mark.parametrize("seed", COMPACT_CPU_SEEDS)
+def test_random_compact_chains_plan(seed, tmp_path):
+    """Random chains of compact operators (27-point neighbourhoods, extra streamed
+    fields) are planned onto plane-streaming kernels -- kernels/compact3d.h, or
+    star3d.h where every operator of the chain happens to be a star -- never the
+    generic kernel (CPU: hipRTC only), and the two oracles agree on them."""
+    prog, ins, chain, opt = _compact_case(seed, tmp_path)
+    a = npo.run_reference(prog, inputs=ins)
+    b = c_oracle.CompiledReference(prog).run(inputs=ins)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (seed, k)
+    with Plan(lower(chain), options=opt) as plan:
+        text = plan.describe()
+        assert "[compact" in text or "[star" in text, text
+        assert "[point]" not in text, text
+        assert sorted(plan.output_names) == sorted(prog["outputs"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", COMPACT_GPU_SEEDS)
+def test_hip_matches_oracle_on_random_compact_chains(seed, tmp_path):
+    prog, ins, chain, opt = _compact_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain), options=opt) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]])
+                for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
