@@ -68,10 +68,18 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_TJI (SF_TJH - 2 * SF_T)
 #define SF_TKI (SF_TKH - 2 * SF_HK)
 
-// one image of one window
+// One image of one window = the first and last row of every thread row
+// (SF_ROWS_ELEMS) + the wave-edge words of every row, for SF_BY + 2 thread rows and
+// SF_WPR + 2 waves per row: the virtual thread rows -1 / SF_BY are never written
+// (what is read there only reaches halo rows, whose results are discarded) and the
+// virtual waves -1 / SF_WPR hold the consumer's boundary constant -- so no thread
+// tests whether a neighbour exists, and every address is ONE run-time base per
+// kind plus a compile-time offset.  The edge words of all images come first (a few
+// KB: one base register reaches all of them through the 16-bit offset field),
+// the row images follow.
 #define SF_ROWS_ELEMS (SF_BY * 2 * SF_TKH)
 #define SF_EDGE_WAVES (SF_WPR + 2)
-#define SF_EDGE_ELEMS (SF_BY * SF_RJ * SF_EDGE_WAVES * 2)
+#define SF_EDGE_ELEMS ((SF_BY + 2) * SF_RJ * SF_EDGE_WAVES * 2)
 #define SF_WIN_ELEMS (SF_ROWS_ELEMS + SF_EDGE_ELEMS)
 
 template <int I>
@@ -122,16 +130,20 @@ struct sf_win {
   static constexpr int ring = diag ? 4 : 2;  // images
 };
 
-// LDS offset (elements) of window W's image ring
+// number of the first image of window W's ring among all images
 template <int W>
 struct sf_win_base {
-  static constexpr int value = sf_win_base<W - 1>::value + (sf_win<W - 1>::lateral ? sf_win<W - 1>::ring * SF_WIN_ELEMS : 0);
+  static constexpr int value = sf_win_base<W - 1>::value + (sf_win<W - 1>::lateral ? sf_win<W - 1>::ring : 0);
 };
 template <>
 struct sf_win_base<0> {
   static constexpr int value = 0;
 };
-#define SF_LDS_ELEMS (sf_win_base<SF_NWIN>::value > 0 ? sf_win_base<SF_NWIN>::value : 1)
+#define SF_IMAGES (sf_win_base<SF_NWIN>::value)
+#define SF_LDS_ELEMS (SF_IMAGES > 0 ? SF_IMAGES * SF_WIN_ELEMS : 1)
+// element offsets of image `g` (numbered over all windows)
+#define SF_EDGE_IMAGE(g) ((g) * SF_EDGE_ELEMS)
+#define SF_ROWS_IMAGE(g) (SF_IMAGES * SF_EDGE_ELEMS + (g) * SF_ROWS_ELEMS)
 
 struct sf_state {
   sf_vec w[SF_NWIN][SF_SLOTS][SF_RJ];
@@ -141,15 +153,20 @@ struct sf_ctx {
   const sf_t* in;
   sf_auxptrs xp;
   int tx, ty, lane, wave;
+  // run-time parts of the LDS addresses (elements): this thread's vector in the first
+  // / last row of the thread row below / above (clamped at the tile's ends), in its
+  // own rows, and the edge word (thread row ty - 1, row 0, wave - 1, side 0)
+  int row_lo, row_hi, row_own, edge0;
   unsigned jmask, kmask;
   bool kvec_in, tile_inside;
   int goff, halo, cb, ce, j0, k0;
   unsigned ld_off[SF_RJ], st_off[SF_RJ];
 };
 
-__device__ __forceinline__ int sf_rows_at(int ty, int which) { return (ty * 2 + which) * SF_TKH; }
-__device__ __forceinline__ int sf_edge_at(int ty, int r, int w, int side) {
-  return SF_ROWS_ELEMS + (((ty * SF_RJ + r) * SF_EDGE_WAVES + (w + 1)) * 2 + side);
+__host__ __device__ constexpr int sf_rows_at(int ty, int which) { return (ty * 2 + which) * SF_TKH; }
+// (ty in -1 .. SF_BY, w in -1 .. SF_WPR)
+__host__ __device__ constexpr int sf_edge_at(int ty, int r, int w, int side) {
+  return ((((ty + 1) * SF_RJ + r) * SF_EDGE_WAVES + (w + 1)) * 2 + side);
 }
 
 // value of the adjacent lane through the DPP data path; lanes without a source
@@ -160,13 +177,13 @@ __device__ __forceinline__ T sf_neighbour_lane_or(T x, T edge) {
   if constexpr (sizeof(T) == 4) {
     int moved = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x), ctrl, 0xf,
                                             0xf, false);
-    asm volatile("" : "+v"(moved));  // keeps LLVM's DPP combiner off it (star3d.h)
+    asm("" : "+v"(moved));  // keeps LLVM's DPP combiner off it (star3d.h); not volatile: may move, may die
     return __builtin_bit_cast(T, moved);
   } else {
     const long long v = __builtin_bit_cast(long long, x), e = __builtin_bit_cast(long long, edge);
     int rlo = __builtin_amdgcn_update_dpp((int)(e & 0xffffffffll), (int)(v & 0xffffffffll), ctrl, 0xf, 0xf, false);
     int rhi = __builtin_amdgcn_update_dpp((int)(e >> 32), (int)(v >> 32), ctrl, 0xf, 0xf, false);
-    asm volatile("" : "+v"(rlo), "+v"(rhi));
+    asm("" : "+v"(rlo), "+v"(rhi));
     return __builtin_bit_cast(T, ((long long)rhi << 32) | (unsigned int)rlo);
   }
 }
@@ -226,61 +243,96 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const sf_t* fiel
   return v;
 }
 
-// Neighbourhood of row R of the plane stage S produces, read from window WIN
-// through mask NEED at phase PH: n[v][(d*3+e)*3+f] for the SF_VK points of the row.
-template <int WIN, unsigned NEED, int PH, int R>
-__device__ __forceinline__ void sf_gather(const sf_state& st, const sf_t* lds_all, const sf_ctx& cx,
-                                          sf_t (&n)[SF_VK][27]) {
+// Per stage and step: what a thread needs of one window beyond its own registers --
+// rows -1 and SF_RJ of the three planes (the neighbouring thread rows', from LDS)
+// and, for every source row -1..SF_RJ, the element left of its first and right of
+// its last column (the adjacent lane's, through DPP; at a wave edge the
+// neighbouring wave's, from LDS).  Filled row by row as the output rows advance
+// (sf_prepare_row), so that every lane exchange is done once per source row, not
+// once per output row that reads it.
+struct sf_nbr {
+  sf_vec lo[3], hi[3];
+  sf_t km[3][SF_RJ + 2], kp[3][SF_RJ + 2];
+};
+
+__host__ __device__ constexpr unsigned sf_plane_bits(unsigned m, int d) { return (m >> (d * 9)) & 0x1ffu; }
+
+// source row RR (-1 .. SF_RJ) of window WIN at phase PH
+template <int WIN, unsigned NEED, int PH, int RR>
+__device__ __forceinline__ void sf_prepare_row(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx) {
   constexpr int slot[3] = {PH % SF_SLOTS, (PH + 1) % SF_SLOTS, (PH + 2) % SF_SLOTS};
   constexpr bool diag = sf_win<WIN>::diag;
   // image that holds plane d: diagonal windows publish `next` every step (ring of 4:
   // next is this step's image, cur the previous one, prev the one before); star-like
   // windows publish `cur` (ring of 2)
   constexpr int image[3] = {diag ? (PH + 2) % 4 : 0, diag ? (PH + 3) % 4 : PH % 2, diag ? PH % 4 : 0};
-  const int ty = cx.ty, tx = cx.tx;
+  constexpr bool below = RR < 0, above = RR >= SF_RJ;
   sf_static_for<0, 3>([&](auto D) {
     constexpr int d = decltype(D)::value;
-    if constexpr (sf_needs_plane(NEED, d)) {
-      const sf_t* lds = lds_all + sf_win_base<WIN>::value + image[d] * SF_WIN_ELEMS;
-      sf_static_for<0, 3>([&](auto E) {
-        constexpr int e = decltype(E)::value;
-        if constexpr (sf_needs_row(NEED, d, e)) {
-          constexpr int rr = R + e - 1;            // row inside the thread, -1 / SF_RJ: the neighbouring thread row's
-          constexpr bool below = rr < 0, above = rr >= SF_RJ;
-          sf_vec row;
-          int oty = ty;                            // thread row that owns the row, and its index there
-          constexpr int orow = below ? SF_RJ - 1 : (above ? 0 : rr);
-          if constexpr (below) {
-            row = st.w[WIN][slot[d]][0];
-            if (ty > 0) {
-              oty = ty - 1;
-              row = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(ty - 1, 1) + tx * SF_VK]);
-            }
-          } else if constexpr (above) {
-            row = st.w[WIN][slot[d]][SF_RJ - 1];
-            if (ty < SF_BY - 1) {
-              oty = ty + 1;
-              row = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(ty + 1, 0) + tx * SF_VK]);
-            }
-          } else {
-            row = st.w[WIN][slot[d]][rr];
-          }
-          constexpr unsigned bits = (NEED >> ((d * 3 + e) * 3)) & 7u;
-          sf_t km_e = (sf_t)0, kp_e = (sf_t)0;
-          if constexpr ((bits & 1u) != 0)  // k-1: the lane below, or the lower wave's last element
-            km_e = sf_neighbour_lane_or<true>(row[SF_VK - 1], lds[sf_edge_at(oty, orow, cx.wave - 1, 1)]);
-          if constexpr ((bits & 4u) != 0)  // k+1
-            kp_e = sf_neighbour_lane_or<false>(row[0], lds[sf_edge_at(oty, orow, cx.wave + 1, 0)]);
-#pragma unroll
-          for (int v = 0; v < SF_VK; ++v) {
-            if constexpr ((bits & 1u) != 0) n[v][(d * 3 + e) * 3 + 0] = (v > 0) ? row[v > 0 ? v - 1 : 0] : km_e;
-            if constexpr ((bits & 2u) != 0) n[v][(d * 3 + e) * 3 + 1] = row[v];
-            if constexpr ((bits & 4u) != 0)
-              n[v][(d * 3 + e) * 3 + 2] = (v < SF_VK - 1) ? row[v < SF_VK - 1 ? v + 1 : v] : kp_e;
-          }
-        }
-      });
+    constexpr unsigned bits = sf_plane_bits(NEED, d);
+    // rows of this plane that some output row reads as its j-1 / j / j+1 neighbour
+    constexpr bool as_jm = (bits & 0x007u) != 0, as_jp = (bits & 0x1c0u) != 0;
+    constexpr bool want_row = below ? as_jm : (above ? as_jp : bits != 0);
+    constexpr bool want_km = want_row && (bits & 0x049u) != 0 && (!below || (bits & 0x001u)) && (!above || (bits & 0x040u));
+    constexpr bool want_kp = want_row && (bits & 0x124u) != 0 && (!below || (bits & 0x004u)) && (!above || (bits & 0x100u));
+    if constexpr (want_row) {
+      constexpr int g = sf_win_base<WIN>::value + image[d];
+      sf_vec row;
+      // thread row that owns the row (relative to ty), and its index there
+      constexpr int dty = below ? -1 : (above ? 1 : 0);
+      constexpr int orow = below ? SF_RJ - 1 : (above ? 0 : RR);
+      if constexpr (below) {
+        row = *reinterpret_cast<const sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_lo]);
+        nb.lo[d] = row;
+      } else if constexpr (above) {
+        row = *reinterpret_cast<const sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_hi]);
+        nb.hi[d] = row;
+      } else {
+        row = st.w[WIN][slot[d]][RR < 0 ? 0 : (RR >= SF_RJ ? SF_RJ - 1 : RR)];
+      }
+      // cx.edge0 addresses (ty - 1, row 0, wave - 1, side 0): the rest is compile-time
+      constexpr int e_lo = sf_edge_at(dty, orow, -1, 1) - sf_edge_at(-1, 0, -1, 0);
+      constexpr int e_hi = sf_edge_at(dty, orow, 1, 0) - sf_edge_at(-1, 0, -1, 0);
+      if constexpr (want_km)  // k-1: the lane below, or the lower wave's last element
+        nb.km[d][RR + 1] = sf_neighbour_lane_or<true>(row[SF_VK - 1], lds_all[SF_EDGE_IMAGE(g) + cx.edge0 + e_lo]);
+      if constexpr (want_kp)  // k+1
+        nb.kp[d][RR + 1] = sf_neighbour_lane_or<false>(row[0], lds_all[SF_EDGE_IMAGE(g) + cx.edge0 + e_hi]);
     }
+  });
+}
+
+// Neighbourhood of output row R: n[v][(d*3+e)*3+f] for the SF_VK points of the row,
+// read from window WIN through mask NEED at phase PH.
+template <int WIN, unsigned NEED, int PH, int R>
+__device__ __forceinline__ void sf_gather(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx,
+                                          sf_t (&n)[SF_VK][27]) {
+  constexpr int slot[3] = {PH % SF_SLOTS, (PH + 1) % SF_SLOTS, (PH + 2) % SF_SLOTS};
+  // source rows not prepared yet: -1, 0 and 1 before the first output row, R + 1 afterwards
+  if constexpr (R == 0) {
+    sf_prepare_row<WIN, NEED, PH, -1>(nb, st, lds_all, cx);
+    sf_prepare_row<WIN, NEED, PH, 0>(nb, st, lds_all, cx);
+  }
+  sf_prepare_row<WIN, NEED, PH, R + 1>(nb, st, lds_all, cx);
+  sf_static_for<0, 3>([&](auto D) {
+    constexpr int d = decltype(D)::value;
+    sf_static_for<0, 3>([&](auto E) {
+      constexpr int e = decltype(E)::value;
+      constexpr unsigned bits = (NEED >> ((d * 3 + e) * 3)) & 7u;
+      if constexpr (bits != 0) {
+        constexpr int rr = R + e - 1;
+        sf_vec row;
+        if constexpr (rr < 0) row = nb.lo[d];
+        else if constexpr (rr >= SF_RJ) row = nb.hi[d];
+        else row = st.w[WIN][slot[d]][rr < 0 ? 0 : (rr >= SF_RJ ? SF_RJ - 1 : rr)];
+#pragma unroll
+        for (int v = 0; v < SF_VK; ++v) {
+          if constexpr ((bits & 1u) != 0) n[v][(d * 3 + e) * 3 + 0] = (v > 0) ? row[v > 0 ? v - 1 : 0] : nb.km[d][rr + 1];
+          if constexpr ((bits & 2u) != 0) n[v][(d * 3 + e) * 3 + 1] = row[v];
+          if constexpr ((bits & 4u) != 0)
+            n[v][(d * 3 + e) * 3 + 2] = (v < SF_VK - 1) ? row[v < SF_VK - 1 ? v + 1 : v] : nb.kp[d][rr + 1];
+        }
+      }
+    });
   });
 }
 
@@ -322,6 +374,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all,
   const bool store_plane = (S == SF_T) && q >= cx.cb && q < cx.ce && plane_in;
   sf_t pad = (sf_t)0;
   if constexpr (S < SF_T) pad = sf_stage<(S < SF_T ? S + 1 : S)>::bc();
+  sf_nbr nbn, nbx;
   sf_static_for<0, SF_RJ>([&](auto RR) {
     constexpr int r = decltype(RR)::value;
     sf_t n[SF_VK][27], x[SF_VK][27];
@@ -332,8 +385,8 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all,
         n[v][b] = (sf_t)0;
         x[v][b] = (sf_t)0;
       }
-    sf_gather<src, stage::need, PH, r>(st, lds_all, cx, n);
-    if constexpr (has_x) sf_gather<xw, stage::xneed, PH, r>(st, lds_all, cx, x);
+    sf_gather<src, stage::need, PH, r>(nbn, st, lds_all, cx, n);
+    if constexpr (has_x) sf_gather<xw, stage::xneed, PH, r>(nbx, st, lds_all, cx, x);
     sf_vec o;
 #pragma unroll
     for (int v = 0; v < SF_VK; ++v) o[v] = stage::apply(n[v], x[v], sc);
@@ -378,17 +431,20 @@ __device__ __forceinline__ void sf_publish(const sf_state& st, sf_t* lds_all, co
     if constexpr (sf_win<W>::lateral) {
       constexpr bool diag = sf_win<W>::diag;
       constexpr int slot = diag ? (PH + 2) % SF_SLOTS : (PH + 1) % SF_SLOTS;  // next : cur
-      constexpr int image = diag ? PH % 4 : PH % 2;
-      sf_t* lds = lds_all + sf_win_base<W>::value + image * SF_WIN_ELEMS;
-      *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(cx.ty, 0) + cx.tx * SF_VK]) = st.w[W][slot][0];
-      *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(cx.ty, 1) + cx.tx * SF_VK]) = st.w[W][slot][SF_RJ - 1];
+      constexpr int g = sf_win_base<W>::value + (diag ? PH % 4 : PH % 2);
+      *reinterpret_cast<sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_own]) = st.w[W][slot][0];
+      *reinterpret_cast<sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_own + SF_TKH]) = st.w[W][slot][SF_RJ - 1];
+      // own edge words: (ty, r, wave, side) = edge0 + compile-time offset
+      constexpr int own = sf_edge_at(0, 0, 0, 0) - sf_edge_at(-1, 0, -1, 0);
       if (cx.lane == 0) {
 #pragma unroll
-        for (int r = 0; r < SF_RJ; ++r) lds[sf_edge_at(cx.ty, r, cx.wave, 0)] = st.w[W][slot][r][0];
+        for (int r = 0; r < SF_RJ; ++r)
+          lds_all[SF_EDGE_IMAGE(g) + cx.edge0 + own + r * SF_EDGE_WAVES * 2] = st.w[W][slot][r][0];
       }
       if (cx.lane == 63) {
 #pragma unroll
-        for (int r = 0; r < SF_RJ; ++r) lds[sf_edge_at(cx.ty, r, cx.wave, 1)] = st.w[W][slot][r][SF_VK - 1];
+        for (int r = 0; r < SF_RJ; ++r)
+          lds_all[SF_EDGE_IMAGE(g) + cx.edge0 + own + r * SF_EDGE_WAVES * 2 + 1] = st.w[W][slot][r][SF_VK - 1];
       }
     }
     sf_publish<W + 1, PH>(st, lds_all, cx);
@@ -407,7 +463,7 @@ __device__ __forceinline__ void sf_edge_prefill(sf_t* lds_all, const sf_ctx& cx)
         for (int image = 0; image < sf_win<W>::ring; ++image)
 #pragma unroll
           for (int r = 0; r < SF_RJ; ++r) {
-            sf_t* lds = lds_all + sf_win_base<W>::value + image * SF_WIN_ELEMS;
+            sf_t* lds = lds_all + SF_EDGE_IMAGE(sf_win_base<W>::value + image);
             if (cx.wave == 0) lds[sf_edge_at(cx.ty, r, -1, 1)] = bc;
             if (cx.wave == SF_WPR - 1) lds[sf_edge_at(cx.ty, r, SF_WPR, 0)] = bc;
           }
@@ -476,6 +532,10 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   cx.lane = cx.tx & 63;
   cx.goff = goff;
   cx.halo = halo;
+  cx.row_own = sf_rows_at(0, 0) + cx.ty * 2 * SF_TKH + cx.tx * SF_VK;
+  cx.row_lo = ((cx.ty > 0 ? cx.ty - 1 : 0) * 2 + 1) * SF_TKH + cx.tx * SF_VK;
+  cx.row_hi = ((cx.ty < SF_BY - 1 ? cx.ty + 1 : SF_BY - 1) * 2) * SF_TKH + cx.tx * SF_VK;
+  cx.edge0 = (cx.ty * SF_RJ * SF_EDGE_WAVES + cx.wave) * 2;  // = sf_edge_at(ty - 1, 0, wave - 1, 0)
 
   // XCD-aware block order: j-adjacent tiles (sharing halo rows) land on one XCD / L2
   const int nb = gridDim.x, b = blockIdx.x;

@@ -60,6 +60,7 @@ struct Options {
 // ---------------------------------------------------------------- plan pieces
 struct CompiledKernel {
   std::string name, source;
+  std::string flags;  // extra compiler flags (space-separated), part of the cache key
   std::vector<char> code;
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
@@ -145,9 +146,10 @@ static void compile_kernel(CompiledKernel& k) {
       HIPRTC_SUCCESS)
     throw Error(SF_ERR_COMPILE, "hiprtcCreateProgram failed");
   const std::string def = "-DSF_KERNEL_NAME=" + k.name;
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                        def.c_str()};
-  hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+  std::vector<std::string> extra = split_ws(k.flags);
+  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", def.c_str()};
+  for (auto& f : extra) opts.push_back(f.c_str());
+  hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;
     hiprtcGetProgramLogSize(prog, &n);
@@ -268,13 +270,17 @@ static void write_cache_file(const std::string& path, const std::vector<char>& c
 
 static std::atomic<long> g_cache_hits{0}, g_cache_misses{0}, g_cache_recompiles{0};
 
-static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& source) {
-  auto it = pl.kernel_by_source.find(source);
+static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& source,
+                         const std::string& flags = "") {
+  // (kernels without extra flags keep the names and cache keys they always had)
+  const std::string keyed = flags.empty() ? source : flags + "\n" + source;
+  auto it = pl.kernel_by_source.find(keyed);
   if (it != pl.kernel_by_source.end()) return it->second;
   CompiledKernel k;
-  k.name = prefix + "_" + hex8(fnv1a(source));
+  k.name = prefix + "_" + hex8(fnv1a(keyed));
   k.source = source;
-  const std::string key = k.name + "\n" + source;
+  k.flags = flags;
+  const std::string key = k.name + "\n" + keyed;
   bool cached = false;
   {
     std::lock_guard<std::mutex> lock(g_code_cache_mutex);
@@ -301,7 +307,7 @@ static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::stri
   }
   read_metadata(k);
   pl.kernels.push_back(std::move(k));
-  pl.kernel_by_source[source] = (int)pl.kernels.size() - 1;
+  pl.kernel_by_source[keyed] = (int)pl.kernels.size() - 1;
   return (int)pl.kernels.size() - 1;
 }
 
@@ -312,7 +318,7 @@ static size_t star_lds_bytes(const StarCfg& c, DT dt) {
   if (c.compact) {
     // kernels/compact3d.h: per window a ring of images (first / last row of every
     // thread row + the wave-edge columns of every row incl. two virtual waves)
-    const size_t win = (size_t)c.BY * 2 * c.BX * c.VK + (size_t)c.BY * c.RJ * (c.BX / 64 + 2) * 2;
+    const size_t win = (size_t)c.BY * 2 * c.BX * c.VK + (size_t)(c.BY + 2) * c.RJ * (c.BX / 64 + 2) * 2;
     return std::max<size_t>(1, (size_t)c.lds_images * win) * size_of(dt);
   }
   const size_t rows = c.noj ? 0 : (size_t)c.T * c.BY * 2 * c.BX * c.VK;
@@ -336,8 +342,9 @@ static int star_regs_estimate(const StarCfg& c, DT dt) {
   // spills after all is rejected by select_star from its metadata.
   const int words = (dt == DT::F64) ? 2 : 1;
   const int P = c.RJ * c.VK;
-  if (c.compact)  // three live planes per window, one more in flight per loaded window, the gathered rows
-    return 3 * c.nwin * P * words + (1 + c.nwin - c.T) * P * words + 40 + 4 * P;
+  if (c.compact)  // three live planes per window, one more in flight per loaded window; fitted to
+                  // the code objects of round 2 (box, T = 2: P = 16 -> 180, P = 20 -> 212)
+    return (3 * c.nwin + 1 + c.nwin - c.T) * P * words + 52 + P;
   return 3 * c.T * P * words + 20 + (33 * P) / 10 +
          ((c.prefetch2 || c.reverse == 2) ? P * words * c.pfd : 0);
 }
@@ -628,6 +635,13 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
   return out;
 }
 
+// Extra compiler flags of the compact kernels: without the SLP vectoriser hipcc
+// keeps the 26 adds of a box stencil scalar instead of pairing them into
+// v_pk_add_f32, whose operand pairs it has to assemble with moves (option compact.slp).
+static std::string compact_flags(const sf_plan& pl) {
+  return pl.opt.get("compact.slp", 0) != 0 ? "" : "-fno-slp-vectorize";
+}
+
 // The same for a group of compact operators (kernels/compact3d.h).
 static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>& memo, const std::vector<int>& kernels,
                                  DT dt) {
@@ -653,7 +667,7 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
     StarKernelSource g = gen_compact(P, kernels, ranked[ci]);
     int ck = -1;
     try {
-      ck = intern_kernel(pl, prefix, g.source);
+      ck = intern_kernel(pl, prefix, g.source, compact_flags(pl));
     } catch (const Error& e) {
       if (pinned || e.status != SF_ERR_COMPILE) throw;
       if (pl.opt.get("debug", 0) != 0)
@@ -1107,7 +1121,7 @@ static void ensure_device(sf_plan& pl) {
       if (k.mod) (void)hipModuleUnload(k.mod);
       k.mod = nullptr;
       k.fn = nullptr;
-      const std::string key = k.name + "\n" + k.source;
+      const std::string key = k.name + "\n" + (k.flags.empty() ? k.source : k.flags + "\n" + k.source);
       const std::string path = disk_cache_path(key);
       if (!path.empty()) std::remove(path.c_str());
       compile_kernel(k);
