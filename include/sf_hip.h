@@ -163,6 +163,8 @@ int sf_plan_execute_step_ranges(sf_plan* plan, int step, int i_begin, int i_end,
  * runs beside a halo exchange, so that the RCCL copy kernels find free units
  * instead of queueing behind 200-microsecond blocks that leave no registers. */
 int sf_plan_set_reserved_cus(sf_plan* plan, int cus);
+/* Number of device buffers of the plan (ids 0 .. n-1). */
+int sf_plan_num_buffers(const sf_plan* plan);
 /* Device address, plane size in bytes and plane count of device buffer `id`. */
 int sf_plan_buffer_info(const sf_plan* plan, int buffer_id, void** device_ptr,
                         size_t* plane_bytes, int* planes);
@@ -195,6 +197,50 @@ int sf_flag_set(void* stream, unsigned int* flag, unsigned int value);
  * the stream continue: a waiting kernel always terminates. */
 int sf_flag_wait(void* stream, const unsigned int* flag, unsigned int value,
                  unsigned int timeout_ms, unsigned int* status);
+
+/* ---- peer-to-peer halo transport, owned by the library ------------------------
+ * One rank's end of the neighbour exchange of a slab-decomposed run.  A rank
+ * PUSHES the planes next to a slab boundary straight into its neighbour's ghost
+ * planes -- device memory of the neighbour's plan, mapped through a HIP IPC handle
+ * -- with DMA copies (no compute units; over xGMI between the GPUs of a node),
+ * ordered by flag words in a page of host memory the ranks of the node share.
+ * Nothing but this header is needed to drive a decomposed run from C: create a
+ * plan per rank (option "slab=..."), sf_halo_export its slab buffers, hand the
+ * blobs to the neighbouring ranks by whatever means the caller has (MPI, a file,
+ * torch.distributed ...), sf_halo_connect, then alternate sf_halo_start /
+ * sf_plan_execute_step_ranges / sf_halo_finish.
+ * (Role in the reference: the SMI remote streams between devices,
+ * stencilflow/sdfg_generator.py:848-891, and the MPI rank bookkeeping of
+ * bin/run_distributed_program.py:98-100,283-299.) */
+typedef struct sf_halo sf_halo;
+#define SF_HALO_BLOB_BYTES 256
+/* `session`: a name unique to this run, the same on all ranks (names the shared
+ * flag pages).  timeout_ms: how long a stream waits for a neighbour before it
+ * gives up and marks the transport failed (sf_halo_check); 0 = 20 s. */
+int sf_halo_create(int rank, int world, const char* session, int device,
+                   unsigned int timeout_ms, sf_halo** out);
+int sf_halo_destroy(sf_halo* halo);
+/* Register slab buffer `key` (0..59; e.g. the plan's buffer id): `device_base` is
+ * the start of its allocation (sf_plan_buffer_info), holding n_local + 2*halo
+ * planes of plane_bytes.  Writes SF_HALO_BLOB_BYTES to `blob`: the description the
+ * neighbouring ranks need. */
+int sf_halo_export(sf_halo* halo, int key, void* device_base, size_t plane_bytes,
+                   int n_local, int halo_planes, void* blob);
+/* Map the neighbours' buffers `key` from their blobs (NULL where there is no
+ * neighbour).  Collective with the neighbours' calls only through the blobs. */
+int sf_halo_connect(sf_halo* halo, int key, const void* lower_blob,
+                    const void* upper_blob);
+/* Start exchange of `depth` planes per direction of buffer `key`: waits (on the
+ * transport's streams) for everything enqueued on `compute_stream` so far, then
+ * pushes the owned planes next to each boundary into the neighbours' ghost planes
+ * and waits for theirs.  Asynchronous; every rank calls it at the same point of
+ * the schedule. */
+int sf_halo_start(sf_halo* halo, int key, int depth, void* compute_stream);
+/* Make `compute_stream` wait until the exchange started last on `key` is done. */
+int sf_halo_finish(sf_halo* halo, int key, void* compute_stream);
+/* Fails (SF_ERR_DEVICE) if a wait of this rank has timed out; call after
+ * synchronising. */
+int sf_halo_check(sf_halo* halo);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,7 @@ API = [
     ("sf_plan_execute_step", _I, [_P, _I, _I, _P]),
     ("sf_plan_execute_step_ranges", _I, [_P, _I, _I, _I, _I, _I, _P]),
     ("sf_plan_set_reserved_cus", _I, [_P, _I]),
+    ("sf_plan_num_buffers", _I, [_P]),
     ("sf_plan_buffer_info", _I,
      [_P, _I, _PP, ctypes.POINTER(ctypes.c_size_t), _IP]),
     ("sf_plan_input_buffer", _I, [_P, _I]),
@@ -84,7 +85,15 @@ API = [
     ("sf_copy_async", _I, [_P, _P, _Z, _P]),
     ("sf_flag_set", _I, [_P, _P, ctypes.c_uint]),
     ("sf_flag_wait", _I, [_P, _P, ctypes.c_uint, ctypes.c_uint, _P]),
+    ("sf_halo_create", _I, [_I, _I, _S, _I, ctypes.c_uint, _PP]),
+    ("sf_halo_destroy", _I, [_P]),
+    ("sf_halo_export", _I, [_P, _I, _P, _Z, _I, _I, _P]),
+    ("sf_halo_connect", _I, [_P, _I, _P, _P]),
+    ("sf_halo_start", _I, [_P, _I, _I, _P]),
+    ("sf_halo_finish", _I, [_P, _I, _P]),
+    ("sf_halo_check", _I, [_P]),
 ]
+HALO_BLOB_BYTES = 256
 
 
 def library_path():
@@ -340,6 +349,10 @@ class Plan:
     def set_reserved_cus(self, cus):
         """Leave `cus` compute units free in the launches that follow (0 = none)."""
         _check(self._lib.sf_plan_set_reserved_cus(self._h, int(cus)))
+
+    @property
+    def num_buffers(self):
+        return _check(self._lib.sf_plan_num_buffers(self._h))
 
     def buffer_info(self, buffer_id):
         ptr = ctypes.c_void_p()

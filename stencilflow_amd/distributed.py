@@ -392,6 +392,115 @@ class ShmExchanger:
         self._boxes = {}
 
 
+class PeerExchanger:
+    """Peer-to-peer transport owned by the library (``sf_halo_*`` of the C ABI): a
+    rank pushes its boundary planes straight into the neighbour's ghost planes --
+    the neighbour's device buffer, mapped through a HIP IPC handle -- with DMA
+    copies over xGMI, ordered by flag words in host memory the ranks share.  No
+    compute units, no torch on the data path: the interior launch beside an
+    exchange keeps the whole chip.  Python only hands the buffer descriptions
+    ("blobs") from rank to rank once, at ``attach``.
+
+    ``exchange_blobs(list_of_bytes) -> (lower_list, upper_list)`` moves the blobs to
+    the neighbours; the default uses the default ``torch.distributed`` group
+    (gloo control plane).
+    """
+
+    reserved_cus = 0  # copies run on the DMA engines
+
+    def __init__(self, rank, world, session, device=0, timeout_ms=20000, exchange_blobs=None):
+        import ctypes
+        from .backend import HALO_BLOB_BYTES, load_library
+        self.rank, self.world, self.device = rank, world, device
+        self._ct, self._lib = ctypes, load_library()
+        self._blob_bytes = HALO_BLOB_BYTES
+        self._exchange_blobs = exchange_blobs or self._exchange_blobs_dist
+        self._geometry = {}  # key -> (plane_bytes, n_local, halo)
+        self._h = ctypes.c_void_p()
+        self._check(self._lib.sf_halo_create(rank, world, str(session).encode(), device, int(timeout_ms),
+                                             ctypes.byref(self._h)))
+
+    def _check(self, status):
+        if status != 0:
+            raise RuntimeError("peer-to-peer halo transport: " + (self._lib.sf_last_error() or b"").decode())
+
+    def _exchange_blobs_dist(self, blobs):
+        import torch.distributed as dist
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, (self.rank, blobs))
+        by_rank = dict(gathered)
+        return by_rank.get(self.rank - 1), by_rank.get(self.rank + 1)
+
+    def attach(self, plan, n_local, halo):
+        """Register every slab buffer of ``plan`` and map the neighbours' (collective)."""
+        ct = self._ct
+        keys, blobs = [], []
+        for buf in range(plan.num_buffers):
+            ptr, plane_bytes, planes = plan.buffer_info(buf)
+            if planes <= 1 or buf in self._geometry:
+                continue
+            blob = ct.create_string_buffer(self._blob_bytes)
+            self._check(self._lib.sf_halo_export(self._h, buf, ct.c_void_p(ptr), plane_bytes, n_local, halo, blob))
+            self._geometry[buf] = (plane_bytes, n_local, halo)
+            keys.append(buf)
+            blobs.append(blob.raw)
+        if self.world == 1 or not keys:
+            return
+        lower, upper = self._exchange_blobs(blobs)
+        for i, buf in enumerate(keys):
+            lo = ct.create_string_buffer(lower[i], self._blob_bytes) if lower else None
+            hi = ct.create_string_buffer(upper[i], self._blob_bytes) if upper else None
+            self._check(self._lib.sf_halo_connect(self._h, buf, lo, hi))
+
+    def handshake(self, device=None):
+        """Done on the real buffers by ``SlabRunner`` (``verify``): nothing to prove
+        before buffers exist."""
+
+    def verify(self, tensor, plane_bytes, n_local, halo, key):
+        """One exchange of the deepest halo on buffer ``key`` with rank-stamped
+        boundary planes; every rank checks what arrived, then clears the planes."""
+        import torch
+        if self.world == 1:
+            return
+        view = tensor.view(n_local + 2 * halo, plane_bytes)
+        view[halo:halo + n_local] = self.rank + 1
+        self.finish(self.start(tensor, halo_regions(n_local, halo, halo, plane_bytes), key=key))
+        torch.cuda.current_stream(self.device).synchronize()
+        self.check()
+        lo, hi = int(view[0, 0]), int(view[-1, -1])
+        view.zero_()
+        torch.cuda.current_stream(self.device).synchronize()
+        if lo != (self.rank if self.rank > 0 else 0):
+            raise RuntimeError("peer-to-peer halo transport: wrong data from the lower neighbour")
+        if hi != (self.rank + 2 if self.rank < self.world - 1 else 0):
+            raise RuntimeError("peer-to-peer halo transport: wrong data from the upper neighbour")
+
+    def start(self, tensor, regions, key=None):
+        import torch
+        if self.world == 1:
+            return None
+        plane_bytes, _, _ = self._geometry[key]
+        depth = regions["send_down"][1] // plane_bytes
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.sf_halo_start(self._h, key, int(depth), self._ct.c_void_p(stream)))
+        return key
+
+    def finish(self, handle):
+        import torch
+        if handle is None:
+            return
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.sf_halo_finish(self._h, handle, self._ct.c_void_p(stream)))
+
+    def check(self):
+        self._check(self._lib.sf_halo_check(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.sf_halo_destroy(self._h)
+            self._h = self._ct.c_void_p()
+
+
 class LocalExchanger:
     """All ranks in one process: ``finish`` of the last rank to arrive performs
     the copies for everyone (tests; ranks must be stepped in lockstep)."""
@@ -523,6 +632,20 @@ class SlabRunner:
         self._valid = 0
         self._early = None  # (step, handles) of an exchange started a launch ahead
         self.early_exchange = bool(early_exchange)
+        if world > 1 and hasattr(self.exchanger, "attach"):
+            self.attach_exchanger(self.exchanger)
+
+    def attach_exchanger(self, exchanger, verify=True):
+        """Hand the plan's slab buffers to a transport that maps them into the
+        neighbouring ranks (``PeerExchanger``) and prove the connection on the
+        chain's first buffer (collective)."""
+        self.exchanger = exchanger
+        exchanger.attach(self.plan, self.n_local, self.halo)
+        if verify and self.inputs and hasattr(exchanger, "verify"):
+            buf = self.inputs[0][0]
+            tensor, plane_bytes, _ = self._buffer_tensor(buf)
+            with self.torch.cuda.stream(self.stream):
+                exchanger.verify(tensor, plane_bytes, self.n_local, self.halo, buf)
 
     def _buffer_tensor(self, buf):
         if buf not in self._tensors:

@@ -57,12 +57,14 @@ def test_plain_multi_gpu_command_never_degrades_to_one_gpu():
 @pytest.mark.gpu
 def test_plain_command_two_ranks_on_this_gpu():
     """The whole N = 2 path from the plain command on a one-GPU box: both ranks on
-    device 0 (test hook), so RCCL cannot connect them and the ladder lands on the
-    shared-memory transport; the line must report 2 ranks, connected."""
+    device 0 (test hook): RCCL cannot connect them, the peer-to-peer transport
+    (sf_halo_*) can; the line must report 2 ranks, connected."""
     r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64", "--stages", "24"],
              env={"SF_BENCH_SINGLE_DEVICE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rec = _line(r.stdout)
     assert rec["n_gpus"] == 2 and rec["config"]["ranks"] == 2
-    assert rec["config"]["transport"] in ("shm", "gloo", "rccl")
+    # processes sharing one device can map each other's buffers: the library's own
+    # peer-to-peer transport proves itself and is used
+    assert rec["config"]["transport"] == "p2p", rec["config"]
     assert "128x64x64" in rec["config"]["workload"] and rec["value"] > 0

@@ -129,13 +129,15 @@ def _gpu_worker(rank, world, port, shape, stages, overlap, groups, transport="gl
     import stencilflow_amd as sf
     from oracle import numpy_oracle as npo
     from stencilflow_amd import programs
-    from stencilflow_amd.distributed import ShmExchanger, SlabRunner, TorchDistExchanger
+    from stencilflow_amd.distributed import PeerExchanger, ShmExchanger, SlabRunner, TorchDistExchanger
     from stencilflow_amd.lowering import lower
     import tempfile
     _init(rank, world, port)
     if transport == "shm":
         exchanger = ShmExchanger(rank, world, "t{}".format(port), device=0)
         exchanger.handshake()
+    elif transport == "p2p":
+        exchanger = PeerExchanger(rank, world, "t{}".format(port), device=0)  # verified at attach
     else:
         exchanger = TorchDistExchanger(rank, world, staging="host")
     rng = np.random.default_rng(11)
@@ -149,7 +151,7 @@ def _gpu_worker(rank, world, port, shape, stages, overlap, groups, transport="gl
     runner.upload([x[runner.lo:runner.hi]])
     runner.execute()
     runner.synchronize()
-    if transport == "shm":
+    if transport in ("shm", "p2p"):
         exchanger.check()
     out = np.zeros(runner.local_shape, np.float32)
     runner.download([out])
@@ -178,6 +180,18 @@ def test_processes_on_one_gpu_shared_memory_transport(world, overlap, groups, ea
     _spawn(_gpu_worker, world, (48, 20, 64), 19, overlap, groups, "shm", early)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,overlap,groups,early", [(2, True, 4, False), (3, True, 4, True),
+                                                        (3, False, 2, False), (3, True, 1, False)])
+def test_processes_on_one_gpu_peer_to_peer_transport(world, overlap, groups, early):
+    """The library's own transport (sf_halo_* of the C ABI, PeerExchanger): DMA
+    pushes into the neighbour's ghost planes through IPC-mapped device memory,
+    flags in shared host memory.  On this one-GPU box the "peers" are processes
+    sharing the device -- everything but the xGMI wire; one of three ranks has two
+    neighbours.  Results bit for bit against the oracle."""
+    _spawn(_gpu_worker, world, (48, 20, 64), 19, overlap, groups, "p2p", early)
+
+
 def _handshake_worker(rank, world, port):
     dist = _init(rank, world, port)
     from stencilflow_amd.distributed import TorchDistExchanger
@@ -193,7 +207,7 @@ def test_transport_handshake_gloo(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("first,expect", [("rccl", "shared by the ranks"), ("gloo", "gloo")])
+@pytest.mark.parametrize("first,expect", [("p2p", "DMA pushes"), ("rccl", "shared by the ranks"), ("gloo", "gloo")])
 def test_bench_three_ranks_on_one_gpu_falls_back(first, expect):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one
     rank per process), with all ranks (one of them with two neighbours) pointed
