@@ -163,6 +163,8 @@ int sf_plan_execute_step_ranges(sf_plan* plan, int step, int i_begin, int i_end,
  * runs beside a halo exchange, so that the RCCL copy kernels find free units
  * instead of queueing behind 200-microsecond blocks that leave no registers. */
 int sf_plan_set_reserved_cus(sf_plan* plan, int cus);
+/* The HIP stream (hipStream_t) the plan launches on when a call is given NULL. */
+int sf_plan_stream(sf_plan* plan, void** stream);
 /* Number of device buffers of the plan (ids 0 .. n-1). */
 int sf_plan_num_buffers(const sf_plan* plan);
 /* Device address, plane size in bytes and plane count of device buffer `id`. */

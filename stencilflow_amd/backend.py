@@ -75,6 +75,7 @@ API = [
     ("sf_plan_execute_step", _I, [_P, _I, _I, _P]),
     ("sf_plan_execute_step_ranges", _I, [_P, _I, _I, _I, _I, _I, _P]),
     ("sf_plan_set_reserved_cus", _I, [_P, _I]),
+    ("sf_plan_stream", _I, [_P, _PP]),
     ("sf_plan_num_buffers", _I, [_P]),
     ("sf_plan_buffer_info", _I,
      [_P, _I, _PP, ctypes.POINTER(ctypes.c_size_t), _IP]),

@@ -1048,18 +1048,29 @@ static void build_plan(sf_plan& pl) {
       // non-temporal output stores for fields beyond the Infinity Cache (see rank_star_cfgs)
       const double out_bytes = cells * (double)size_of(dt);
       const bool nts = pl.opt.get("generic.nt", out_bytes >= 256.0 * 1024 * 1024 ? 1 : 0) != 0;
-      const int ppt = (int)std::max<long long>(1, std::min<long long>(8, pl.opt.get("generic.ppt", 1)));
-      GenericKernelSource g =
-          vec ? gen_generic_vec(P, st.kernels[0], xcd, nts, ppt, pl.opt.get("generic.fast", 0) != 0,
-                                pl.opt.get("generic.bio", 0) != 0)
-              : gen_generic(P, st.kernels[0], xcd, nts);
+      // marching form (a thread walks `generic.ppt` planes with a register window,
+      // default 8) for 3-D programs; generic.march=0 restores the one-plane form
+      const bool march = vec && P.n[0] > 1 && pl.opt.get("generic.march", 1) != 0;
+      const int ppt = (int)std::max<long long>(1, std::min<long long>(march ? 256 : 8, pl.opt.get("generic.ppt", march ? 8 : 1)));
+      auto make = [&](bool marching) {
+        return marching ? gen_generic_march(P, st.kernels[0], xcd, nts, ppt)
+               : vec    ? gen_generic_vec(P, st.kernels[0], xcd, nts, march ? 1 : ppt, pl.opt.get("generic.fast", 0) != 0,
+                                          pl.opt.get("generic.bio", 0) != 0)
+                        : gen_generic(P, st.kernels[0], xcd, nts);
+      };
+      GenericKernelSource g = make(march);
       st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
-      if (vec) {
-        const CompiledKernel& k = pl.kernels[st.ck];
-        if (std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs) > 0) {
-          g = gen_generic(P, st.kernels[0], xcd, nts);
-          st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
-        }
+      auto unclean = [&](int ck) {
+        const CompiledKernel& k = pl.kernels[ck];
+        return std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs) > 0;
+      };
+      if (march && unclean(st.ck)) {
+        g = make(false);
+        st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
+      }
+      if (vec && unclean(st.ck)) {
+        g = gen_generic(P, st.kernels[0], xcd, nts);
+        st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
       }
       st.generic_vk = g.vk;
       st.generic_ppt = g.planes_per_thread;
@@ -1722,6 +1733,15 @@ int sf_plan_set_reserved_cus(sf_plan* plan, int cus) {
   SF_API_BEGIN
   if (!plan || cus < 0 || cus >= 256) throw sf::Error(SF_ERR_INVALID, "reserved compute units must be in [0, 256)");
   plan->reserved_cus = cus;
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_plan_stream(sf_plan* plan, void** stream) {
+  SF_API_BEGIN
+  if (!plan || !stream) throw Error(SF_ERR_INVALID, "null argument");
+  ensure_device(*plan);
+  *stream = (void*)plan->stream;
   return SF_OK;
   SF_API_END
 }

@@ -1,0 +1,165 @@
+/* capi_slab_demo.c -- a slab-decomposed run driven from plain C through
+ * include/sf_hip.h alone (no Python, no torch, no MPI): the parent forks one
+ * process per rank BEFORE anything touches the GPU; every rank builds its plan
+ * (option "slab=lo:hi:halo"), registers its slab buffers with the library's
+ * peer-to-peer transport (sf_halo_*), trades the 256-byte buffer descriptions with
+ * its neighbours over socket pairs, and executes the chain: per launch, push the
+ * boundary planes into the neighbours' ghost planes, compute the interior beside
+ * the transfer, then the boundary planes.  Results go to <out>.<rank> (raw planes
+ * the rank owns); tests/test_capi_slab.py compares them with the oracle.
+ *
+ * The reference's counterpart is `mpirun -n N bin/run_distributed_program.py`
+ * (bin/run_distributed_program.py:98-100,283-299).  All ranks use device 0 here
+ * (a one-GPU test box); on a node with N GPUs pass the rank as the device.
+ *
+ *   cc -I include tests/capi_slab_demo.c -L stencilflow_amd/csrc -lsf_hip -o demo
+ *   ./demo <sfir file> <input.dat> <out prefix> <world> <n0> <plane_bytes> <halo>
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include "sf_hip.h"
+
+#define CHECK(call)                                                        \
+  do {                                                                     \
+    if ((call) < 0) {                                                      \
+      fprintf(stderr, "rank %d: %s: %s\n", rank, #call, sf_last_error()); \
+      return 2;                                                            \
+    }                                                                      \
+  } while (0)
+
+static char* read_file(const char* path, size_t* size) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return NULL;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  char* buf = (char*)malloc((size_t)n + 1);
+  if (fread(buf, 1, (size_t)n, f) != (size_t)n) {
+    fclose(f);
+    free(buf);
+    return NULL;
+  }
+  buf[n] = 0;
+  fclose(f);
+  if (size) *size = (size_t)n;
+  return buf;
+}
+
+/* exchange one blob with a neighbour over its socket (both sides send, then receive) */
+static int trade(int fd, const char* mine, char* theirs) {
+  if (write(fd, mine, SF_HALO_BLOB_BYTES) != SF_HALO_BLOB_BYTES) return -1;
+  size_t got = 0;
+  while (got < SF_HALO_BLOB_BYTES) {
+    ssize_t n = read(fd, theirs + got, SF_HALO_BLOB_BYTES - got);
+    if (n <= 0) return -1;
+    got += (size_t)n;
+  }
+  return 0;
+}
+
+static int run_rank(int rank, int world, int down_fd, int up_fd, const char* sfir, const char* input,
+                    size_t input_bytes, const char* out_prefix, int n0, size_t plane_bytes, int halo,
+                    const char* session) {
+  const int lo = (int)((long long)n0 * rank / world), hi = (int)((long long)n0 * (rank + 1) / world);
+  char opt[96];
+  snprintf(opt, sizeof opt, "slab=%d:%d:%d", lo, hi, halo);
+  sf_plan* plan = NULL;
+  CHECK(sf_plan_create(sfir, 0, opt, &plan));
+  sf_halo* link = NULL;
+  CHECK(sf_halo_create(rank, world, session, 0, 20000, &link));
+  for (int b = 0; b < sf_plan_num_buffers(plan); ++b) {
+    void* base;
+    size_t pb;
+    int planes;
+    CHECK(sf_plan_buffer_info(plan, b, &base, &pb, &planes));
+    if (planes == 1) continue; /* not split into slabs */
+    char mine[SF_HALO_BLOB_BYTES], lower[SF_HALO_BLOB_BYTES], upper[SF_HALO_BLOB_BYTES];
+    CHECK(sf_halo_export(link, b, base, pb, hi - lo, halo, mine));
+    if (rank > 0 && trade(down_fd, mine, lower) != 0) return 3;
+    if (rank < world - 1 && trade(up_fd, mine, upper) != 0) return 3;
+    CHECK(sf_halo_connect(link, b, rank > 0 ? lower : NULL, rank < world - 1 ? upper : NULL));
+  }
+  if (input_bytes != (size_t)n0 * plane_bytes) {
+    fprintf(stderr, "input file has %zu bytes, expected %zu\n", input_bytes, (size_t)n0 * plane_bytes);
+    return 4;
+  }
+  const void* ins[1] = {input + (size_t)lo * plane_bytes};
+  CHECK(sf_plan_upload(plan, ins));
+  void* cs = NULL;
+  CHECK(sf_plan_stream(plan, &cs));
+  const int steps = sf_plan_num_steps(plan);
+  for (int s = 0; s < steps; ++s) {
+    int buf = -1, depth = 0;
+    CHECK(sf_plan_step_halo(plan, s, &buf, &depth));
+    if (depth > 0) CHECK(sf_halo_start(link, buf, depth, cs)); /* boundary planes -> the neighbours' ghosts */
+    CHECK(sf_plan_execute_step(plan, s, 3, NULL));              /* interior, beside the transfer */
+    if (depth > 0) CHECK(sf_halo_finish(link, buf, cs));
+    CHECK(sf_plan_execute_step(plan, s, 1, NULL));              /* planes next to the lower boundary */
+    CHECK(sf_plan_execute_step(plan, s, 2, NULL));              /* ... and the upper one */
+  }
+  CHECK(sf_plan_synchronize(plan));
+  CHECK(sf_halo_check(link));
+  size_t out_bytes = sf_plan_output_bytes(plan, 0);
+  char* out = (char*)malloc(out_bytes);
+  void* outs[1] = {out};
+  CHECK(sf_plan_download(plan, outs));
+  char path[512];
+  snprintf(path, sizeof path, "%s.%d", out_prefix, rank);
+  FILE* f = fopen(path, "wb");
+  if (!f || fwrite(out, 1, out_bytes, f) != out_bytes) return 5;
+  fclose(f);
+  free(out);
+  /* the neighbours may still be reading this rank's flag page: leave together */
+  char token = 1, other;
+  if (rank > 0 && (write(down_fd, &token, 1) != 1 || read(down_fd, &other, 1) != 1)) return 6;
+  if (rank < world - 1 && (write(up_fd, &token, 1) != 1 || read(up_fd, &other, 1) != 1)) return 6;
+  CHECK(sf_halo_destroy(link));
+  CHECK(sf_plan_destroy(plan));
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc != 8) {
+    fprintf(stderr, "usage: %s <sfir> <input.dat> <out prefix> <world> <n0> <plane_bytes> <halo>\n", argv[0]);
+    return 1;
+  }
+  const int world = atoi(argv[4]), n0 = atoi(argv[5]), halo = atoi(argv[7]);
+  const size_t plane_bytes = (size_t)atoll(argv[6]);
+  size_t input_bytes = 0;
+  char* sfir = read_file(argv[1], NULL);
+  char* input = read_file(argv[2], &input_bytes);
+  if (!sfir || !input || world < 1 || world > 8) {
+    fprintf(stderr, "cannot read the program or the input\n");
+    return 1;
+  }
+  /* links[r] connects rank r (its "up" side) with rank r + 1 (its "down" side) */
+  int links[8][2];
+  for (int r = 0; r + 1 < world; ++r)
+    if (socketpair(AF_UNIX, SOCK_STREAM, 0, links[r]) != 0) return 1;
+  char session[64];
+  snprintf(session, sizeof session, "capi%d", (int)getpid());
+  pid_t pids[8];
+  for (int r = 0; r < world; ++r) {
+    pids[r] = fork(); /* nothing has initialised the GPU yet */
+    if (pids[r] == 0) {
+      const int down = r > 0 ? links[r - 1][1] : -1, up = r < world - 1 ? links[r][0] : -1;
+      const int rc = run_rank(r, world, down, up, sfir, input, input_bytes, argv[3], n0, plane_bytes, halo, session);
+      _exit(rc);
+    }
+  }
+  int failed = 0;
+  for (int r = 0; r < world; ++r) {
+    int status = 0;
+    waitpid(pids[r], &status, 0);
+    if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+      fprintf(stderr, "rank %d failed (status %d)\n", r, status);
+      failed = 1;
+    }
+  }
+  return failed;
+}

@@ -1,0 +1,56 @@
+"""A slab-decomposed run driven through include/sf_hip.h alone: tests/capi_slab_demo.c
+(plain C: fork per rank, sf_plan_* + sf_halo_*, socket pairs for the 256-byte buffer
+descriptions) against the oracle.  CPU: the program compiles and links against the
+library; GPU: 2 and 3 ranks on this box's GPU, results bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import stencilflow_amd as sf
+from stencilflow_amd import programs
+from stencilflow_amd.lowering import lower
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "stencilflow_amd", "csrc")
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "capi_slab_demo")
+    cmd = ["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "capi_slab_demo.c"), "-L", CSRC, "-lsf_hip",
+           "-Wl,-rpath," + CSRC, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_driver_of_a_decomposed_run_builds(tmp_path):
+    exe = _build(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage:" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,fuse,stages", [(2, 2, 6), (3, 2, 5), (3, 1, 3)])
+def test_c_driver_of_a_decomposed_run(tmp_path, world, fuse, stages):
+    from oracle import numpy_oracle as npo
+    exe = _build(tmp_path)
+    shape = (16 * world + 3, 20, 64)
+    prog = programs.jacobi3d(shape, stages, bc_value=0.25)
+    path = programs.write_program(prog, str(tmp_path / "p.json"))
+    sfir = str(tmp_path / "p.sfir")
+    with open(sfir, "w") as f:
+        f.write(lower(sf.KernelChainGraph(path)))
+    x = np.random.default_rng(5).uniform(-1, 1, shape).astype(np.float32)
+    x.tofile(str(tmp_path / "a.dat"))
+    env = dict(os.environ, SF_HIP_OPTIONS="fuse={}".format(fuse), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, sfir, str(tmp_path / "a.dat"), str(tmp_path / "out"), str(world), str(shape[0]),
+                        str(shape[1] * shape[2] * 4), str(fuse)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = npo.run_reference(prog, {"a": x})["b%d" % (stages - 1)]
+    for rank in range(world):
+        lo, hi = shape[0] * rank // world, shape[0] * (rank + 1) // world
+        got = np.fromfile(str(tmp_path / ("out.%d" % rank)), np.float32).reshape((hi - lo, ) + shape[1:])
+        assert np.array_equal(got, want[lo:hi]), rank
