@@ -21,7 +21,8 @@ compiler-dependent — see numpy_oracle's header).  Types are left to the C
 compiler (``__auto_type`` locals, ``<tgmath.h>`` calls), which makes this an
 independent check of the explicit typing in ``numpy_oracle``.
 
-PARITY: unpinned beyond the known-answer vectors listed in numpy_oracle.py.
+PARITY: pinned through numpy_oracle.py (bit-identical to it on every fixture and
+on random programs), whose header lists the vectors captured from the reference.
 """
 
 import ast

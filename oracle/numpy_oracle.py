@@ -21,12 +21,18 @@ PARITY PINNING.  The reference's CPU path cannot be built in this environment:
 it is C++ generated at run time by DaCe (un-vendored, empty submodule ``dace/``,
 no version recoverable), and the reference stores no expected
 outputs.  This oracle is therefore pinned by (a) the closed-form known answers
-the reference's own test programs imply (tests/test_oracle_kat.py), (b) the one
-output vector obtainable from the reference's ``Simulator`` (tests/golden/
-simulator12_expected.json, generated by tests/golden/make_reference_fixtures.py)
-and (c) structure fixtures captured from the reference's ``KernelChainGraph``.
-Deep iterates of the jacobi chains have no independent pin: "parity unpinned"
-beyond those vectors.
+the reference's own test programs imply (tests/test_oracle_kat.py), (b) output
+vectors of the reference's own ``Simulator`` -- on simulator12.json, on nine
+float32 / mixed-dtype programs and on BASELINE configs[0] itself (jacobi3d 32^3,
+8 operators), captured by tests/golden/make_reference_fixtures.py and
+make_simulator_fixtures.py -- which this module reproduces BIT FOR BIT when it
+types literals the way the Simulator does (``typing="nep50"``,
+tests/test_reference_vectors.py), and (c) structure fixtures captured from the
+reference's ``KernelChainGraph``.  What no vector from the reference covers is
+the TYPING CONTRACT below (the Simulator is NumPy, not DaCe's C++) and iterates
+deeper than C1's eight operators: for those, parity is pinned up to that typing
+only; tests/rounding_envelope.py measures how far the admissible typings lie
+apart.
 
 TYPING CONTRACT.  The reference CPU kernel is the C++ DaCe emits for the Python
 tasklet text; Python ``float`` literals print as C++ ``double`` literals, ``int``

@@ -71,6 +71,9 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #ifndef SF_BUFFER_IO
 #define SF_BUFFER_IO 0
 #endif
+// (diagnostic values: 2 = buffer loads only, 3 = buffer stores only)
+#define SF_BIO_LOADS (SF_BUFFER_IO == 1 || SF_BUFFER_IO == 2)
+#define SF_BIO_STORES (SF_BUFFER_IO == 1 || SF_BUFFER_IO == 3)
 
 // SF_BUFFER_IO: planes are read and written with buffer instructions whose
 // resource describes exactly one plane.  A lane (or a whole row, or -- with zero
@@ -276,7 +279,7 @@ __device__ __forceinline__ bool sf_row_ok(const sf_ctx& cx, const int p, const i
 // global domain).
 __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, const int r,
                                               const bool enabled = true) {
-#if SF_BUFFER_IO
+#if SF_BIO_LOADS
   // wave-uniform: a plane outside the global domain (or a load the caller has
   // switched off) gets a resource of zero records
   const bool plane_ok =
@@ -324,7 +327,7 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, con
 
 // `dst = row r of plane p` if `cond` (wave-uniform).  SF_BUFFER_IO: always issued,
 // with a resource of zero records when `cond` is false (dst then holds the padding).
-#if SF_BUFFER_IO
+#if SF_BIO_LOADS
 #define SF_LOAD_ROW_IF(cond, dst, p, r) dst = sf_load_row(cx, p, r, cond)
 #else
 #define SF_LOAD_ROW_IF(cond, dst, p, r) \
@@ -341,7 +344,7 @@ __device__ __forceinline__ typename sf_stage<S>::aux_row sf_aux_row(const sf_ctx
   const bool plane_ok = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G) && (q + cx.halo >= 0) &&
                         q >= cx.cb - (SF_T - S) && q < cx.ce + (SF_T - S);
   const bool row_ok = ((cx.jmask >> r) & 1u) != 0;
-#if SF_BUFFER_IO
+#if SF_BIO_LOADS
   // never under a branch: a plane this stage does not evaluate has zero records
   // (fields lacking dimensions are indexed by the dimensions they have, under a guard)
   return sf_stage<S>::load_aux_bio(cx.aux, (long long)(q + cx.halo), plane_ok, cx.ld_off[r], SF_PLANE_BYTES,
@@ -486,7 +489,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       // last stage of the group: write interior, in-domain points
       // SF_EXPERIMENT 1: timing-only build without the output stores (invalid results)
       if (SF_EXPERIMENT == 1) asm volatile("" ::"v"(o));
-#if SF_BUFFER_IO
+#if SF_BIO_STORES
       {
         // always issued: a plane that is not stored has a resource of zero records,
         // rows and lanes that are not stored an offset outside the plane

@@ -68,7 +68,7 @@ struct CompiledKernel {
   double total_ms = 0;
   double updates_per_launch = 0, alg_bytes_per_launch = 0;
   // from the code object's amdhsa metadata (msgpack note)
-  int vgprs = -1, agprs = -1, sgprs = -1, spills = -1, scratch = -1, lds = -1;
+  int vgprs = -1, agprs = -1, sgprs = -1, spills = -1, scratch = -1, lds = -1, sgpr_spills = -1;
   bool from_disk = false;  // the code object came from the on-disk cache
 };
 
@@ -187,6 +187,7 @@ static void read_metadata(CompiledKernel& k) {
   k.agprs = metadata_uint(k.code, ".agpr_count");
   k.sgprs = metadata_uint(k.code, ".sgpr_count");
   k.spills = metadata_uint(k.code, ".vgpr_spill_count");
+  k.sgpr_spills = metadata_uint(k.code, ".sgpr_spill_count");
   k.scratch = metadata_uint(k.code, ".private_segment_fixed_size");
   k.lds = metadata_uint(k.code, ".group_segment_fixed_size");
 }
@@ -561,6 +562,23 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   return out;
 }
 
+// What a code object's metadata says about its fitness.
+//  * SGPR spills make a kernel WRONG on gfx950 / ROCm 7.2 (tools/spill_probe.py,
+//    profiles/r02_spill_probe.log: every failing pinned shape of the star kernel
+//    spills SGPRs -- the buffer descriptors of the branch-free loads and stores are
+//    what drives the scalar registers out -- and no shape without SGPR spills fails,
+//    however many VGPRs it spills or AGPRs it uses): never accepted, unless the
+//    diagnostic environment variable SF_HIP_UNSAFE_SGPR_SPILLS=1 is set (the probe).
+//  * VGPR spills, scratch and AGPR copies are correct but slow: rejected by the
+//    planner's search, accepted for a pinned shape with allow_spills=1 (experiments).
+static bool kernel_unsafe(const CompiledKernel& k) {
+  static const bool tolerate = std::getenv("SF_HIP_UNSAFE_SGPR_SPILLS") != nullptr;
+  return k.sgpr_spills > 0 && !tolerate;
+}
+static bool kernel_slow(const CompiledKernel& k) {
+  return std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs) > 0;
+}
+
 // Pick a tile shape for a fused group by compiling candidates in order of
 // modelled cost and reading the code object's metadata.  A kernel that spills,
 // uses scratch or overflows into AGPRs is rejected: besides being slow, such
@@ -615,12 +633,11 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
       continue;
     }
     const CompiledKernel& k = pl.kernels[ck];
-    const int bad = std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs);
     if (pl.opt.get("debug", 0) != 0)
-      std::fprintf(stderr, "[sf_hip] candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d\n",
+      std::fprintf(stderr, "[sf_hip] candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d sgpr spill %d\n",
                    ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs,
-                   k.agprs, k.spills, k.scratch);
-    if (bad == 0 || (pinned && pl.opt.get("allow_spills", 0) != 0)) {
+                   k.agprs, k.spills, k.scratch, k.sgpr_spills);
+    if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
       if (!out.ok) {
         out.ok = true;
         out.cfg = ranked[ci];
@@ -677,14 +694,13 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
       continue;
     }
     const CompiledKernel& k = pl.kernels[ck];
-    const int bad = std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs);
     if (pl.opt.get("debug", 0) != 0)
       std::fprintf(stderr,
                    "[sf_hip] compact candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d "
                    "scratch %d lds %d\n",
                    ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs, k.agprs,
                    k.spills, k.scratch, k.lds);
-    if (bad == 0 || (pinned && pl.opt.get("allow_spills", 0) != 0)) {
+    if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
       if (!out.ok) {
         out.ok = true;
         out.cfg = ranked[ci];
@@ -740,7 +756,7 @@ static void validate_options(const sf_plan& pl) {
     const char* key;
     long long lo, hi;
   };
-  static const Range ranges[] = {{"k1.pf2", 0, 2}, {"k1.rev", 0, 2},  {"k1.dpp", 0, 4},   {"k1.bio", 0, 1},
+  static const Range ranges[] = {{"k1.pf2", 0, 2}, {"k1.rev", 0, 2},  {"k1.dpp", 0, 4},   {"k1.bio", 0, 3},
                                  {"k1.ul", 0, 1},  {"k1.db", 0, 1},   {"k1.nt", 0, 3},    {"k1.auxpre", 0, 2},
                                  {"graph", 0, 1},  {"autotune", 0, 8}};
   for (const Range& r : ranges) {
@@ -1060,10 +1076,7 @@ static void build_plan(sf_plan& pl) {
       };
       GenericKernelSource g = make(march);
       st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
-      auto unclean = [&](int ck) {
-        const CompiledKernel& k = pl.kernels[ck];
-        return std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs) > 0;
-      };
+      auto unclean = [&](int ck) { return kernel_unsafe(pl.kernels[ck]) || kernel_slow(pl.kernels[ck]); };
       if (march && unclean(st.ck)) {
         g = make(false);
         st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
@@ -1072,6 +1085,12 @@ static void build_plan(sf_plan& pl) {
         g = gen_generic(P, st.kernels[0], xcd, nts);
         st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
       }
+      // the one-point form is the last resort: VGPR spills there are slow but correct,
+      // SGPR spills are not acceptable anywhere
+      if (kernel_unsafe(pl.kernels[st.ck]))
+        throw Error(SF_ERR_UNSUPPORTED, "operator '" + P.kernels[st.kernels[0]].name +
+                                            "': the generated kernel spills scalar registers, which gives wrong "
+                                            "results on gfx950 (profiles/r02_spill_probe.log); simplify the operator");
       st.generic_vk = g.vk;
       st.generic_ppt = g.planes_per_thread;
       st.scalars = g.scalars;
@@ -1677,6 +1696,8 @@ int sf_plan_kernel_resources(const sf_plan* p, int i, int* vgprs, int* agprs, in
   if (spills) *spills = k.spills;
   if (scratch) *scratch = k.scratch;
   if (lds) *lds = k.lds;
+  // (diagnostics: SF_HIP_REPORT_SGPR_SPILLS=1 reports SGPR spills in place of the scratch size)
+  if (scratch && std::getenv("SF_HIP_REPORT_SGPR_SPILLS")) *scratch = k.sgpr_spills;
   return SF_OK;
 }
 int sf_plan_debug_counters(sf_plan* plan, unsigned long long* out, int count) {

@@ -810,14 +810,15 @@ def test_full_c5_configuration_bit_exact():
 def test_full_c4_grid_eight_slabs_bit_exact():
     """C4's grid -- 4096 x 512 x 512 float32 split into eight 512-plane slabs,
     deep halos, overlapped exchange with reserved compute units -- for the
-    first 40 operators of the chain, all 1.07 billion results against the C
+    first 200 operators of the chain, all 1.07 billion results against the C
     oracle.  The eight ranks share this GPU; halos are copied by the in-process
-    exchanger (the RCCL transport is the only part not exercised)."""
+    exchanger (tests/test_distributed.py::test_full_c4_grid_across_processes runs
+    the same grid over the peer-to-peer and the shared-memory transport)."""
     import tempfile
     from oracle import c_oracle
     from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
     from stencilflow_amd.lowering import lower
-    shape, stages, block, world = (4096, 512, 512), 40, 8, 8
+    shape, stages, block, world = (4096, 512, 512), 200, 8, 8
     x = np.random.default_rng(SEED + 34).random(shape, dtype=np.float32)
     with tempfile.TemporaryDirectory() as tmp:
         path = programs.write_program(programs.jacobi3d(shape, stages), os.path.join(tmp, "c4.json"))

@@ -67,6 +67,8 @@ def main():
                 plan.run([x], [out], 1)
                 plan.close()
                 ntotal += 1
+                if ntotal % 50 == 0:
+                    print("# %d configurations run, %d failures so far" % (ntotal, nfail), flush=True)
                 ok = np.array_equal(out, want) if tol == 0.0 else npo.arrays_match(want, out, tol)
                 if not ok:
                     nfail += 1
