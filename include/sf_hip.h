@@ -243,6 +243,16 @@ int sf_halo_finish(sf_halo* halo, int key, void* compute_stream);
 /* Fails (SF_ERR_DEVICE) if a wait of this rank has timed out; call after
  * synchronising. */
 int sf_halo_check(sf_halo* halo);
+/* One rank's execution of the whole chain, `repetitions` times, with the deep-halo
+ * schedule: the plan was created with "slab=lo:hi:H" and every slab
+ * buffer registered with `halo` under its buffer id.  After an exchange of H planes a
+ * launch of reach d also recomputes the H - d ghost planes that are still
+ * computable, so the following launches need no communication; the launch that does
+ * is split -- its interior runs beside the transfer, both boundary regions follow in
+ * one launch.  Programs that are not a pure chain exchange every slab buffer a launch
+ * reads across planes, at that launch's reach.  Asynchronous on the plan's stream;
+ * every rank makes the same call. */
+int sf_plan_execute_decomposed(sf_plan* plan, sf_halo* halo, int repetitions);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,7 @@ API = [
     ("sf_halo_start", _I, [_P, _I, _I, _P]),
     ("sf_halo_finish", _I, [_P, _I, _P]),
     ("sf_halo_check", _I, [_P]),
+    ("sf_plan_execute_decomposed", _I, [_P, _P, _I]),
 ]
 HALO_BLOB_BYTES = 256
 

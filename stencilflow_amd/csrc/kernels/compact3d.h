@@ -46,7 +46,11 @@
 // describes exactly one plane (see star3d.h, SF_BUFFER_IO): lanes, rows and whole
 // planes that must not touch memory get an offset outside the resource.
 //
-// Macros from codegen: SF_T SF_NX SF_VK SF_RJ SF_BX SF_BY SF_HK SF_KTILED SF_N0G
+// 2-D programs (SF_NOJ: stream axis = rows, one row per thread, SF_BY = SF_RJ = 1,
+// k-tiled strips): offsets are {-1,0,1}^2 -- the 9-point `box` of the generator in
+// 2-D -- only the wave-edge words of an image are used.
+//
+// Macros from codegen: SF_T SF_NX SF_VK SF_RJ SF_BX SF_BY SF_HK SF_KTILED SF_NOJ SF_N0G
 //   SF_N1 SF_N2 SF_NJT SF_NKT SF_NT SF_OPAQUE SF_ROW_FENCE SF_KERNEL_NAME;
 //   typedef sf_t, struct sf_scalars, struct sf_auxptrs (extra-field pointers),
 //   template<int S> struct sf_stage {need, xneed, xwin, xarg, bc(), xbc(), apply()}.
@@ -65,7 +69,11 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_TJH (SF_BY * SF_RJ)
 #define SF_TKH (SF_BX * SF_VK)
 #define SF_WPR (SF_BX / 64)
+#if SF_NOJ
+#define SF_TJI 1  // 2-D programs: the stream axis is j, there is no tiled row axis (one row per thread)
+#else
 #define SF_TJI (SF_TJH - 2 * SF_T)
+#endif
 #define SF_TKI (SF_TKH - 2 * SF_HK)
 
 // One image of one window = the first and last row of every thread row
@@ -432,8 +440,10 @@ __device__ __forceinline__ void sf_publish(const sf_state& st, sf_t* lds_all, co
       constexpr bool diag = sf_win<W>::diag;
       constexpr int slot = diag ? (PH + 2) % SF_SLOTS : (PH + 1) % SF_SLOTS;  // next : cur
       constexpr int g = sf_win_base<W>::value + (diag ? PH % 4 : PH % 2);
-      *reinterpret_cast<sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_own]) = st.w[W][slot][0];
-      *reinterpret_cast<sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_own + SF_TKH]) = st.w[W][slot][SF_RJ - 1];
+      if constexpr (!SF_NOJ) {
+        *reinterpret_cast<sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_own]) = st.w[W][slot][0];
+        *reinterpret_cast<sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_own + SF_TKH]) = st.w[W][slot][SF_RJ - 1];
+      }
       // own edge words: (ty, r, wave, side) = edge0 + compile-time offset
       constexpr int own = sf_edge_at(0, 0, 0, 0) - sf_edge_at(-1, 0, -1, 0);
       if (cx.lane == 0) {
@@ -553,12 +563,12 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   }
   if (cx.cb >= cx.ce) return;
 
-  cx.j0 = jt * SF_TJI - SF_T + cx.ty * SF_RJ;
+  cx.j0 = SF_NOJ ? 0 : (jt * SF_TJI - SF_T + cx.ty * SF_RJ);
   cx.k0 = SF_KTILED ? (kt * SF_TKI - SF_HK + cx.tx * SF_VK) : cx.tx * SF_VK;
   {
-    const int tj0 = jt * SF_TJI - SF_T;
+    const int tj0 = SF_NOJ ? 0 : (jt * SF_TJI - SF_T);
     const int tk0 = SF_KTILED ? (kt * SF_TKI - SF_HK) : 0;
-    cx.tile_inside = tj0 >= 0 && tj0 + SF_TJH <= SF_N1 && tk0 >= 0 && tk0 + SF_TKH <= SF_N2;
+    cx.tile_inside = tj0 >= 0 && tj0 + (SF_NOJ ? 1 : SF_TJH) <= SF_N1 && tk0 >= 0 && tk0 + SF_TKH <= SF_N2;
   }
   cx.jmask = 0;
   cx.kmask = 0;
@@ -568,7 +578,7 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     const int j = cx.j0 + r, tr = cx.ty * SF_RJ + r;
     const bool in_dom = (j >= 0) && (j < SF_N1);
     cx.jmask |= (in_dom ? 1u : 0u) << r;
-    store_mask |= ((in_dom && tr >= SF_T && tr < SF_TJH - SF_T) ? 1u : 0u) << r;
+    store_mask |= ((in_dom && (SF_NOJ || (tr >= SF_T && tr < SF_TJH - SF_T))) ? 1u : 0u) << r;
   }
 #pragma unroll
   for (int v = 0; v < SF_VK; ++v) cx.kmask |= ((cx.k0 + v >= 0 && cx.k0 + v < SF_N2) ? 1u : 0u) << v;

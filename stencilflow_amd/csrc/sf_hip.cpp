@@ -668,7 +668,8 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
   const std::string sig = "compact" + std::to_string(fnv1a(gen_compact(P, kernels, probe).source));
   auto it = memo.find(sig);
   if (it != memo.end()) return it->second;
-  const std::string prefix = std::string("sf_compact3d_") + short_of(dt) + "_t" + std::to_string(kernels.size());
+  const std::string prefix = std::string(P.n[1] == 1 ? "sf_compact2d_" : "sf_compact3d_") + short_of(dt) + "_t" +
+                             std::to_string(kernels.size());
   StarChoice out;
   std::vector<StarCfg> ranked;
   try {
@@ -677,7 +678,8 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
     memo[sig] = out;
     return out;
   }
-  const bool pinned = pl.opt.kv.count("k1.bx") && pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj");
+  const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
+                      (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
   const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
   int rejected = 0;
   for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {
@@ -872,7 +874,7 @@ static void build_plan(sf_plan& pl) {
       // only; an extra field needs its neighbours' planes, which a slab run does not
       // exchange for program inputs -- such stages stay on the generic kernel there
       const bool whole_domain = pl.halo == 0 && pl.n_local == P.n[0];
-      const bool compact_dims = P.nd == 3 && P.n[0] > 1 && P.n[1] > 1 && pl.opt.get("compact", 1) != 0;
+      const bool compact_dims = ((P.nd == 3 && P.n[1] > 1) || P.nd == 2) && P.n[0] > 1 && pl.opt.get("compact", 1) != 0;
       CompactShape cshape;
       bool compact = !generic_only && compact_dims && compact_eligible(P, P.kernels[k], &cshape) &&
                      (cshape.extra.empty() || whole_domain);
@@ -1066,7 +1068,8 @@ static void build_plan(sf_plan& pl) {
       const bool nts = pl.opt.get("generic.nt", out_bytes >= 256.0 * 1024 * 1024 ? 1 : 0) != 0;
       // marching form (a thread walks `generic.ppt` planes with a register window,
       // default 8) for 3-D programs; generic.march=0 restores the one-plane form
-      const bool march = vec && P.n[0] > 1 && pl.opt.get("generic.march", 1) != 0;
+      const bool march = vec && P.n[0] > 1 && pl.opt.get("generic.march", 1) != 0 && pl.opt.get("generic.bio", 0) == 0 &&
+                         pl.opt.get("generic.fast", 0) == 0;  // (those two are variants of the one-plane form)
       const int ppt = (int)std::max<long long>(1, std::min<long long>(march ? 256 : 8, pl.opt.get("generic.ppt", march ? 8 : 1)));
       auto make = [&](bool marching) {
         return marching ? gen_generic_march(P, st.kernels[0], xcd, nts, ppt)
@@ -2134,3 +2137,71 @@ int sf_halo_check(sf_halo* h) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- native slab schedule
+extern "C" int sf_plan_execute_decomposed(sf_plan* plan, sf_halo* halo, int repetitions) {
+  SF_API_BEGIN
+  if (!plan || !halo || repetitions < 0) throw Error(SF_ERR_INVALID, "sf_plan_execute_decomposed: bad argument");
+  sf_plan& pl = *plan;
+  ensure_device(pl);
+  autotune(pl);
+  const Program& P = pl.P;
+  const int n = (int)pl.n_local, H = pl.halo;
+  const bool has_lower = pl.goff > 0, has_upper = pl.goff + pl.n_local < P.n[0];
+  const bool alone = !has_lower && !has_upper;
+  if (!alone && H < 1) throw Error(SF_ERR_STATE, "sf_plan_execute_decomposed: the plan has no halo (option slab=lo:hi:halo)");
+  // a chain: every launch reads exactly the slab buffer the previous one wrote
+  bool chain = true;
+  for (size_t s = 0; s < pl.steps.size(); ++s) {
+    const Step& st = pl.steps[s];
+    if (st.in_bufs.size() != 1 || (s > 0 && st.in_bufs[0] != pl.steps[s - 1].out_buf)) chain = false;
+  }
+  auto exchange_all = [&](const std::vector<int>& bufs, int depth) {
+    for (int b : bufs) {
+      const int rc = sf_halo_start(halo, b, depth, (void*)pl.stream);
+      if (rc != SF_OK) throw Error(rc, sf_last_error());
+    }
+  };
+  auto finish_all = [&](const std::vector<int>& bufs) {
+    for (int b : bufs) {
+      const int rc = sf_halo_finish(halo, b, (void*)pl.stream);
+      if (rc != SF_OK) throw Error(rc, sf_last_error());
+    }
+  };
+  for (int rep = 0; rep < repetitions; ++rep) {
+    int valid = 0;  // ghost planes of the chain's current field that are still good
+    for (size_t s = 0; s < pl.steps.size(); ++s) {
+      const Step& st = pl.steps[s];
+      const int d = st.halo_buf >= 0 ? st.halo_depth : 0;
+      if (alone || d == 0) {
+        launch_ranges(pl, st, 0, n, 0, 0, pl.stream);
+        continue;
+      }
+      if (2 * std::max(d, chain ? H : d) > n) throw Error(SF_ERR_STATE, "slab too thin for its halo");
+      if (chain && d <= valid) {
+        const int ext = valid - d;
+        launch_ranges(pl, st, has_lower ? -ext : 0, n + (has_upper ? ext : 0), 0, 0, pl.stream);
+        valid = ext;
+        continue;
+      }
+      std::vector<int> bufs;
+      if (chain) {
+        bufs.push_back(st.in_bufs[0]);
+      } else {
+        for (int b : st.in_bufs)
+          if (pl.buffers[b].slabbed && pl.buffers[b].planes > 1 && std::find(bufs.begin(), bufs.end(), b) == bufs.end())
+            bufs.push_back(b);
+      }
+      const int depth = chain ? H : d;
+      exchange_all(bufs, depth);
+      launch_ranges(pl, st, has_lower ? d : 0, n - (has_upper ? d : 0), 0, 0, pl.stream);  // beside the transfer
+      finish_all(bufs);
+      const int ext = depth - d;
+      launch_ranges(pl, st, has_lower ? -ext : 0, has_lower ? d : 0, has_upper ? n - d : 0, has_upper ? n + ext : 0,
+                    pl.stream);
+      valid = chain ? ext : 0;
+    }
+  }
+  return SF_OK;
+  SF_API_END
+}

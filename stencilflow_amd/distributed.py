@@ -790,6 +790,16 @@ class SlabRunner:
             self.stream.synchronize()
         return (time.perf_counter() - t0) / repeats
 
+    def execute_native(self, repetitions=1):
+        """The same schedule run by the library itself (``sf_plan_execute_decomposed``;
+        peer-to-peer transport only), asynchronous on the plan's own stream --
+        ``plan.synchronize()`` waits for it."""
+        import ctypes
+        from .backend import _check
+        if not hasattr(self.exchanger, "_h"):
+            raise RuntimeError("the native schedule needs the library's own transport (PeerExchanger)")
+        _check(self.plan._lib.sf_plan_execute_decomposed(self.plan._h, self.exchanger._h, int(repetitions)))
+
     def execute(self):
         """One execution of the whole chain (asynchronous on ``self.stream``)."""
         for s in range(len(self.steps)):

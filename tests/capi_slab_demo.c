@@ -13,7 +13,9 @@
  * (a one-GPU test box); on a node with N GPUs pass the rank as the device.
  *
  *   cc -I include tests/capi_slab_demo.c -L stencilflow_amd/csrc -lsf_hip -o demo
- *   ./demo <sfir file> <input.dat> <out prefix> <world> <n0> <plane_bytes> <halo>
+ *   ./demo <sfir file> <input.dat> <out prefix> <world> <n0> <plane_bytes> <halo> [deep]
+ * With "deep" the per-launch loop below is replaced by ONE call of the library's
+ * own deep-halo schedule, sf_plan_execute_decomposed (halo = several launches' reach).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -64,7 +66,7 @@ static int trade(int fd, const char* mine, char* theirs) {
 
 static int run_rank(int rank, int world, int down_fd, int up_fd, const char* sfir, const char* input,
                     size_t input_bytes, const char* out_prefix, int n0, size_t plane_bytes, int halo,
-                    const char* session) {
+                    const char* session, int deep) {
   const int lo = (int)((long long)n0 * rank / world), hi = (int)((long long)n0 * (rank + 1) / world);
   char opt[96];
   snprintf(opt, sizeof opt, "slab=%d:%d:%d", lo, hi, halo);
@@ -92,7 +94,8 @@ static int run_rank(int rank, int world, int down_fd, int up_fd, const char* sfi
   CHECK(sf_plan_upload(plan, ins));
   void* cs = NULL;
   CHECK(sf_plan_stream(plan, &cs));
-  const int steps = sf_plan_num_steps(plan);
+  const int steps = deep ? 0 : sf_plan_num_steps(plan);
+  if (deep) CHECK(sf_plan_execute_decomposed(plan, link, 1));
   for (int s = 0; s < steps; ++s) {
     int buf = -1, depth = 0;
     CHECK(sf_plan_step_halo(plan, s, &buf, &depth));
@@ -124,10 +127,11 @@ static int run_rank(int rank, int world, int down_fd, int up_fd, const char* sfi
 }
 
 int main(int argc, char** argv) {
-  if (argc != 8) {
-    fprintf(stderr, "usage: %s <sfir> <input.dat> <out prefix> <world> <n0> <plane_bytes> <halo>\n", argv[0]);
+  if (argc != 8 && argc != 9) {
+    fprintf(stderr, "usage: %s <sfir> <input.dat> <out prefix> <world> <n0> <plane_bytes> <halo> [deep]\n", argv[0]);
     return 1;
   }
+  const int deep = argc == 9 && strcmp(argv[8], "deep") == 0;
   const int world = atoi(argv[4]), n0 = atoi(argv[5]), halo = atoi(argv[7]);
   const size_t plane_bytes = (size_t)atoll(argv[6]);
   size_t input_bytes = 0;
@@ -148,7 +152,7 @@ int main(int argc, char** argv) {
     pids[r] = fork(); /* nothing has initialised the GPU yet */
     if (pids[r] == 0) {
       const int down = r > 0 ? links[r - 1][1] : -1, up = r < world - 1 ? links[r][0] : -1;
-      const int rc = run_rank(r, world, down, up, sfir, input, input_bytes, argv[3], n0, plane_bytes, halo, session);
+      const int rc = run_rank(r, world, down, up, sfir, input, input_bytes, argv[3], n0, plane_bytes, halo, session, deep);
       _exit(rc);
     }
   }

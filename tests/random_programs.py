@@ -269,14 +269,18 @@ def star_program(seed):
 # --- random chains of COMPACT operators (kernels/compact3d.h): any subset of the 27
 # offsets {-1,0,1}^3 of the previous stage, optionally a second full input field read
 # through such offsets, scalar / literal coefficients, int / float / shrink boundaries,
-# plain star stages in between; 3-D, awkward sizes; only + - * and selects ------------
+# plain star stages in between; 3-D and 2-D, awkward sizes; only + - * and selects -----
 def compact_program(seed):
     rng = np.random.default_rng(seed)
-    its = ["i", "j", "k"]
+    nd = 3 if rng.random() < 0.7 else 2
+    its = ["i", "j", "k"][3 - nd:]
     vk = int(rng.choice([4, 4, 4, 2, 1]))
-    dims = [int(rng.integers(3, 22)), int(rng.integers(3, 37)), vk * int(rng.integers(2, 36))]
-    if vk == 1 and dims[2] % 2 == 0:
-        dims[2] += 1
+    if nd == 3:
+        dims = [int(rng.integers(3, 22)), int(rng.integers(3, 37)), vk * int(rng.integers(2, 36))]
+    else:
+        dims = [int(rng.integers(3, 90)), vk * int(rng.integers(2, 150))]
+    if vk == 1 and dims[-1] % 2 == 0:
+        dims[-1] += 1
     dtype = "float32" if rng.random() < 0.65 else "float64"
     prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": [],
             "dimensions": dims, "program": {}}
@@ -296,17 +300,16 @@ def compact_program(seed):
         return "%s[%s]" % (field, ",".join(it if o == 0 else "%s%+d" % (it, o) for it, o in zip(its, off)))
 
     def offsets(density, allow_diagonal=True):
+        import itertools
         offs = []
-        for di in (-1, 0, 1):
-            for dj in (-1, 0, 1):
-                for dk in (-1, 0, 1):
-                    nz = (di != 0) + (dj != 0) + (dk != 0)
-                    if nz > 1 and not allow_diagonal:
-                        continue
-                    if rng.random() < density:
-                        offs.append((di, dj, dk))
+        for off in itertools.product((-1, 0, 1), repeat=nd):
+            nz = sum(1 for o in off if o != 0)
+            if nz > 1 and not allow_diagonal:
+                continue
+            if rng.random() < density:
+                offs.append(tuple(off))
         if not offs:
-            offs.append(tuple(int(v) for v in rng.integers(-1, 2, 3)))
+            offs.append(tuple(int(v) for v in rng.integers(-1, 2, nd)))
         return [offs[int(t)] for t in rng.permutation(len(offs))]
 
     def bc():
@@ -345,7 +348,7 @@ def compact_program(seed):
         if rng.random() < 0.6:
             expr = "%r * (%s)" % (float(np.round(1.0 / max(1, len(terms)), 8)), expr)
         if rng.random() < 0.1:
-            expr = "(%s) if %s > 0.0 else (%s - 0.5)" % (expr, access(prev, (0, 0, 0)), expr)
+            expr = "(%s) if %s > 0.0 else (%s - 0.5)" % (expr, access(prev, (0, ) * nd), expr)
         bcs = {f: bc() for f, _ in fields}
         prog["program"][name] = {"computation_string": "%s = %s" % (name, expr),
                                  "boundary_conditions": bcs, "data_type": dtype}

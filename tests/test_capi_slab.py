@@ -33,8 +33,10 @@ def test_c_driver_of_a_decomposed_run_builds(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,fuse,stages", [(2, 2, 6), (3, 2, 5), (3, 1, 3)])
-def test_c_driver_of_a_decomposed_run(tmp_path, world, fuse, stages):
+@pytest.mark.parametrize("world,fuse,stages,halo", [(2, 2, 6, 0), (3, 2, 5, 0), (3, 1, 3, 0), (3, 2, 17, 8), (2, 3, 11, 6)])
+def test_c_driver_of_a_decomposed_run(tmp_path, world, fuse, stages, halo):
+    """halo = 0: the per-launch loop of the demo (halo = one launch's reach); halo > 0:
+    one call of the library's deep-halo schedule, sf_plan_execute_decomposed."""
     from oracle import numpy_oracle as npo
     exe = _build(tmp_path)
     shape = (16 * world + 3, 20, 64)
@@ -46,8 +48,9 @@ def test_c_driver_of_a_decomposed_run(tmp_path, world, fuse, stages):
     x = np.random.default_rng(5).uniform(-1, 1, shape).astype(np.float32)
     x.tofile(str(tmp_path / "a.dat"))
     env = dict(os.environ, SF_HIP_OPTIONS="fuse={}".format(fuse), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([exe, sfir, str(tmp_path / "a.dat"), str(tmp_path / "out"), str(world), str(shape[0]),
-                        str(shape[1] * shape[2] * 4), str(fuse)], capture_output=True, text=True, timeout=600, env=env)
+    args = [exe, sfir, str(tmp_path / "a.dat"), str(tmp_path / "out"), str(world), str(shape[0]),
+            str(shape[1] * shape[2] * 4), str(halo or fuse)] + (["deep"] if halo else [])
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     want = npo.run_reference(prog, {"a": x})["b%d" % (stages - 1)]
     for rank in range(world):

@@ -33,8 +33,14 @@ def main():
         ("hotspot 3-D f32", ("float32", st, 0.0, n, n, n, 1, 1, 1), {"stencil_shape": "hotspot"}),
         ("box 3-D f32", ("float32", st, 0.0, n, n, n, 1, 1, 1), {"stencil_shape": "box"}),
         ("cross 3-D f32, extra field every 2nd stage", ("float32", st, 0.5, n, n, n, 1, 1, 1), {}),
-        ("cross 2-D f32", ("float32", st, 0.0, 0, 8 * n, 8 * n, 0, 1, 1), {}),
-        ("hotspot 2-D f32", ("float32", st, 0.0, 0, 8 * n, 8 * n, 0, 1, 1), {"stencil_shape": "hotspot"}),
+        # 2-D programs are given as size_x, size_y, 0 (the reference generator pairs sizes
+        # and extents by position: `0 N N` with extents `0 1 1` -- round 1's 2-D cases --
+        # yields a k-only stencil on a 2-D grid)
+        ("cross 2-D f32", ("float32", st, 0.0, 8 * n, 8 * n, 0, 1, 1, 0), {}),
+        ("hotspot 2-D f32", ("float32", st, 0.0, 8 * n, 8 * n, 0, 1, 1, 0), {"stencil_shape": "hotspot"}),
+        ("box 2-D f32", ("float32", st, 0.0, 8 * n, 8 * n, 0, 1, 1, 0), {"stencil_shape": "box"}),
+        ("cross 2-D f32, extra field every 2nd stage", ("float32", st, 0.5, 8 * n, 8 * n, 0, 1, 1, 0), {}),
+        ("k-only 2-D f32 (round 1's 'cross 2-D')", ("float32", st, 0.0, 0, 8 * n, 8 * n, 0, 1, 1), {}),
     ]
     rng = np.random.default_rng(5)
     with tempfile.TemporaryDirectory() as tmp:
@@ -62,9 +68,9 @@ def main():
             ops = len(prog["program"])
             cells = float(np.prod(shape)) * ops
             bpu = 8.0 if dtype == np.float32 else 16.0
-            kinds = plan.describe().count("[star"), plan.describe().count("[point]")
+            kinds = plan.describe().count("[star") + plan.describe().count("[compact"), plan.describe().count("[point]")
             print(json.dumps({"case": label, "opts": args.opts, "dims": shape, "operators": ops, "launches": plan.num_launches,
-                              "star/point launches": kinds, "ms": round(ms, 3),
+                              "streaming/point launches": kinds, "ms": round(ms, 3),
                               "Mcells/s": round(cells / ms / 1e3), "frac_8TB": round(cells * bpu / (ms * 1e-3) / 8e12, 3),
                               "first": plan.describe().splitlines()[1].strip()[:110]}), flush=True)
             plan.close()
