@@ -184,10 +184,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3",
+    ap.add_argument("--workload", choices=["c3", "c2", "c5", "box"], default="c3",
                     help="c3 = jacobi3d 512^3 f32 (headline, default); c2 = "
                     "jacobi2d 4096^2 f32; c5 = diffusion/advection/laplacian "
-                    "512^3 f64 (own records; single GPU only)")
+                    "512^3 f64; box = the generator's 27-point box chain 512^3 f32 "
+                    "(own records; single GPU only)")
     ap.add_argument("--size", type=int, default=0)
     ap.add_argument("--stages", type=int, default=1000)
     ap.add_argument("--options", type=str, default="")
@@ -251,6 +252,12 @@ def main():
         np_dtype, dtype_name, bpu = np.float32, "f32", 8.0
         label = "jacobi2d {}x{} float32, {}-operator chain, constant BC 0.0".format(
             n, n, args.stages)
+    elif args.workload == "box":
+        n = args.size or 512
+        shape = (n, n, n)
+        prog, _ = programs.synthesize("float32", args.stages, 0.0, n, n, n, 1, 1, 1, stencil_shape="box")
+        np_dtype, dtype_name, bpu = np.float32, "f32", 8.0
+        label = "27-point box {}^3 float32 (bin/synthesize.py -stencil_shape box), {}-operator chain".format(n, args.stages)
     else:
         n = args.size or 512
         shape = (n, n, n)

@@ -2,13 +2,14 @@
 double-sum typing (the contract) against float-sum typing, the two
 readings the reference's tasklet text admits (stencilflow/stencil/cpu.py:89-102).
 
-Measured (profiles/r02_rounding_envelope.log): at the depth of BASELINE.json's
-configs[0] (8 operators) the two differ by 4.2e-7 at most -- within the 1e-6 of
-north_star whichever one DaCe produces.  At 1000 operators they are 1-3e-6 apart
-(the crossing lies between 16 and 64 operators on constant data, where every
-interior point rounds alike and the bias adds up, and around 200 on random
-data): there "within 1e-6 of the CPU reference" holds for the typing of the
-contract, not for both, and the tests below state exactly that.
+Measured (profiles/r02_rounding_envelope.log, 512^3): at the depth of
+BASELINE.json's configs[0] (8 operators) the two differ by 4.2e-7 at most --
+within the 1e-6 of north_star whichever one DaCe produces.  At 1000 operators
+they are 4.5e-6 (random data) to 3.9e-5 (constant data, where every interior
+point rounds alike and the bias adds up) apart; the crossing lies at 16-32
+operators on constant data and around 200 on random data.  There "within 1e-6 of
+the CPU reference" holds for the typing of the contract, not for both, and the
+tests below state exactly that.
 """
 import numpy as np
 import pytest

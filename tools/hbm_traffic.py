@@ -34,7 +34,7 @@ def main():
                 result = json.load(f)
         except (OSError, ValueError):
             result = {}
-    for wl in ("c3", "c2", "c5"):
+    for wl in ("c3", "c2", "c5", "box", "generic"):
         root = "gpurun_out/prof_%s_%s" % (tag, wl)
         if not os.path.isdir(root):
             continue
@@ -54,7 +54,7 @@ def main():
                 "correction": "gfx950: FETCH_SIZE reports half of a wide coalesced read stream -> x2 "
                               "(MI355X_MICROARCH.md, HBM)",
                 "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- "
-                           "python3 bench.py --workload %s --steps 1 --warmup 0 --stages 100 "
+                           "python3 bench.py <%s workload of tools/profile_round.sh> --steps 1 --warmup 0 "
                            "--no-cpu-baseline" % wl,
                 "round": tag,
             }
