@@ -616,7 +616,7 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
   const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
                       (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
   const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
-  int rejected = 0;
+  int rejected = 0, sgpr_rejects = 0;
   for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {  // compile errors rarely depend on the shape
     StarKernelSource g = gen_star(P, kernels, ranked[ci]);
     int ck = -1;
@@ -637,6 +637,7 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
       std::fprintf(stderr, "[sf_hip] candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d sgpr spill %d\n",
                    ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs,
                    k.agprs, k.spills, k.scratch, k.sgpr_spills);
+    if (kernel_unsafe(k) && ++sgpr_rejects >= 3) break;  // (scalar registers hardly depend on the tile shape)
     if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
       if (!out.ok) {
         out.ok = true;
@@ -681,7 +682,7 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
   const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
                       (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
   const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
-  int rejected = 0;
+  int rejected = 0, sgpr_rejects = 0;
   for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {
     StarKernelSource g = gen_compact(P, kernels, ranked[ci]);
     int ck = -1;
@@ -699,9 +700,12 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
     if (pl.opt.get("debug", 0) != 0)
       std::fprintf(stderr,
                    "[sf_hip] compact candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d "
-                   "scratch %d lds %d\n",
+                   "scratch %d sgpr spill %d lds %d\n",
                    ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs, k.agprs,
-                   k.spills, k.scratch, k.lds);
+                   k.spills, k.scratch, k.sgpr_spills, k.lds);
+    // scalar registers are spent on the group's windows and descriptors, hardly on the
+    // tile shape: a second shape that spills them settles it for this group length
+    if (kernel_unsafe(k) && ++sgpr_rejects >= 2) break;
     if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
       if (!out.ok) {
         out.ok = true;
@@ -822,7 +826,8 @@ static void build_plan(sf_plan& pl) {
   for (int k = 0; k < K;) {
     Step st;
     StarShape shape;
-    bool star = !generic_only && star_ok_dims && star_eligible(P, P.kernels[k], &shape);
+    // (star=0: diagnostics -- star chains then run on the compact kernel)
+    bool star = !generic_only && star_ok_dims && star_eligible(P, P.kernels[k], &shape) && pl.opt.get("star", 1) != 0;
     if (star && P.n[1] == 1) {
       for (auto& a : P.kernels[k].acc)
         if (a.off[1] != 0) star = false;
@@ -870,10 +875,11 @@ static void build_plan(sf_plan& pl) {
         st.kernels.push_back(k);
       }
     } else {
-      // compact operators (27-point neighbourhoods, one extra streamed field): 3-D programs
-      // only; an extra field needs its neighbours' planes, which a slab run does not
-      // exchange for program inputs -- such stages stay on the generic kernel there
-      const bool whole_domain = pl.halo == 0 && pl.n_local == P.n[0];
+      // compact operators (27-point neighbourhoods, one extra streamed field).  In a slab
+      // run an extra field is one more slab-split field the launch reads across planes:
+      // the runner exchanges every such field at the launch's reach (SlabRunner's rule for
+      // launches that are not a pure chain; the extra field reaches at most T planes)
+      const bool whole_domain = true;
       const bool compact_dims = ((P.nd == 3 && P.n[1] > 1) || P.nd == 2) && P.n[0] > 1 && pl.opt.get("compact", 1) != 0;
       CompactShape cshape;
       bool compact = !generic_only && compact_dims && compact_eligible(P, P.kernels[k], &cshape) &&
