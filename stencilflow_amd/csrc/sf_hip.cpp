@@ -637,7 +637,7 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
       std::fprintf(stderr, "[sf_hip] candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d sgpr spill %d\n",
                    ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs,
                    k.agprs, k.spills, k.scratch, k.sgpr_spills);
-    if (kernel_unsafe(k) && ++sgpr_rejects >= 3) break;  // (scalar registers hardly depend on the tile shape)
+    (void)sgpr_rejects;  // (star kernels: SGPR spills do depend on the shape -- hotspot 512^3: shapes 1-3 spill, 4 does not)
     if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
       if (!out.ok) {
         out.ok = true;
@@ -703,9 +703,9 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
                    "scratch %d sgpr spill %d lds %d\n",
                    ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs, k.agprs,
                    k.spills, k.scratch, k.sgpr_spills, k.lds);
-    // scalar registers are spent on the group's windows and descriptors, hardly on the
-    // tile shape: a second shape that spills them settles it for this group length
-    if (kernel_unsafe(k) && ++sgpr_rejects >= 2) break;
+    // scalar registers are spent on the group's windows and descriptors more than on the
+    // tile shape: four shapes that spill them settle it for this group length
+    if (kernel_unsafe(k) && ++sgpr_rejects >= 4) break;
     if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
       if (!out.ok) {
         out.ok = true;
