@@ -132,8 +132,11 @@ const char* sf_plan_describe(const sf_plan* plan);
 
 /* ---- slab decomposition (multi-GPU; one plan per rank) --------------------
  * The outermost dimension is split into contiguous slabs.  A rank's plan is
- * created with the option "slab=<lo>:<hi>:<halo>" and works on local arrays of
- * (hi-lo+2*halo) planes.  One chain execution is a sequence of steps; before
+ * created with the option "slab=<lo>:<hi>:<halo>[:<extent>]" and works on local
+ * arrays of (hi-lo+2*halo) planes.  All ranks must build the same launches (they
+ * exchange the same planes): with slabs of unequal height pass the same <extent>
+ * -- e.g. the thinnest slab's height -- on every rank; the planner then derives
+ * everything that depends on the slab's height from it.  One chain execution is a sequence of steps; before
  * step s the planes listed by sf_plan_step_halo must have been exchanged with
  * the neighbouring ranks for the buffer it names. */
 int sf_plan_num_steps(const sf_plan* plan);

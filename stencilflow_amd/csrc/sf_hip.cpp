@@ -127,7 +127,7 @@ struct sf_plan {
   int reserved_cus = 0;  // compute units the star launches leave free (sf_plan_set_reserved_cus)
   bool scalars_set = false;
   // slab decomposition of I0
-  long long n_local = 0, goff = 0;
+  long long n_local = 0, goff = 0, plan_extent = 0;
   int halo = 0;
   std::string description;
   bool autotuned = false;
@@ -501,13 +501,14 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   // Cache: nothing of it would survive until the next launch reads it, and not
   // allocating the written lines leaves the cache to the input stream (C3 +3 %,
   // C5 +1.4 %; the cache-resident 64 MiB field of C2 loses 13 % with them).
-  const double field_bytes = (double)pl.n_local * (double)P.n[1] * (double)P.n[2] * (double)size_of(dt);
+  const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] *
+                             (double)P.n[2] * (double)size_of(dt);
   base.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
   const std::string pfx = base.noj ? "k2." : "k1.";
   const long long pin_bx = pl.opt.get(pfx + "bx", 0);
   const long long pin_by = base.noj ? 1 : pl.opt.get("k1.by", 0);
   const long long pin_rj = base.noj ? 1 : pl.opt.get("k1.rj", 0);
-  const int range = (int)pl.n_local;
+  const int range = (int)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local);
 
   std::vector<std::pair<double, StarCfg>> ranked;
   for (int bx : {64, 128, 256}) {
@@ -792,14 +793,19 @@ static void build_plan(sf_plan& pl) {
   {
     const std::string slab = pl.opt.gets("slab", "");
     if (!slab.empty()) {
-      long long lo, hi;
+      long long lo, hi, extent = 0;
       int h;
-      if (std::sscanf(slab.c_str(), "%lld:%lld:%d", &lo, &hi, &h) != 3 || lo < 0 || hi > P.n[0] ||
-          lo >= hi || h < 0)
-        throw Error(SF_ERR_INVALID, "option slab=<lo>:<hi>:<halo> out of range");
+      const int got = std::sscanf(slab.c_str(), "%lld:%lld:%d:%lld", &lo, &hi, &h, &extent);
+      if (got < 3 || lo < 0 || hi > P.n[0] || lo >= hi || h < 0 || (got == 4 && extent < 1))
+        throw Error(SF_ERR_INVALID, "option slab=<lo>:<hi>:<halo>[:<planning extent>] out of range");
       pl.n_local = hi - lo;
       pl.goff = lo;
       pl.halo = h;
+      // The ranks of a decomposed run must plan ALIKE (same launch groups, same reach:
+      // they exchange the same planes): everything the planner derives from the slab's
+      // height uses this common extent -- the thinnest slab, given by the caller -- not
+      // the rank's own height.
+      pl.plan_extent = got == 4 ? extent : pl.n_local;
     }
   }
 
@@ -1070,7 +1076,8 @@ static void build_plan(sf_plan& pl) {
       const bool vec = (P.n[2] % 4 == 0) && pl.opt.get("generic.vec", 1) != 0;
       const bool xcd = pl.opt.get("generic.xcd", 1) != 0;
       // non-temporal output stores for fields beyond the Infinity Cache (see rank_star_cfgs)
-      const double out_bytes = cells * (double)size_of(dt);
+      const double out_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] *
+                               (double)P.n[2] * (double)size_of(dt);  // (alike on all ranks of a slab run)
       const bool nts = pl.opt.get("generic.nt", out_bytes >= 256.0 * 1024 * 1024 ? 1 : 0) != 0;
       // marching form (a thread walks `generic.ppt` planes with a register window,
       // default 8) for 3-D programs; generic.march=0 restores the one-plane form

@@ -574,14 +574,18 @@ class SlabRunner:
         self.local_shape = (self.n_local, ) + tuple(global_shape[1:])
         self.has_lower = rank > 0
         self.has_upper = rank < world - 1
+        # decisions every rank must take alike use the thinnest slab -- the planner's
+        # included (fourth field of the slab option: launch groups, tile search and
+        # cache policies follow that extent on every rank, so all ranks build the same
+        # launches and exchange the same planes)
+        n_min = global_shape[0] // world
+
         def make_plan(h):
             opts = dict(options)
             if world > 1:
-                opts["slab"] = "{}:{}:{}".format(self.lo, self.hi, h)
+                opts["slab"] = "{}:{}:{}:{}".format(self.lo, self.hi, h, n_min)
             return Plan(sfir_text, device=device, options=opts)
 
-        # decisions every rank must take alike use the thinnest slab
-        n_min = global_shape[0] // world
 
         def check(h, reach):
             if world > 1 and (n_min < h or n_min < 2 * reach):

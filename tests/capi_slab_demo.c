@@ -68,8 +68,8 @@ static int run_rank(int rank, int world, int down_fd, int up_fd, const char* sfi
                     size_t input_bytes, const char* out_prefix, int n0, size_t plane_bytes, int halo,
                     const char* session, int deep) {
   const int lo = (int)((long long)n0 * rank / world), hi = (int)((long long)n0 * (rank + 1) / world);
-  char opt[96];
-  snprintf(opt, sizeof opt, "slab=%d:%d:%d", lo, hi, halo);
+  char opt[96]; /* (fourth field: the extent every rank plans with -- the thinnest slab) */
+  snprintf(opt, sizeof opt, "slab=%d:%d:%d:%d", lo, hi, halo, n0 / world);
   sf_plan* plan = NULL;
   CHECK(sf_plan_create(sfir, 0, opt, &plan));
   sf_halo* link = NULL;
