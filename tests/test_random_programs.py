@@ -188,8 +188,9 @@ def test_random_compact_chains_under_slab_decomposition(seed, tmp_path):
     if shape[0] < 2 * world * 2 * fuse:
         pytest.skip("outermost extent too small to split")
     exch = LocalExchanger(world)
+    groups = int(rng.integers(1, 3))  # (alike on all ranks)
     runners = [SlabRunner(sfir, shape, r, world, options={"fuse": fuse}, exchanger=exch.for_rank(r),
-                          groups_per_exchange=int(rng.integers(1, 3))) for r in range(world)]
+                          groups_per_exchange=groups) for r in range(world)]
     slabbed = {n for n, d in p["inputs"].items() if npo._input_dims(p, n) and npo._input_dims(p, n)[0] == npo._own_iterators(p)[0]}
     for r in runners:
         if r.plan.scalar_names:
