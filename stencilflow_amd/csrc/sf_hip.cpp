@@ -272,7 +272,12 @@ static void write_cache_file(const std::string& path, const std::vector<char>& c
 static std::atomic<long> g_cache_hits{0}, g_cache_misses{0}, g_cache_recompiles{0};
 
 static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& source,
-                         const std::string& flags = "") {
+                         const std::string& flags_in = "") {
+  // (diagnostics: $SF_HIP_EXTRA_FLAGS adds compiler flags to every kernel, e.g.
+  // "-mllvm -amdgpu-spill-sgpr-to-vgpr=0"; they become part of name and cache key)
+  std::string flags = flags_in;
+  if (const char* extra = std::getenv("SF_HIP_EXTRA_FLAGS"))
+    if (*extra) flags += (flags.empty() ? "" : " ") + std::string(extra);
   // (kernels without extra flags keep the names and cache keys they always had)
   const std::string keyed = flags.empty() ? source : flags + "\n" + source;
   auto it = pl.kernel_by_source.find(keyed);
