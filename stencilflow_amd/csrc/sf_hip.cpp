@@ -1527,7 +1527,7 @@ static void execute(sf_plan& pl, int repetitions) {
 
 extern "C" {
 
-int sf_version(void) { return 1000; }
+int sf_version(void) { return 1001; }  // 1.1: sf_halo_*, sf_plan_execute_decomposed, sf_plan_stream, sf_plan_num_buffers, sf_code_cache_stats
 
 const char* sf_last_error(void) { return sf::g_last_error.c_str(); }
 
