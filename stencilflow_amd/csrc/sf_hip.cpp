@@ -899,11 +899,22 @@ static void build_plan(sf_plan& pl) {
         std::vector<int> group{k};
         std::set<std::string> extras;
         if (!cshape.extra.empty()) extras.insert(cshape.extra);
+        // 2-D groups with diagonal accesses (the 9-point box) are fastest two deep
+        // (profiles/r02_synth_perf.log: 8.7e5 / 8.6e5 / 6.8e5 Mcells/s at depth 2 / 3 / 4;
+        // star-like 2-D groups with extra fields keep the 2-D default of 4); an explicit
+        // fuse= option is followed as given
+        auto diagonal = [](const CompactShape& sh) {
+          return compact_lateral(sh.need, 0) || compact_lateral(sh.need, 2) || compact_lateral(sh.xneed, 0) ||
+                 compact_lateral(sh.xneed, 2);
+        };
+        bool group_diagonal = diagonal(cshape);
         while ((int)group.size() < fuse && k + (int)group.size() < K) {
           const int cur = group.back(), nxt = cur + 1;
           const Kernel& kc = P.kernels[cur];
           CompactShape nshape;
           if (!compact_eligible(P, P.kernels[nxt], &nshape, kc.name)) break;
+          if (P.nd == 2 && !pl.opt.kv.count("fuse") && (int)group.size() >= 2 && (group_diagonal || diagonal(nshape))) break;
+          group_diagonal = group_diagonal || diagonal(nshape);
           if (P.field(kc.name).role != Role::Temp) break;
           if (consumers[kc.name] != 1) break;
           if (P.kernels[nxt].dt != kc.dt) break;
