@@ -403,6 +403,9 @@ def main():
             # region -- and keep the faster one (maxima over ranks; an exchange timed
             # alone would not show a transport whose copies queue behind the compute kernel)
             def chain_seconds():
+                # (same random data for every candidate: attaching a transport proves
+                # itself on the buffers and clears them, and zeros flatter the clock)
+                runner.upload([synthetic(runner.local_shape, rank)])
                 runner.execute()
                 runner.synchronize()
                 dist.barrier()
