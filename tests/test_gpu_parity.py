@@ -855,3 +855,29 @@ def test_degenerate_programs(tmp_path):
         want = npo.run_reference(prog, inputs=ins)["b"]
         got, _ = _run_gpu(path, ins)
         assert got["b"].dtype == want.dtype and np.array_equal(got["b"], want), name
+
+
+def test_command_line_with_a_named_reference_checker(programs_dir, tmp_path):
+    """bin/synthesize.py -> bin/run_program.py ... -compare-to-reference: the CPU checker is
+    named on the command line (-reference-checker module:function); without one the
+    flag fails loudly -- the product never computes on the CPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("SF_REFERENCE_CHECKER", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bin", "synthesize.py"), "float32", "3", "1", "12", "16", "32",
+                        "1", "1", "1", "-stencil_shape", "box"], cwd=str(tmp_path), capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    prog = r.stdout.strip().split(": ")[-1]
+    cmd = [sys.executable, os.path.join(root, "bin", "run_program.py"), prog, "hardware", "-compare-to-reference",
+           "-log-level", "1"]
+    ok = subprocess.run(cmd + ["-reference-checker", "tests.reference_provider:reference_outputs"], cwd=str(tmp_path),
+                        capture_output=True, text=True, env=env)
+    assert ok.returncode == 0 and "Results verified" in ok.stdout, ok.stdout[-800:] + ok.stderr[-800:]
+    name = os.path.splitext(prog)[0].replace(".", "_")
+    out = np.fromfile(str(tmp_path / "results" / name / "b2.dat"), np.float32)
+    ref = np.fromfile(str(tmp_path / "results" / name / "reference" / "b2.dat"), np.float32)
+    assert out.size == 12 * 16 * 32 and np.array_equal(out, ref)
+    bad = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, env=env)
+    assert bad.returncode != 0 and "RuntimeError" in bad.stderr
