@@ -123,7 +123,7 @@ def test_decomposed_chain_protocol_gloo(tmp_path, world, fuse):
     _spawn(_chain_worker, world, (18, 6, 8), 5, fuse, str(tmp_path))
 
 
-def _gpu_worker(rank, world, port, shape, stages, overlap, groups, transport="gloo", early=False):
+def _gpu_worker(rank, world, port, shape, stages, overlap, groups, transport="gloo", early=False, native=False):
     import torch
     sys.path.insert(0, ROOT)
     import stencilflow_amd as sf
@@ -149,8 +149,12 @@ def _gpu_worker(rank, world, port, shape, stages, overlap, groups, transport="gl
     runner = SlabRunner(sfir, shape, rank, world, device=0, exchanger=exchanger,
                         overlap=overlap, groups_per_exchange=groups, early_exchange=early)
     runner.upload([x[runner.lo:runner.hi]])
-    runner.execute()
-    runner.synchronize()
+    if native:  # the same schedule run by the library itself (sf_plan_execute_decomposed)
+        runner.execute_native()
+        runner.plan.synchronize()
+    else:
+        runner.execute()
+        runner.synchronize()
     if transport in ("shm", "p2p"):
         exchanger.check()
     out = np.zeros(runner.local_shape, np.float32)
@@ -190,6 +194,14 @@ def test_processes_on_one_gpu_peer_to_peer_transport(world, overlap, groups, ear
     sharing the device -- everything but the xGMI wire; one of three ranks has two
     neighbours.  Results bit for bit against the oracle."""
     _spawn(_gpu_worker, world, (48, 20, 64), 19, overlap, groups, "p2p", early)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,groups", [(2, 4), (3, 2), (3, 1)])
+def test_native_deep_halo_schedule_matches_the_oracle(world, groups):
+    """SlabRunner.execute_native: the library's own schedule (sf_plan_execute_decomposed)
+    over its own transport, 2-3 processes on this GPU, against the oracle bit for bit."""
+    _spawn(_gpu_worker, world, (48, 20, 64), 19, True, groups, "p2p", False, True)
 
 
 def _c4_worker(rank, world, port, shape, stages, transport, out_dir):
