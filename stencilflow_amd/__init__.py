@@ -14,3 +14,4 @@ from .dtypes import str_to_dtype
 from .log_level import LogLevel
 from .kernel_chain_graph import Input, Kernel, KernelChainGraph, Output
 from .run_program import run_program, set_reference_backend
+from .run_distributed_program import run_distributed_program
