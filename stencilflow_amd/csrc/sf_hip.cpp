@@ -6,6 +6,7 @@
 #include "../../include/sf_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <amd_comgr/amd_comgr.h>
 #include <hip/hiprtc.h>
 
 #include <sys/stat.h>
@@ -69,6 +70,7 @@ struct CompiledKernel {
   double updates_per_launch = 0, alg_bytes_per_launch = 0;
   // from the code object's amdhsa metadata (msgpack note)
   int vgprs = -1, agprs = -1, sgprs = -1, spills = -1, scratch = -1, lds = -1, sgpr_spills = -1;
+  int late_exec_restores = 0;  // see count_late_exec_restores()
   bool from_disk = false;  // the code object came from the on-disk cache
 };
 
@@ -182,7 +184,105 @@ static int metadata_uint(const std::vector<char>& code, const char* key) {
   return -1;
 }
 
+// The toolchain fault behind the wrong results of "spilling" code objects (ROCm 7.2
+// LLVM for gfx950; found and proven in round 2, DESIGN.md §5.1, tools/asm_objects.py):
+// after a divergent `if` the compiler restores EXEC at the top of the join block
+// (`s_or_b64 exec, exec, s[a:b]`).  Under scalar-register pressure the greedy SGPR
+// allocator splits live ranges and puts its split copies (s_mov_b32/b64) or spill
+// code (v_readlane / v_writelane) at the top of that block, AHEAD of the restore --
+// harmless by themselves.  The VGPR allocator then no longer recognises the restore
+// as part of the block's prologue and places ITS copies and spill code ahead of it as
+// well, where they run under the narrowed EXEC of the `if` body: lanes (here: whole
+// waves, the condition being a thread row) that did not take the branch keep stale
+// registers.  Moving the restore back to the top of the block, and nothing else,
+// makes every failing object correct; padding every instruction with s_nop changes
+// nothing; the basic / fast SGPR allocators (which never split) do not produce it.
+// The enabling condition can be read off the machine code: an EXEC restore preceded by
+// a run of copy / spill instructions that contains an SGPR copy or an SGPR spill-lane
+// access.  A code object that contains it is never run.  (The instructions are told apart with comgr's
+// single-instruction disassembler; without one every SGPR-spilling object is refused, the
+// proxy that held in all measurements: -1.)
+namespace {
+struct DisasmCursor {
+  const char* base;
+  uint64_t size;
+  std::string text;
+};
+uint64_t disasm_read(uint64_t from, char* to, uint64_t size, void* user) {
+  auto* c = static_cast<DisasmCursor*>(user);
+  if (from >= c->size) return 0;
+  const uint64_t n = std::min<uint64_t>(size, c->size - from);
+  std::memcpy(to, c->base + from, n);
+  return n;
+}
+void disasm_print(const char* instruction, void* user) { static_cast<DisasmCursor*>(user)->text = instruction; }
+void disasm_address(uint64_t, void*) {}
+}  // namespace
+
+static int count_late_exec_restores(const std::vector<char>& code) {
+  if (code.size() < 64 || std::memcmp(code.data(), "\177ELF", 4) != 0 || code[4] != 2) return 0;
+  auto rd = [&](size_t off, int bytes) -> unsigned long long {
+    unsigned long long v = 0;
+    if (off + bytes > code.size()) return 0;
+    std::memcpy(&v, &code[off], bytes);
+    return v;
+  };
+  amd_comgr_disassembly_info_t info;
+  if (amd_comgr_create_disassembly_info("amdgcn-amd-amdhsa--gfx950", disasm_read, disasm_print, disasm_address, &info) !=
+      AMD_COMGR_STATUS_SUCCESS)
+    return -1;
+  const size_t shoff = rd(0x28, 8), shentsize = rd(0x3A, 2), shnum = rd(0x3C, 2);
+  int hits = 0;
+  for (size_t sidx = 0; sidx < shnum; ++sidx) {
+    const size_t sh = shoff + sidx * shentsize;
+    if (sh + 64 > code.size()) break;
+    const unsigned long long type = rd(sh + 4, 4), flags = rd(sh + 8, 8), off = rd(sh + 0x18, 8), size = rd(sh + 0x20, 8);
+    if (type != 1 /*SHT_PROGBITS*/ || !(flags & 4 /*SHF_EXECINSTR*/) || off + size > code.size()) continue;
+    // classes: R = EXEC restore, S = scalar allocator code (SGPR copy, spill-lane access),
+    // V = vector copy / spill code, N = padding, X = anything else
+    std::string classes;
+    DisasmCursor cur{code.data() + off, size, ""};
+    for (uint64_t at = 0; at < size;) {
+      uint64_t len = 0;
+      cur.text.clear();
+      if (amd_comgr_disassemble_instruction(info, at, &cur, &len) != AMD_COMGR_STATUS_SUCCESS || len == 0) {
+        classes += 'X';
+        at += 4;
+        continue;
+      }
+      at += len;
+      const size_t b = cur.text.find_first_not_of(" \t");
+      const std::string t = b == std::string::npos ? "" : cur.text.substr(b);
+      auto starts = [&](const char* p) { return t.compare(0, std::strlen(p), p) == 0; };
+      char c = 'X';
+      if (starts("s_or_b64 exec, exec, s[") || starts("s_xor_b64 exec, exec, s[") || starts("s_andn2_b64 exec, exec, s["))
+        c = 'R';
+      else if ((starts("s_mov_b32 s") || starts("s_mov_b64 s[") || starts("s_mov_b32 vcc") || starts("s_mov_b64 vcc")) &&
+               t.find("exec") == std::string::npos)
+        c = 'S';
+      else if (starts("v_readlane_b32 ") || starts("v_writelane_b32 "))
+        c = 'S';
+      else if (starts("v_mov_b32_e32 ") || starts("v_mov_b64_e32 ") || starts("v_accvgpr_") || starts("scratch_load_") ||
+               starts("scratch_store_"))
+        c = 'V';
+      else if (starts("s_nop") || starts("s_waitcnt"))
+        c = 'N';
+      classes += c;
+    }
+    for (size_t i = 0; i < classes.size(); ++i) {
+      if (classes[i] != 'R') continue;
+      bool scalar_code = false;
+      for (size_t j = i; j-- > 0 && (classes[j] == 'S' || classes[j] == 'V' || classes[j] == 'N');)
+        scalar_code = scalar_code || classes[j] == 'S';
+      if (scalar_code) ++hits;
+    }
+  }
+  amd_comgr_destroy_disassembly_info(info);
+  return hits;
+}
+
 static void read_metadata(CompiledKernel& k) {
+  k.late_exec_restores = count_late_exec_restores(k.code);
   k.vgprs = metadata_uint(k.code, ".vgpr_count");
   k.agprs = metadata_uint(k.code, ".agpr_count");
   k.sgprs = metadata_uint(k.code, ".sgpr_count");
@@ -288,6 +388,19 @@ static int intern_kernel(sf_plan& pl, const std::string& prefix, const std::stri
   k.flags = flags;
   const std::string key = k.name + "\n" + keyed;
   bool cached = false;
+  // (diagnostics: $SF_HIP_OBJECT_DIR/<kernel name>.co, a code object assembled by hand --
+  // e.g. the compiler's own output with instructions padded or moved, tools/asm_objects.py --
+  // takes the place of the compiler's; nothing is cached)
+  if (const char* dir = std::getenv("SF_HIP_OBJECT_DIR")) {
+    std::ifstream f(std::string(dir) + "/" + k.name + ".co", std::ios::binary);
+    if (f) {
+      k.code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+      read_metadata(k);
+      pl.kernels.push_back(std::move(k));
+      pl.kernel_by_source[keyed] = (int)pl.kernels.size() - 1;
+      return (int)pl.kernels.size() - 1;
+    }
+  }
   {
     std::lock_guard<std::mutex> lock(g_code_cache_mutex);
     auto c = g_code_cache.find(key);
@@ -569,17 +682,19 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
 }
 
 // What a code object's metadata says about its fitness.
-//  * SGPR spills make a kernel WRONG on gfx950 / ROCm 7.2 (tools/spill_probe.py,
-//    profiles/r02_spill_probe.log: every failing pinned shape of the star kernel
-//    spills SGPRs -- the buffer descriptors of the branch-free loads and stores are
-//    what drives the scalar registers out -- and no shape without SGPR spills fails,
-//    however many VGPRs it spills or AGPRs it uses): never accepted, unless the
-//    diagnostic environment variable SF_HIP_UNSAFE_SGPR_SPILLS=1 is set (the probe).
+//  * A code object in which register-allocator code sits ahead of an EXEC restore
+//    (count_late_exec_restores) is WRONG -- the toolchain fault behind every wrong result of
+//    "spilling" code objects seen in rounds 1 and 2 (tools/spill_probe.py: all failing shapes
+//    spill SGPRs; tools/asm_objects.py: why).  Never accepted, unless the diagnostic
+//    environment variable SF_HIP_UNSAFE_SGPR_SPILLS=1 is set (the probes).  SGPR spills as
+//    such (lane moves into a VGPR) are correct.
 //  * VGPR spills, scratch and AGPR copies are correct but slow: rejected by the
 //    planner's search, accepted for a pinned shape with allow_spills=1 (experiments).
 static bool kernel_unsafe(const CompiledKernel& k) {
   static const bool tolerate = std::getenv("SF_HIP_UNSAFE_SGPR_SPILLS") != nullptr;
-  return k.sgpr_spills > 0 && !tolerate;
+  // (SF_HIP_STRICT_SGPR_SPILLS=1: round 2's first criterion, any SGPR spill, on top)
+  static const bool strict = std::getenv("SF_HIP_STRICT_SGPR_SPILLS") != nullptr;
+  return (k.late_exec_restores > 0 || ((strict || k.late_exec_restores < 0) && k.sgpr_spills > 0)) && !tolerate;
 }
 static bool kernel_slow(const CompiledKernel& k) {
   return std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs) > 0;
@@ -640,9 +755,9 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
     }
     const CompiledKernel& k = pl.kernels[ck];
     if (pl.opt.get("debug", 0) != 0)
-      std::fprintf(stderr, "[sf_hip] candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d sgpr spill %d\n",
+      std::fprintf(stderr, "[sf_hip] candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d sgpr spill %d late exec restores %d\n",
                    ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs,
-                   k.agprs, k.spills, k.scratch, k.sgpr_spills);
+                   k.agprs, k.spills, k.scratch, k.sgpr_spills, k.late_exec_restores);
     (void)sgpr_rejects;  // (star kernels: SGPR spills do depend on the shape -- hotspot 512^3: shapes 1-3 spill, 4 does not)
     if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
       if (!out.ok) {
@@ -706,9 +821,9 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
     if (pl.opt.get("debug", 0) != 0)
       std::fprintf(stderr,
                    "[sf_hip] compact candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d "
-                   "scratch %d sgpr spill %d lds %d\n",
+                   "scratch %d sgpr spill %d late exec restores %d lds %d\n",
                    ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs, k.agprs,
-                   k.spills, k.scratch, k.sgpr_spills, k.lds);
+                   k.spills, k.scratch, k.sgpr_spills, k.late_exec_restores, k.lds);
     // scalar registers are spent on the group's windows and descriptors more than on the
     // tile shape: four shapes that spill them settle it for this group length
     if (kernel_unsafe(k) && ++sgpr_rejects >= 4) break;
@@ -1118,11 +1233,12 @@ static void build_plan(sf_plan& pl) {
         st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
       }
       // the one-point form is the last resort: VGPR spills there are slow but correct,
-      // SGPR spills are not acceptable anywhere
+      // a code object with allocator code ahead of an EXEC restore is not acceptable anywhere
       if (kernel_unsafe(pl.kernels[st.ck]))
         throw Error(SF_ERR_UNSUPPORTED, "operator '" + P.kernels[st.kernels[0]].name +
-                                            "': the generated kernel spills scalar registers, which gives wrong "
-                                            "results on gfx950 (profiles/r02_spill_probe.log); simplify the operator");
+                                            "': the compiler placed register-allocator code ahead of an EXEC "
+                                            "restore in the generated kernel, which gives wrong results on gfx950 "
+                                            "(DESIGN.md 5.1); simplify the operator");
       st.generic_vk = g.vk;
       st.generic_ppt = g.planes_per_thread;
       st.scalars = g.scalars;
@@ -1729,7 +1845,8 @@ int sf_plan_kernel_resources(const sf_plan* p, int i, int* vgprs, int* agprs, in
   if (scratch) *scratch = k.scratch;
   if (lds) *lds = k.lds;
   // (diagnostics: SF_HIP_REPORT_SGPR_SPILLS=1 reports SGPR spills in place of the scratch size)
-  if (scratch && std::getenv("SF_HIP_REPORT_SGPR_SPILLS")) *scratch = k.sgpr_spills;
+  // (... plus 1000 x the EXEC restores found behind allocator code, count_late_exec_restores)
+  if (scratch && std::getenv("SF_HIP_REPORT_SGPR_SPILLS")) *scratch = k.sgpr_spills + 1000 * k.late_exec_restores;
   return SF_OK;
 }
 int sf_plan_debug_counters(sf_plan* plan, unsigned long long* out, int count) {

@@ -42,7 +42,7 @@ def main():
     ins5 = {k: v["data"] for k, v in c5["inputs"].items() if k != "a"}
     want5 = npo.run_reference(c5, dict(ins5, a=x5))["lap"]
     cases.append(("c5", c5, x5, want5, 0.0, [ins5[k] for k in c5["inputs"] if k != "a"]))
-    nfail = ntotal = 0
+    nfail = ntotal = nsgpr = 0
     with tempfile.TemporaryDirectory() as tmp:
         for name, prog, x, want, tol, scal in cases:
             path = programs.write_program(prog, os.path.join(tmp, "p.json"))
@@ -67,6 +67,10 @@ def main():
                 plan.run([x], [out], 1)
                 plan.close()
                 ntotal += 1
+                # (SF_HIP_REPORT_SGPR_SPILLS=1: `scratch` carries the SGPR spill count; such objects run
+                # since the criterion became "no allocator code ahead of an EXEC restore")
+                if os.environ.get("SF_HIP_REPORT_SGPR_SPILLS"):
+                    nsgpr += any(r["scratch"] % 1000 > 0 for r in res)
                 if ntotal % 50 == 0:
                     print("# %d configurations run, %d failures so far" % (ntotal, nfail), flush=True)
                 ok = np.array_equal(out, want) if tol == 0.0 else npo.arrays_match(want, out, tol)
@@ -74,7 +78,7 @@ def main():
                     nfail += 1
                     print(json.dumps({"case": name, "opt": opt, "maxrel": npo.max_rel_err(want, out),
                                       "res": res}), flush=True)
-    print("configs run: %d, failures: %d" % (ntotal, nfail))
+    print("configs run: %d (%d of them with code objects that spill SGPRs), failures: %d" % (ntotal, nsgpr, nfail))
 
 
 if __name__ == "__main__":

@@ -38,6 +38,8 @@ def main():
     out_dir = os.path.join("gpurun_out", "spill")
     os.makedirs(out_dir, exist_ok=True)
     kept = {"fail": 0, "pass_spill": 0}
+    tally = {"shapes": 0, "failing": 0, "flagged": 0, "failing_unflagged": 0, "flagged_passing": 0,
+             "sgpr_spilling_unflagged_passing": 0}
     with tempfile.TemporaryDirectory() as tmp:
         path = programs.write_program(prog, os.path.join(tmp, "p.json"))
         sfir = lower(sf.KernelChainGraph(path))
@@ -54,7 +56,16 @@ def main():
             plan.run([x], [got], 1)
             bad = np.argwhere(got != want)
             spilled = any(r["spills"] or r["scratch"] or r["agprs"] for r in res.values())
-            line = {"opt": opt, "res": list(res.values()), "spilled": spilled, "bad_points": int(len(bad))}
+            # (SF_HIP_REPORT_SGPR_SPILLS=1: `scratch` = SGPR spills + 1000 x EXEC restores behind allocator code)
+            late = sum(r["scratch"] // 1000 for r in res.values())
+            line = {"opt": opt, "res": list(res.values()), "spilled": spilled, "bad_points": int(len(bad)),
+                    "sgpr_spills": sum(r["scratch"] % 1000 for r in res.values()), "late_exec_restores": late}
+            tally["shapes"] += 1
+            tally["failing"] += bool(len(bad))
+            tally["flagged"] += bool(late)
+            tally["failing_unflagged"] += bool(len(bad)) and not late
+            tally["flagged_passing"] += bool(late) and not len(bad)
+            tally["sgpr_spilling_unflagged_passing"] += (not late) and (not len(bad)) and line["sgpr_spills"] > 0
             if len(bad):
                 line["bad_i"] = sorted(set(int(b[0]) for b in bad))[:20]
                 line["bad_j"] = sorted(set(int(b[1]) for b in bad))[:40]
@@ -69,6 +80,7 @@ def main():
                     with open(os.path.join(out_dir, "{}_{}_{}.hip".format(tag, kept[tag], name)), "w") as f:
                         f.write("// " + json.dumps(line) + "\n" + plan.kernel_source(i))
             plan.close()
+    print("# " + json.dumps(tally), flush=True)
 
 
 if __name__ == "__main__":
