@@ -808,7 +808,21 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
                       (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
   const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
   int rejected = 0, sgpr_rejects = 0;
-  for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {
+  // Dense 3-D groups (box-like: every operator reads 18 or more of the 27 offsets of one field)
+  // are bound by vector-instruction issue; letting the scheduler mix the rows of a step is worth
+  // +4 % there (27-point box 512^3: 7.49 -> 7.75e5, profiles/r02_synth_box.log) and costs 12
+  // registers, so the unfenced form is tried first and the fenced one if it does not come out clean.
+  bool dense = P.n[1] != 1 && !pl.opt.kv.count("k1.fence");
+  for (size_t si = 0; dense && si < kernels.size(); ++si) {
+    CompactShape sh;
+    const std::string want = si == 0 ? std::string() : P.kernels[kernels[si - 1]].name;
+    dense = compact_eligible(P, P.kernels[kernels[si]], &sh, want) && sh.extra.empty() &&
+            __builtin_popcount(sh.need) >= 18;
+  }
+  for (size_t ci2 = 0; ci2 < 2 * tries && rejected < 2; ++ci2) {
+    const size_t ci = ci2 / 2;
+    if (!dense && (ci2 & 1)) continue;
+    if (dense) ranked[ci].row_fence = (int)(ci2 & 1);
     StarKernelSource g = gen_compact(P, kernels, ranked[ci]);
     int ck = -1;
     try {
