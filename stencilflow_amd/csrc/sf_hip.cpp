@@ -257,10 +257,15 @@ static int count_late_exec_restores(const std::vector<char>& code) {
       char c = 'X';
       if (starts("s_or_b64 exec, exec, s[") || starts("s_xor_b64 exec, exec, s[") || starts("s_andn2_b64 exec, exec, s["))
         c = 'R';
+      else if (t.find("_saveexec_b64") != std::string::npos || starts("s_mov_b64 exec,") || starts("s_and_b64 exec,"))
+        c = 'E';  // EXEC narrowed: an `if` body starts behind it
       else if ((starts("s_mov_b32 s") || starts("s_mov_b64 s[") || starts("s_mov_b32 vcc") || starts("s_mov_b64 vcc")) &&
-               t.find("exec") == std::string::npos)
-        c = 'S';
-      else if (starts("v_readlane_b32 ") || starts("v_writelane_b32 "))
+               t.find("exec") == std::string::npos) {
+        // register-to-register (a split copy) or a constant (a rematerialised value -- or what the program says)
+        const size_t comma = t.find(", ");
+        const char first = comma == std::string::npos || comma + 2 >= t.size() ? 's' : t[comma + 2];
+        c = (first == 's' || first == 'v' || first == 't' || first == 'm') ? 'S' : 'C';
+      } else if (starts("v_readlane_b32 ") || starts("v_writelane_b32 "))
         c = 'S';
       else if (starts("v_mov_b32_e32 ") || starts("v_mov_b64_e32 ") || starts("v_accvgpr_") || starts("scratch_load_") ||
                starts("scratch_store_"))
@@ -271,10 +276,17 @@ static int count_late_exec_restores(const std::vector<char>& code) {
     }
     for (size_t i = 0; i < classes.size(); ++i) {
       if (classes[i] != 'R') continue;
-      bool scalar_code = false;
-      for (size_t j = i; j-- > 0 && (classes[j] == 'S' || classes[j] == 'V' || classes[j] == 'N');)
-        scalar_code = scalar_code || classes[j] == 'S';
-      if (scalar_code) ++hits;
+      bool copies = false, constants = false;
+      size_t j = i;
+      while (j > 0 && (classes[j - 1] == 'S' || classes[j - 1] == 'C' || classes[j - 1] == 'V' || classes[j - 1] == 'N')) {
+        --j;
+        copies = copies || classes[j] == 'S';
+        constants = constants || classes[j] == 'C';
+      }
+      // a run of constants and vector moves that reaches back to where EXEC was narrowed is the
+      // whole body of an `if` that selects a constant: what the program says
+      const bool whole_body = j > 0 && classes[j - 1] == 'E';
+      if (copies || (constants && !whole_body)) ++hits;
     }
   }
   amd_comgr_destroy_disassembly_info(info);
@@ -290,10 +302,10 @@ static void read_metadata(CompiledKernel& k) {
   k.scratch = metadata_uint(k.code, ".private_segment_fixed_size");
   k.lds = metadata_uint(k.code, ".group_segment_fixed_size");
   // The SGPR allocator splits and spills only once it has run out of registers, and then the
-  // object reports all of them in use (106 on gfx950; the kernels of the benchmarks report 46-89).
-  // Below that no allocator code exists and a constant set inside an `if` body next to the
-  // restore -- which reads the same -- is what the program says.
-  k.late_exec_restores = k.sgprs >= 96 ? count_late_exec_restores(k.code) : 0;
+  // object reports all of them in use (106 on gfx950: every object of the probes that shows the
+  // fault; the kernels of the benchmarks report 46-89 and show nothing).  Far below that no
+  // allocator code exists, and scalar moves next to a restore are what the program says.
+  k.late_exec_restores = k.sgprs >= 64 ? count_late_exec_restores(k.code) : 0;
 }
 
 // Code objects are cached per process: plans of the same program (slab ranks,
