@@ -257,15 +257,10 @@ static int count_late_exec_restores(const std::vector<char>& code) {
       char c = 'X';
       if (starts("s_or_b64 exec, exec, s[") || starts("s_xor_b64 exec, exec, s[") || starts("s_andn2_b64 exec, exec, s["))
         c = 'R';
-      else if (t.find("_saveexec_b64") != std::string::npos || starts("s_mov_b64 exec,") || starts("s_and_b64 exec,"))
-        c = 'E';  // EXEC narrowed: an `if` body starts behind it
       else if ((starts("s_mov_b32 s") || starts("s_mov_b64 s[") || starts("s_mov_b32 vcc") || starts("s_mov_b64 vcc")) &&
-               t.find("exec") == std::string::npos) {
-        // register-to-register (a split copy) or a constant (a rematerialised value -- or what the program says)
-        const size_t comma = t.find(", ");
-        const char first = comma == std::string::npos || comma + 2 >= t.size() ? 's' : t[comma + 2];
-        c = (first == 's' || first == 'v' || first == 't' || first == 'm') ? 'S' : 'C';
-      } else if (starts("v_readlane_b32 ") || starts("v_writelane_b32 "))
+               t.find("exec") == std::string::npos)
+        c = 'S';  // a split copy, or a constant: the allocator rematerialises values the same way
+      else if (starts("v_readlane_b32 ") || starts("v_writelane_b32 "))
         c = 'S';
       else if (starts("v_mov_b32_e32 ") || starts("v_mov_b64_e32 ") || starts("v_accvgpr_") || starts("scratch_load_") ||
                starts("scratch_store_"))
@@ -276,17 +271,13 @@ static int count_late_exec_restores(const std::vector<char>& code) {
     }
     for (size_t i = 0; i < classes.size(); ++i) {
       if (classes[i] != 'R') continue;
-      bool copies = false, constants = false;
-      size_t j = i;
-      while (j > 0 && (classes[j - 1] == 'S' || classes[j - 1] == 'C' || classes[j - 1] == 'V' || classes[j - 1] == 'N')) {
-        --j;
-        copies = copies || classes[j] == 'S';
-        constants = constants || classes[j] == 'C';
-      }
-      // a run of constants and vector moves that reaches back to where EXEC was narrowed is the
-      // whole body of an `if` that selects a constant: what the program says
-      const bool whole_body = j > 0 && classes[j - 1] == 'E';
-      if (copies || (constants && !whole_body)) ++hits;
+      // (no exemption for constants, nor for runs that reach back to where EXEC was narrowed: an object
+      // with `s_or_saveexec; s_mov vcc_lo, <constant>; v_mov_b64 copies; s_xor_b64 exec` -- allocator code
+      // inside an `else` prologue -- gave wrong results, profiles/r02_config_fuzz_detector.log)
+      bool scalar_code = false;
+      for (size_t j = i; j-- > 0 && (classes[j] == 'S' || classes[j] == 'V' || classes[j] == 'N');)
+        scalar_code = scalar_code || classes[j] == 'S';
+      if (scalar_code) ++hits;
     }
   }
   amd_comgr_destroy_disassembly_info(info);

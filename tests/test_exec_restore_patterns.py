@@ -41,9 +41,14 @@ PATTERNS = {
     # a rematerialised constant ahead of the restore, behind other instructions of the body
     "constant_after_body": ("s_and_saveexec_b64 s[0:1], vcc\n ds_read_b32 v1, v2\n s_mov_b32 s6, 0x3fdc28f5\n"
                             " s_or_b64 exec, exec, s[0:1]\n", 1),
-    # what a program says: an `else` body that only selects a constant
+    # an `else` body that only selects a constant reads the same as a rematerialised constant next to
+    # allocator copies: flagged when scalar registers are exhausted (the price of being sure), not
+    # searched at all below that (test_objects_far_from_register_exhaustion_are_not_searched)
     "constant_select": ("s_andn2_saveexec_b64 s[0:1], s[6:7]\n s_mov_b32 s6, 0xc28f5c29\n s_mov_b32 s7, 0x3fdc28f5\n"
-                        " v_mov_b64_e32 v[6:7], s[6:7]\n s_or_b64 exec, exec, s[0:1]\n", 0),
+                        " v_mov_b64_e32 v[6:7], s[6:7]\n s_or_b64 exec, exec, s[0:1]\n", 1),
+    # seen in a failing object (tools/config_fuzz.py, math program): allocator code inside an `else` prologue
+    "else_prologue": ("s_or_saveexec_b64 s[0:1], s[0:1]\n s_mov_b32 vcc_lo, 0x9037ab78\n v_mov_b64_e32 v[48:49], v[52:53]\n"
+                      " s_mov_b32 vcc_hi, 0x3e21eeb6\n v_mov_b64_e32 v[50:51], v[54:55]\n s_xor_b64 exec, exec, s[0:1]\n", 1),
     # an ordinary join
     "plain_join": ("s_and_saveexec_b64 s[0:1], vcc\n ds_read_b32 v1, v2\n v_add_f32_e32 v1, v1, v1\n"
                    " s_or_b64 exec, exec, s[0:1]\n", 0),
@@ -103,9 +108,10 @@ def test_pattern(base, label):
     assert got["resources"]["scratch"] // 1000 == want, (label, got["resources"])
 
 
-def test_objects_far_from_register_exhaustion_are_not_searched(base):
-    snippet, _ = PATTERNS["split_copy"]
-    got = _plan_report(SF_HIP_OBJECT_DIR=_object_with(base, "low_pressure", snippet, 40), SF_HIP_UNSAFE_SGPR_SPILLS="1")
+@pytest.mark.parametrize("label", ["split_copy", "constant_select"])
+def test_objects_far_from_register_exhaustion_are_not_searched(base, label):
+    snippet, _ = PATTERNS[label]
+    got = _plan_report(SF_HIP_OBJECT_DIR=_object_with(base, "low_pressure_" + label, snippet, 40), SF_HIP_UNSAFE_SGPR_SPILLS="1")
     assert got["resources"]["scratch"] // 1000 == 0
 
 
