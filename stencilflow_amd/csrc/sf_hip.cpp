@@ -255,8 +255,9 @@ static int count_late_exec_restores(const std::vector<char>& code) {
       const std::string t = b == std::string::npos ? "" : cur.text.substr(b);
       auto starts = [&](const char* p) { return t.compare(0, std::strlen(p), p) == 0; };
       char c = 'X';
-      if (starts("s_or_b64 exec, exec, s[") || starts("s_xor_b64 exec, exec, s[") || starts("s_andn2_b64 exec, exec, s["))
-        c = 'R';
+      if (starts("s_or_b64 exec, exec, s[") || starts("s_xor_b64 exec, exec, s[") || starts("s_andn2_b64 exec, exec, s[") ||
+          starts("s_or_saveexec_b64 ") || starts("s_andn2_saveexec_b64 "))
+        c = 'R';  // end of an `if`, `else` entry (two forms), loop exit: the EXEC updates that open a block
       else if ((starts("s_mov_b32 s") || starts("s_mov_b64 s[") || starts("s_mov_b32 vcc") || starts("s_mov_b64 vcc")) &&
                t.find("exec") == std::string::npos)
         c = 'S';  // a split copy, or a constant: the allocator rematerialises values the same way

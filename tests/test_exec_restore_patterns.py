@@ -49,6 +49,9 @@ PATTERNS = {
     # seen in a failing object (tools/config_fuzz.py, math program): allocator code inside an `else` prologue
     "else_prologue": ("s_or_saveexec_b64 s[0:1], s[0:1]\n s_mov_b32 vcc_lo, 0x9037ab78\n v_mov_b64_e32 v[48:49], v[52:53]\n"
                       " s_mov_b32 vcc_hi, 0x3e21eeb6\n v_mov_b64_e32 v[50:51], v[54:55]\n s_xor_b64 exec, exec, s[0:1]\n", 1),
+    # the same ahead of an `else` entry
+    "before_else_entry": ("s_and_saveexec_b64 s[0:1], vcc\n ds_read_b32 v1, v2\n v_mov_b32_e32 v3, v4\n"
+                          " s_mov_b64 s[4:5], s[10:11]\n s_or_saveexec_b64 s[0:1], s[0:1]\n", 1),
     # an ordinary join
     "plain_join": ("s_and_saveexec_b64 s[0:1], vcc\n ds_read_b32 v1, v2\n v_add_f32_e32 v1, v1, v1\n"
                    " s_or_b64 exec, exec, s[0:1]\n", 0),
