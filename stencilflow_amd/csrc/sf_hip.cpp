@@ -2336,6 +2336,11 @@ extern "C" int sf_plan_execute_decomposed(sf_plan* plan, sf_halo* halo, int repe
       if (rc != SF_OK) throw Error(rc, sf_last_error());
     }
   };
+  // program inputs no launch writes (extra fields, auxiliary fields): their ghost planes are
+  // filled once per call, to the full halo depth, at the first launch that reads them
+  std::set<int> fixed, fresh;
+  for (int i = 0; i < P.num_inputs; ++i) fixed.insert(pl.input_buf[i]);
+  for (const Step& st : pl.steps) fixed.erase(st.out_buf);
   for (int rep = 0; rep < repetitions; ++rep) {
     int valid = 0;  // ghost planes of the chain's current field that are still good
     for (size_t s = 0; s < pl.steps.size(); ++s) {
@@ -2361,6 +2366,22 @@ extern "C" int sf_plan_execute_decomposed(sf_plan* plan, sf_halo* halo, int repe
             bufs.push_back(b);
       }
       const int depth = chain ? H : d;
+      if (!chain) {
+        std::vector<int> now, once;
+        for (int b : bufs) {
+          if (fresh.count(b)) continue;
+          if (fixed.count(b)) {
+            once.push_back(b);
+            fresh.insert(b);
+          } else {
+            now.push_back(b);
+          }
+        }
+        exchange_all(once, H);
+        bufs = now;
+        bufs.insert(bufs.end(), once.begin(), once.end());  // (finish_all below waits for both)
+        exchange_all(now, depth);
+      } else
       exchange_all(bufs, depth);
       launch_ranges(pl, st, has_lower ? d : 0, n - (has_upper ? d : 0), 0, 0, pl.stream);  // beside the transfer
       finish_all(bufs);

@@ -636,6 +636,11 @@ class SlabRunner:
         self._valid = 0
         self._early = None  # (step, handles) of an exchange started a launch ahead
         self.early_exchange = bool(early_exchange)
+        # program inputs no launch writes (extra fields, auxiliary fields): their ghost planes are
+        # filled ONCE per execution, to the full halo depth, at the first launch that reads them
+        written = set(self.outputs)
+        self._static = {self.plan.input_buffer(i) for i in range(len(self.plan.input_names))} - written
+        self._fresh = set()
         if world > 1 and hasattr(self.exchanger, "attach"):
             self.attach_exchanger(self.exchanger)
 
@@ -684,6 +689,7 @@ class SlabRunner:
         if s == 0:
             self._valid = 0
             self._early = None
+            self._fresh = set()
         with torch.cuda.stream(self.stream):
             if self.world == 1:
                 self.plan.execute_step(s, 0, raw)
@@ -724,8 +730,13 @@ class SlabRunner:
                 handles = []
                 for buf in (self._slabbed_inputs(s) if not self.is_chain
                             else [self.inputs[s][0]]):
+                    if buf in self._fresh:
+                        continue  # a program input whose ghost planes are in place
                     tensor, plane_bytes, _ = self._buffer_tensor(buf)
-                    regions = halo_regions(n, H, depth, plane_bytes)
+                    once = (not self.is_chain) and buf in self._static
+                    if once:
+                        self._fresh.add(buf)
+                    regions = halo_regions(n, H, H if once else depth, plane_bytes)
                     # the transfer waits for everything queued so far (the planes it
                     # sends were produced by the previous launch) ...
                     handles.append(self.exchanger.start(tensor, regions, key=buf))

@@ -374,3 +374,70 @@ def test_bench_self_loop_selects_rccl():
     deco = rec["config"]["decomposition"]
     assert "slab3" in deco and "RCCL send/recv" in deco and "SELF-LOOP TEST" in deco, deco
     assert rec["value"] > 0 and "roofline" not in rec
+
+
+@pytest.mark.gpu
+def test_program_inputs_no_launch_writes_are_exchanged_once(tmp_path):
+    """A chain whose every operator also reads one extra field across planes (the shape of the
+    reference generator's extra spatial fields, bin/synthesize.py:170-196) on two slabs: the extra
+    field is a program input no launch writes, so its ghost planes are filled once per
+    execution -- at the first launch that reads it, to the full halo depth -- and every
+    later launch finds them in place; fields the launches produce are exchanged whenever
+    they are read across planes.  Result equal to the oracle bit for bit, twice in a row."""
+    import numpy as np
+    from oracle import numpy_oracle as npo
+    import stencilflow_amd as sf
+    from stencilflow_amd import programs
+    from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
+    from stencilflow_amd.lowering import lower
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": "float32"},
+                       "e": {"data": "constant:0.5", "data_type": "float32"}},
+            "outputs": ["b3"], "dimensions": [24, 20, 32], "program": {}}
+    for t in range(4):
+        src = "a" if t == 0 else "b%d" % (t - 1)
+        prog["program"]["b%d" % t] = {
+            "computation_string": "b{t} = 0.25 * ({s}[i-1,j,k] + {s}[i+1,j,k] + {s}[i,j,k-1] + {s}[i,j+1,k]) + "
+                                  "0.125 * (e[i-1,j,k] + e[i+1,j,k] + e[i,j-1,k+1])".format(t=t, s=src),
+            "boundary_conditions": {src: {"type": "constant", "value": 0.0}, "e": {"type": "constant", "value": 1.0}},
+            "data_type": "float32"}
+    rng = np.random.default_rng(77)
+    p = npo.load_program(prog)
+    ins = {n: rng.uniform(-1, 1, npo._dims_shape(p, npo._input_dims(p, n))).astype(np.float32) for n in p["inputs"]}
+    want = npo.run_reference(prog, inputs=ins)
+    sfir = lower(sf.KernelChainGraph(programs.write_program(prog, str(tmp_path / "p.json"))))
+    shape, world = tuple(prog["dimensions"]), 2
+    exch = LocalExchanger(world)
+    runners = [SlabRunner(sfir, shape, r, world, options={"fuse": 2}, exchanger=exch.for_rank(r), groups_per_exchange=1)
+               for r in range(world)]
+    assert runners[0].plan.num_launches >= 2
+    counts = [{} for _ in runners]
+    for r, seen in zip(runners, counts):
+        inner = r.exchanger.start
+
+        def counting(tensor, regions, key=None, _inner=inner, _seen=seen):
+            _seen[key] = _seen.get(key, 0) + 1
+            return _inner(tensor, regions, key=key)
+        r.exchanger.start = counting
+    r0 = runners[0]
+    fixed = r0._static
+    assert fixed and len(fixed) < len(r0.plan.input_names) + 1
+    readers = {b: sum(1 for s in range(len(r0.steps)) if b in r0.inputs[s] and r0.steps[s][1] > 0) for b in fixed}
+    assert max(readers.values()) >= 2, "the program should read an extra field in more than one launch"
+    for execution in range(2):
+        for seen in counts:
+            seen.clear()
+        for r in runners:
+            r.upload([np.ascontiguousarray(ins[n][r.lo:r.hi]) for n in r.plan.input_names])
+        run_lockstep(runners)
+        for seen in counts:
+            assert all(seen.get(b, 0) == 1 for b in fixed if readers[b] > 0), (seen, fixed)
+            assert any(v > 1 for b, v in seen.items() if b not in fixed) or len(seen) > len(fixed)
+        name = r0.plan.output_names[0]
+        got = np.zeros(shape, np.float32)
+        for r in runners:
+            part = [np.zeros(r.local_shape, np.float32) for _ in r.plan.output_names]
+            r.download(part)
+            got[r.lo:r.hi] = part[0]
+        assert np.array_equal(got, want[name])
+    for r in runners:
+        r.close()
