@@ -1,5 +1,11 @@
-import sys, os, tempfile
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""GPU: one operator per launch on the generic kernel (jacobi3d 512^3 f32, option generic_only=1) --
+the command tools/profile.sh wraps when the generic kernel alone is to be profiled.  Prints ms per operator."""
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import stencilflow_amd as sf
 from stencilflow_amd import programs

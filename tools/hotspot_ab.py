@@ -1,7 +1,9 @@
 """GPU: hotspot chains (centre-only auxiliary field per stage) with and without early
 auxiliary-row requests (k1.auxpre)."""
+import os
 import sys
-sys.path.insert(0, "/root/repo")
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import stencilflow_amd as sf
 from stencilflow_amd.backend import Plan
