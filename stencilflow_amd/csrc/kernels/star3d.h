@@ -152,9 +152,20 @@ struct sf_state
 #endif
 };
 
+#ifndef SF_AUX_PASS
+#define SF_AUX_PASS 0
+#endif
+#if SF_AUX_PASS
+typedef sf_stage<2>::aux_row sf_aux_passed;
+static_assert(sizeof(sf_stage<1>::aux_row) == sizeof(sf_aux_passed), "stages must share the auxiliary row layout");
+#endif
+
 struct sf_ctx {
   const sf_t* in;
   sf_auxptrs aux;  // centre-only auxiliary fields (same layout as `in`)
+#if SF_AUX_PASS
+  sf_aux_passed* aux_lds;  // [step parity][row][thread]: stage 1's auxiliary rows on their way to stage 2
+#endif
   int tx, ty, lane, wave;
   unsigned jmask, kmask, store_mask;
   bool kvec_in;
@@ -355,6 +366,22 @@ __device__ __forceinline__ typename sf_stage<S>::aux_row sf_aux_row(const sf_ctx
       plane_ok && row_ok && cx.kvec_in, (long long)(q + cx.halo), cx.j0 + r, cx.k0, plane_ok, row_ok, cx.kvec_in);
 }
 
+#if SF_AUX_PASS
+// SF_AUX_PASS (T = 2, both operators read the same auxiliary fields): stage 2 evaluates at step
+// p + 1 the plane stage 1 evaluated at step p, so stage 1 leaves its auxiliary rows in LDS --
+// slots private to the thread, [step parity][row][thread]: no barrier, no bank conflict -- and
+// stage 2 takes them from there instead of requesting the fields a second time.
+__device__ __forceinline__ void sf_aux_pass(const sf_ctx& cx, const int p, const int r,
+                                            const typename sf_stage<1>::aux_row& ax) {
+  sf_aux_passed v;
+  __builtin_memcpy(&v, &ax, sizeof v);
+  cx.aux_lds[((p & 1) * SF_RJ + r) * (SF_BX * SF_BY) + cx.ty * SF_BX + cx.tx] = v;
+}
+__device__ __forceinline__ sf_aux_passed sf_aux_take(const sf_ctx& cx, const int p, const int r) {
+  return cx.aux_lds[(((p - 1) & 1) * SF_RJ + r) * (SF_BX * SF_BY) + cx.ty * SF_BX + cx.tx];
+}
+#endif
+
 // One stage of the fused group at one step: reads the source window of stage
 // S-1 at phase PH and writes plane q = p - S of stage S (into its own window, or
 // to HBM for the last stage).
@@ -368,10 +395,12 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
   // first / last row of the neighbouring thread rows (LDS)
   sf_vec jm0 = st.w[src][icur][0], jpl = st.w[src][icur][SF_RJ - 1];
   if constexpr (!SF_NOJ && SF_EXPERIMENT != 4) {
-    if (ty > 0)
-      jm0 = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(src, ty - 1, 1) + tx * SF_VK]);
-    if (ty < SF_BY - 1)
-      jpl = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(src, ty + 1, 0) + tx * SF_VK]);
+    // No test of the thread row: the first / last thread row of the tile reads an image that
+    // exists (its own) -- rows 0 and SF_RJ-1 there are halo rows, whatever they take as their
+    // outer neighbour never reaches a stored value.  A divergent `if` here was the construct on
+    // which the toolchain fault of DESIGN.md 5.1 showed.
+    jm0 = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(src, ty > 0 ? ty - 1 : 0, 1) + tx * SF_VK]);
+    jpl = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(src, ty < SF_BY - 1 ? ty + 1 : ty, 0) + tx * SF_VK]);
   }
   // plane this stage produces (local owned coords).  SF_REVERSE: every stage
   // reads only planes finished in earlier steps, so stage S lags 2S-1 steps.
@@ -400,6 +429,10 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
     axs[r] = static_cast<sf_auxslots<S>&>(st).a[r];
     static_cast<sf_auxslots<S>&>(st).a[r] = sf_aux_row<S>(cx, q + 1, r);
 #else
+#if SF_AUX_PASS
+    if constexpr (sf_stage<S>::aux_from_prev) axs[r] = sf_aux_take(cx, p, r);
+    else
+#endif
     axs[r] = sf_aux_row<S>(cx, q, r);
 #endif
   }
@@ -452,6 +485,9 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
     // centre-only auxiliary fields of this stage, row r of plane q
 #if SF_AUX_AHEAD
     const auto ax = axs[r];
+#if SF_AUX_PASS
+    if constexpr (sf_stage<S>::aux_to_next) sf_aux_pass(cx, p, r, ax);
+#endif
 #else
     const auto ax = sf_aux_row<S>(cx, q, r);
 #endif
@@ -718,10 +754,16 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     ) {
   // SF_LDS_DB: two exchange images used alternately -> one barrier per step
   __shared__ sf_t lds_all[(SF_LDS_DB ? 2 : 1) * SF_IMAGE_ELEMS];
+#if SF_AUX_PASS
+  __shared__ sf_aux_passed lds_aux[2 * SF_RJ * SF_BX * SF_BY];
+#endif
 
   sf_ctx cx;
   cx.in = in;
   cx.aux = aux;
+#if SF_AUX_PASS
+  cx.aux_lds = lds_aux;
+#endif
   cx.tx = threadIdx.x;
   // thread row and wave-within-row are the same for all lanes of a wave (SF_BX is
   // a multiple of 64): telling the compiler so makes every test on them a scalar branch

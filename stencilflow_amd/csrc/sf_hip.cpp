@@ -623,6 +623,7 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   // whole step ahead into per-stage slots (2-D, where a thread has one row and
   // registers to spare, +11 %)
   base.aux_ahead = (int)pl.opt.get("k1.auxpre", base.noj ? 2 : 1);
+  base.aux_pass = (int)pl.opt.get("k1.auxpass", 1);
   // Non-temporal output stores when a field is larger than the 256 MiB Infinity
   // Cache: nothing of it would survive until the next launch reads it, and not
   // allocating the written lines leaves the cache to the input stream (C3 +3 %,
