@@ -21,7 +21,7 @@ out = {}
 with tempfile.TemporaryDirectory() as tmp:
     # a pinned tile shape whose three-operator object is known to carry the fault (tools/spill_probe2.py)
     path = programs.write_program(programs.jacobi3d((14, 30, 64), 3, bc_value=0.25), os.path.join(tmp, "p.json"))
-    plan = Plan(lower(sf.KernelChainGraph(path)), options={"fuse": 3, "k1.bx": 64, "k1.by": 2, "k1.rj": 6, "allow_spills": 1})
+    plan = Plan(lower(sf.KernelChainGraph(path)), options={"fuse": 3, "k1.bx": 128, "k1.by": 2, "k1.rj": 8, "allow_spills": 1})
     out["pinned"] = {"describe": plan.describe(), "resources": plan.kernel_resources()}
     plan.close()
     # the benchmark's kernel
