@@ -4,6 +4,9 @@ results (tools/spill_probe.py).  Only the shapes that failed th
 ONE fused launch (3 operators, fuse=3), and for every wrong plane what it holds
 instead: zeros, another plane of the right answer, the answer with one input plane
 missing ...  Compiler flags under test come in through SF_HIP_EXTRA_FLAGS.
+(FAILING lists the shapes that failed with the kernel skeleton of mid round 2 -- git 54b8989 --, whose two LDS
+reads under `if (ty ...)` were the trigger; with the skeleton that reads them unconditionally none of them fails,
+profiles/r02_spill_probe_final_skeleton.log.  To see the fault again check that commit out.)
 usage: SF_HIP_UNSAFE_SGPR_SPILLS=1 SF_HIP_REPORT_SGPR_SPILLS=1 spill_probe2.py [n0]"""
 import json
 import os
