@@ -748,6 +748,7 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
   const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
   int rejected = 0, sgpr_rejects = 0;
   for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {  // compile errors rarely depend on the shape
+    ranked[ci].lds_bytes = star_lds_bytes(ranked[ci], dt);
     StarKernelSource g = gen_star(P, kernels, ranked[ci]);
     int ck = -1;
     try {
