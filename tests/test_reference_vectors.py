@@ -130,3 +130,18 @@ def test_hip_baseline_config0_against_the_reference_simulator(golden_dir, progra
     got, _ = _run_gpu(path, ins, options=options)
     assert _within_tolerance(expected, got["b7"])
     assert npo.max_rel_err(expected, got["b7"]) <= TOL
+
+
+def test_oracle_reproduces_the_reference_simulator_on_the_f64_chain(golden_dir):
+    """The structure of BASELINE.json's configs[3] (C5: diffusion -> advection -> laplacian, float64)
+    on a small grid, evaluated by the reference's own Simulator
+    (tests/golden/make_simulator_f64_chain.py): the NumPy oracle under either typing and the C
+    restatement reproduce it bit for bit -- in float64 the two typings cannot differ."""
+    with open(os.path.join(golden_dir, "simulator_f64_chain.json")) as f:
+        entry = json.load(f)
+    assert "Simulator" in entry["source"]
+    expected = _expected(entry)["lap"]
+    assert expected.dtype == np.float64 and float(np.abs(expected).max()) > 0.0
+    for typing in ("nep50", "cxx"):
+        assert np.array_equal(npo.run_reference(entry["program"], typing=typing)["lap"], expected), typing
+    assert np.array_equal(c_oracle.CompiledReference(entry["program"]).run()["lap"], expected)
