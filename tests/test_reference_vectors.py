@@ -132,16 +132,24 @@ def test_hip_baseline_config0_against_the_reference_simulator(golden_dir, progra
     assert npo.max_rel_err(expected, got["b7"]) <= TOL
 
 
-def test_oracle_reproduces_the_reference_simulator_on_the_f64_chain(golden_dir):
-    """The structure of BASELINE.json's configs[3] (C5: diffusion -> advection -> laplacian, float64)
-    on a small grid, evaluated by the reference's own Simulator
-    (tests/golden/make_simulator_f64_chain.py): the NumPy oracle under either typing and the C
-    restatement reproduce it bit for bit -- in float64 the two typings cannot differ."""
-    with open(os.path.join(golden_dir, "simulator_f64_chain.json")) as f:
-        entry = json.load(f)
-    assert "Simulator" in entry["source"]
-    expected = _expected(entry)["lap"]
-    assert expected.dtype == np.float64 and float(np.abs(expected).max()) > 0.0
-    for typing in ("nep50", "cxx"):
-        assert np.array_equal(npo.run_reference(entry["program"], typing=typing)["lap"], expected), typing
-    assert np.array_equal(c_oracle.CompiledReference(entry["program"]).run()["lap"], expected)
+@pytest.mark.parametrize("name", ["f64_chain3", "f32_hotspot2"])
+def test_oracle_reproduces_the_reference_simulator_on_chains(golden_dir, name):
+    """Two chains evaluated by the reference's own Simulator (tests/golden/make_simulator_chain_fixtures.py):
+    the structure of BASELINE.json's configs[3] (C5: diffusion -> advection -> laplacian, float64) and two
+    float32 operators of the generator's hotspot shape sharing an auxiliary field.  The NumPy oracle with
+    the Simulator's typing reproduces both bit for bit; under the contract's typing the float64 chain is
+    bit-exact as well (in float64 the typings cannot differ) and the float32 one within 1e-6; the C
+    restatement equals the NumPy one."""
+    with open(os.path.join(golden_dir, "simulator_chains.json")) as f:
+        doc = json.load(f)
+    assert "Simulator" in doc["source"]
+    entry = doc["programs"][name]
+    (out, expected), = _expected(entry).items()
+    assert float(np.abs(expected).max()) > 0.0
+    assert np.array_equal(npo.run_reference(entry["program"], typing="nep50")[out], expected)
+    own = npo.run_reference(entry["program"])[out]
+    assert np.array_equal(c_oracle.CompiledReference(entry["program"]).run()[out], own)
+    if expected.dtype == np.float64:
+        assert np.array_equal(own, expected)
+    else:
+        assert _within_tolerance(expected, own)
