@@ -132,9 +132,15 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 // (SF_RING4: modulo 4; slot (PH + 3) % 4 of the input window holds the plane in
 // flight, the same slot of the later stages' windows is never live).
 // (SF_AUX_AHEAD 2) one row set of auxiliary values per stage, requested a step ahead
+#ifndef SF_AUX_CARRY
+#define SF_AUX_CARRY 0
+#endif
 template <int N>
 struct sf_auxslots : sf_auxslots<N - 1> {
   typename sf_stage<N>::aux_row a[SF_RJ];
+#if SF_AUX_CARRY
+  typename sf_stage<N>::aux_row used[SF_RJ];  // the rows this stage used in the current step (for stage N + 1)
+#endif
 };
 template <>
 struct sf_auxslots<0> {};
@@ -427,7 +433,18 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
 #if SF_AUX_AHEAD == 2
     // requested during the previous step; the slot then takes the next plane's row
     axs[r] = static_cast<sf_auxslots<S>&>(st).a[r];
+#if SF_AUX_CARRY
+    // ... which is the row the previous stage has just used (it evaluated this step the plane
+    // this stage evaluates in the next one): handed on in registers, not requested again
+    if constexpr (sf_stage<S>::aux_carry_in)
+      __builtin_memcpy(&static_cast<sf_auxslots<S>&>(st).a[r], &static_cast<sf_auxslots<S - 1>&>(st).used[r],
+                       sizeof(typename sf_stage<S>::aux_row));
+    else
+#endif
     static_cast<sf_auxslots<S>&>(st).a[r] = sf_aux_row<S>(cx, q + 1, r);
+#if SF_AUX_CARRY
+    if constexpr (sf_stage<S>::aux_carry_out) static_cast<sf_auxslots<S>&>(st).used[r] = axs[r];
+#endif
 #else
 #if SF_AUX_PASS
     if constexpr (sf_stage<S>::aux_from_prev) axs[r] = sf_aux_take(cx, p, r);

@@ -153,3 +153,29 @@ def test_oracle_reproduces_the_reference_simulator_on_chains(golden_dir, name):
         assert np.array_equal(own, expected)
     else:
         assert _within_tolerance(expected, own)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["f64_chain3", "f32_hotspot2"])
+@pytest.mark.parametrize("options", [None, {"fuse": 1}, {"generic_only": 1}])
+def test_hip_against_the_reference_simulator_on_chains(golden_dir, tmp_path, name, options):
+    """The HIP path on the two chain vectors of the reference's Simulator: equal to the oracle bit for
+    bit, equal to the reference bit for bit in float64 and within 1e-6 in float32 -- fused (the float32
+    pair takes the auxiliary rows of its first operator over to the second), operator by operator, and
+    on the generic kernel."""
+    from tests.test_gpu_parity import _inputs_of, _run_gpu
+    with open(os.path.join(golden_dir, "simulator_chains.json")) as f:
+        entry = json.load(f)["programs"][name]
+    path = str(tmp_path / (name + ".json"))
+    with open(path, "w") as f:
+        json.dump(entry["program"], f)
+    ins = _inputs_of(path)
+    got, _ = _run_gpu(path, ins, options=options)
+    own = npo.run_reference(path, inputs=ins)
+    (out, exp), = _expected(entry).items()
+    assert got[out].dtype == exp.dtype
+    assert np.array_equal(got[out], own[out])
+    if exp.dtype == np.float64:
+        assert np.array_equal(got[out], exp)
+    else:
+        assert _within_tolerance(exp, got[out])
