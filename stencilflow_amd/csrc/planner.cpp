@@ -1,0 +1,854 @@
+// planner.cpp — from a parsed program to launches: grouping of operators into fused
+// launches, tile-shape search for the plane-streaming kernels (compile candidates in
+// order of modelled cost, read the code objects' metadata), liveness-based device
+// buffers.  (The reference's counterpart is generate_sdfg / generate_reference,
+// stencilflow/sdfg_generator.py:219-677.)
+#include "sf_internal.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+
+namespace sf {
+
+// ---------------------------------------------------------------- planner
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+size_t star_lds_bytes(const StarCfg& c, DT dt) {
+  if (c.compact) {
+    // kernels/compact3d.h: per window a ring of images (first / last row of every
+    // thread row + the wave-edge columns of every row incl. two virtual waves)
+    const size_t win = (size_t)c.BY * 2 * c.BX * c.VK + (size_t)(c.BY + 2) * c.RJ * (c.BX / 64 + 2) * 2;
+    return std::max<size_t>(1, (size_t)c.lds_images * win) * size_of(dt);
+  }
+  const size_t rows = c.noj ? 0 : (size_t)c.T * c.BY * 2 * c.BX * c.VK;
+  const size_t edge = (size_t)c.T * c.BY * c.RJ * (c.BX / 64 + ((c.dpp == 4 && c.BX > 64) ? 2 : 0)) * 2;
+  return (rows + edge) * size_of(dt) * (c.lds_db ? 2 : 1);
+}
+
+// ---- launch-geometry model ------------------------------------------------------
+// Measured on MI355X (profiles/r01_sweep_*.log): for a given fused depth the raw
+// update rate of the star kernel is nearly independent of the tile shape; what
+// separates configurations is (a) redundant halo work in j / k / along the
+// stream axis and (b) how evenly the blocks fill the 256 CUs.  The planner
+// therefore minimises
+//   cost = (tile rows / interior rows) * (tile cols / interior cols)
+//          * (chunk planes + 2T) / chunk planes * (block slots used / blocks)
+// over the tile shapes whose register footprint fits without spilling.
+static int star_regs_estimate(const StarCfg& c, DT dt) {
+  // window + staging registers, plus what the compiler needs around them: fitted
+  // to the code objects of this round (f32 T=2 P=20: 226; f64 T=3 P=6/8/10:
+  // 142/188/232) as 20 + 3.3 P.  It only has to be roughly right -- a shape that
+  // spills after all is rejected by select_star from its metadata.
+  const int words = (dt == DT::F64) ? 2 : 1;
+  const int P = c.RJ * c.VK;
+  if (c.compact)  // three live planes per window, one more in flight per loaded window; fitted to
+                  // the code objects of round 2 (box, T = 2: P = 16 -> 180, P = 20 -> 212)
+    return (3 * c.nwin + 1 + c.nwin - c.T) * P * words + 52 + P;
+  return 3 * c.T * P * words + 20 + (33 * P) / 10 +
+         ((c.prefetch2 || c.reverse == 2) ? P * words * c.pfd : 0);
+}
+
+static int star_blocks_per_cu(const StarCfg& c, DT dt) {
+  const int threads = c.BX * c.BY;
+  const int waves_per_simd = (threads + 255) / 256;  // a block's waves on one SIMD
+  const int regs = star_regs_estimate(c, dt);
+  const int alloc = (regs + 7) / 8 * 8;
+  if (alloc > 256) return 0;  // would lean on AGPR / scratch spills
+  const int by_regs = (512 / alloc) / waves_per_simd;
+  const size_t lds = std::max<size_t>(star_lds_bytes(c, dt), 1);
+  const int by_lds = (int)(160 * 1024 / lds);
+  const int by_waves = 32 / ((threads + 63) / 64);
+  return std::max(0, std::min(std::min(by_regs, by_lds), std::min(by_waves, 8)));
+}
+
+static void star_finish_cfg(StarCfg& c, const Program& P, int T) {
+  const long long tkh = (long long)c.BX * c.VK;
+  const int hk = round_up(T, c.VK);
+  c.ktiled = (tkh != P.n[2]);
+  c.HK = c.ktiled ? hk : 0;
+  c.NKT = c.ktiled ? (int)((P.n[2] + (tkh - 2 * c.HK) - 1) / (tkh - 2 * c.HK)) : 1;
+  if (c.noj) {
+    c.NJT = 1;
+  } else {
+    const int tji = c.BY * c.RJ - 2 * T;
+    if (tji < 1) throw Error(SF_ERR_INVALID, "star kernel: tile has no interior rows (raise k1.by / k1.rj)");
+    c.NJT = (int)((P.n[1] + tji - 1) / tji);
+  }
+}
+
+// chunk length along the stream axis for `range` planes: whole block waves
+static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_out = nullptr,
+                             int reserved_cus = 0, int ranges = 1) {
+  // (`ranges`: plane ranges of this length served by the one launch -- the two
+  // slab boundaries of a split step -- whose blocks share the block slots)
+  const int tiles = c.NJT * c.NKT * std::max(1, ranges);
+  const int slots = std::max(1, 256 - reserved_cus) * std::max(1, star_blocks_per_cu(c, dt));
+  double best = 1e30;
+  int best_li = range;
+  const int max_nch = std::max(1, range / std::max(1, 2 * c.T));
+  for (int nch = 1; nch <= std::min(max_nch, 4096); ++nch) {
+    const int li = (range + nch - 1) / nch;
+    const int real_nch = (range + li - 1) / li;
+    const long long blocks = (long long)tiles * real_nch;
+    if (c.noj) {
+      // 2-D programs: a block is one (or a few) self-contained waves with a
+      // short dependent step, so the sweep is latency-bound until about three
+      // waves share a SIMD (profiles/r01_sweep_10_c2_chunks.log: 4096^2 is
+      // fastest at 24-row chunks = 2.8 waves per SIMD, 1.8x the rate of
+      // 92-row chunks).  Below that, time follows the chunk length; above it,
+      // the warm-up redundancy.
+      const double waves_per_simd = (double)blocks * (double)(c.BX / 64) / 1024.0;
+      const double warm = (double)(li + 2 * c.T + (c.reverse ? c.T - 1 : 0)) / (double)li;
+      const double cost = warm * std::max(1.0, 3.0 / waves_per_simd);
+      if (cost < best - 1e-12) {
+        best = cost;
+        best_li = li;
+      }
+      if (waves_per_simd > 8.0) break;
+      continue;
+    }
+    const long long rounds = (blocks + slots - 1) / slots;
+    const double quant = (double)(rounds * slots) / (double)blocks;
+    const double warm = (double)(li + 2 * c.T + (c.reverse ? c.T - 1 : 0)) / (double)li;
+    // more rounds amortise the tail when block times differ
+    const double cost = warm * quant * (1.0 + 0.02 / (double)rounds);
+    if (cost < best - 1e-12) {
+      best = cost;
+      best_li = li;
+    }
+    if (blocks > 64LL * slots) break;
+  }
+  if (cost_out) *cost_out = best;
+  return best_li;
+}
+
+// chunk length used for a launch over `range` planes (options k1.li / k2.li pin it)
+long long star_chunk_length(const sf_plan& pl, const StarCfg& c, DT dt, int range, int ranges) {
+  long long li = pl.opt.get(c.noj ? "k2.li" : "k1.li", 0);
+  if (li <= 0) li = star_chunk_planes(c, dt, range, nullptr, pl.reserved_cus, ranges);
+  if (li > range) li = range;
+  return std::max<long long>(li, 1);
+}
+
+static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, const StarCfg* proto = nullptr) {
+  const Program& P = pl.P;
+  StarCfg base;
+  if (proto) base = *proto;  // (compact kernels: windows and LDS images of the group)
+  base.T = T;
+  // one 16-byte vector per row and lane: 4 floats or 2 doubles
+  base.VK = (int)pl.opt.get("k1.vk", dt == DT::F64 ? 2 : 4);
+  if (base.VK != 1 && base.VK != 2 && base.VK != 4) throw Error(SF_ERR_INVALID, "k1.vk must be 1, 2 or 4");
+  // rows that do not hold whole 16-byte vectors: 8-byte vectors (rows of 4m+2 floats)
+  // or single elements (odd rows) keep the program on the star kernel -- slower per
+  // point than 16-byte vectors, several times faster than the generic kernel
+  if (!pl.opt.kv.count("k1.vk"))
+    while (base.VK > 1 && P.n[2] % base.VK != 0) base.VK /= 2;
+  if (P.n[2] % base.VK != 0) throw Error(SF_ERR_INVALID, "innermost extent must be a multiple of k1.vk");
+  base.n0g = P.n[0];
+  base.n1 = P.n[1];
+  base.n2 = P.n[2];
+  base.noj = (P.n[1] == 1);
+  base.row_fence = (int)pl.opt.get("k1.fence", 1);
+  base.lds_db = (int)pl.opt.get("k1.db", 1);
+  base.opaque = (int)pl.opt.get("k1.opaque", base.noj ? 0 : 1);  // 2-D: registers are plentiful
+  base.stamp = (int)pl.opt.get("stamp", 0);
+  base.spread = (int)pl.opt.get("k1.spread", 1);
+  // step order: 3-D kernels run stage 1 first (k1.rev=0); 2-D kernels run the
+  // storing stage first, which makes the stages of one step independent of each
+  // other (more instruction-level parallelism for the lone wave) -- measured
+  // +30 % on C2, no change on C3 (profiles/r01_sweep_9_step_order.log)
+  // -- with branch-free buffer loads and stores (k1.bio, below) the compiler counts
+  // the memory operations in flight, a wave no longer drains them once per step,
+  // and stage-1-first with the four-slot input ring overtakes it: C2 +10 %
+  // (profiles/r01_sweep_17_buffer_io.log); k1.rev=1 remains available
+  base.reverse = base.compact ? 1 : (int)pl.opt.get("k1.rev", 0);
+  // input planes: 0 = loaded into the window slot stage 1 has just freed, 1 = into
+  // staging registers a step earlier and copied, 2 = four-slot input ring (two
+  // steps to land, no copy; the step loop is unrolled by 4)
+  // (defaults: the ring for 2-D and f32 3-D -- C2 +10 %, C3 +1.7 %, hotspot chains
+  // +1 % with k1.bio; staging registers for f64, whose ring needs a smaller tile)
+  base.prefetch2 = base.reverse ? 0 : (int)pl.opt.get("k1.pf2", (base.noj || dt == DT::F32) ? 2 : 1);
+  if (base.prefetch2 < 0 || base.prefetch2 > 2) throw Error(SF_ERR_INVALID, "k1.pf2 must be 0, 1 or 2");
+  base.uniform_loads = (int)pl.opt.get("k1.ul", 0);
+  // planes through buffer instructions (out-of-range offsets instead of branches
+  // around loads and stores); a plane must stay well below the 2 GiB offset range
+  const double plane_bytes = (double)P.n[1] * (double)P.n[2] * (double)size_of(dt);
+  // Measured (profiles/r01_sweep_17_buffer_io.log): 2-D +10 % (with the step order
+  // and input ring above), f64 3-D +1..4 %, f32 3-D jacobi +1.7 % with the ring,
+  // f32 3-D chains with auxiliary fields (hotspot) +38 %
+  base.buffer_io = plane_bytes <= 1024.0 * 1024 * 1024 ? (int)pl.opt.get("k1.bio", 1) : 0;
+  base.pfd = (int)pl.opt.get("k1.pfd", 1);
+  if (base.pfd != 1 && base.pfd != 3) throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
+  if ((base.prefetch2 != 1 && base.reverse != 2) || base.prefetch2 == 2) base.pfd = 1;
+  base.experiment = (int)pl.opt.get("experiment", 0);
+  // lane exchange: 0 = __shfl, 1 = DPP, 2 = DPP with bound_ctrl (no copy before the
+  // move), 3 = as 2 and the wave's edge lane gets its value (boundary constant or
+  // the neighbouring wave's edge column) from the move's starting destination
+  // instead of a select, 4 = as 3 with the neighbour test removed: virtual waves
+  // beside every row hold the boundary constant in LDS.  Measured: C3 2 -> 4 +1 %
+  // (3 costs 7 % there: scalar branches per row), C5 2 -> 3/4 +4.7 %, C2 +8 %.
+  const long long dpp_opt = pl.opt.get("k1.dpp", -1);
+  base.dpp = dpp_opt >= 0 ? (int)dpp_opt : 4;
+  base.uniform = (int)pl.opt.get("k1.uni", 0);
+  // auxiliary (centre-only) fields: 1 = a stage requests all its rows before its
+  // first row is evaluated (3-D hotspot chains +21 %); 2 = rows are requested a
+  // whole step ahead into per-stage slots (2-D, where a thread has one row and
+  // registers to spare, +11 %)
+  base.aux_ahead = (int)pl.opt.get("k1.auxpre", base.noj ? 2 : 1);
+  base.aux_pass = (int)pl.opt.get("k1.auxpass", 1);
+  // Non-temporal output stores when a field is larger than the 256 MiB Infinity
+  // Cache: nothing of it would survive until the next launch reads it, and not
+  // allocating the written lines leaves the cache to the input stream (C3 +3 %,
+  // C5 +1.4 %; the cache-resident 64 MiB field of C2 loses 13 % with them).
+  const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] *
+                             (double)P.n[2] * (double)size_of(dt);
+  base.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
+  const std::string pfx = base.noj ? "k2." : "k1.";
+  const long long pin_bx = pl.opt.get(pfx + "bx", 0);
+  const long long pin_by = base.noj ? 1 : pl.opt.get("k1.by", 0);
+  const long long pin_rj = base.noj ? 1 : pl.opt.get("k1.rj", 0);
+  const int range = (int)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local);
+
+  std::vector<std::pair<double, StarCfg>> ranked;
+  for (int bx : {64, 128, 256}) {
+    if (pin_bx && bx != pin_bx) continue;
+    for (int rj = 1; rj <= 8; ++rj) {
+      if (pin_rj && rj != pin_rj) continue;
+      for (int by = 1; by <= 16; ++by) {
+        if (pin_by && by != pin_by) continue;
+        if (bx * by > 1024) continue;
+        StarCfg c = base;
+        c.BX = bx;
+        c.RJ = rj;
+        c.BY = by;
+        if (!c.noj && by * rj - 2 * T < 1) continue;
+        star_finish_cfg(c, P, T);
+        if (star_lds_bytes(c, dt) > 160 * 1024) continue;
+        const bool pinned = pin_bx && pin_by && pin_rj;
+        if (!pinned && star_blocks_per_cu(c, dt) < 1) continue;  // would spill
+        double chunk_cost = 1.0;
+        star_chunk_planes(c, dt, range, &chunk_cost);
+        const double jcost = c.noj ? 1.0 : (double)c.NJT * c.BY * c.RJ / (double)P.n[1];
+        const double kcost = (double)c.NKT * c.BX * c.VK / (double)P.n[2];
+        // a block whose waves do not divide evenly over the 4 SIMDs of its unit
+        // leaves SIMDs idle (one block per unit); every thread pays two LDS edge
+        // rows per stage whatever its row count (profiles/r01_sweep_13_c5_tiles.log:
+        // 64x7 / 64x11 threads lose 10 % / 5 % to 64x8, 3 rows per thread 5-10 % to 4-5)
+        const int waves = (c.BX * c.BY + 63) / 64;
+        const double simd_balance =
+            (!c.noj && star_blocks_per_cu(c, dt) == 1) ? (double)((waves + 3) / 4 * 4) / (double)waves : 1.0;
+        // 2-D: a one-wave block needs neither LDS nor a barrier; wider blocks exchange
+        // their edge columns through LDS every step (measured 10-30 % slower on C2)
+        const double edge_rows = c.noj ? (c.BX > 64 ? 1.2 : 1.0) : 1.0 + 0.8 / (double)c.RJ;
+        // ties go to the larger block (fewer barriers per point)
+        const double cost = jcost * kcost * chunk_cost * simd_balance * edge_rows *
+                            (1.0 + 1e-4 / (double)(c.BX * c.BY * c.RJ));
+        ranked.push_back({cost, c});
+      }
+    }
+  }
+  if (ranked.empty()) throw Error(SF_ERR_INVALID, "star kernel: no tile shape satisfies the given k1.* options");
+  std::stable_sort(ranked.begin(), ranked.end(),
+                   [](const std::pair<double, StarCfg>& a, const std::pair<double, StarCfg>& b) {
+                     return a.first < b.first;
+                   });
+  std::vector<StarCfg> out;
+  for (auto& rc : ranked) out.push_back(rc.second);
+  if (pl.opt.get("debug", 0) != 0)
+    for (size_t i = 0; i < std::min<size_t>(ranked.size(), 8); ++i)
+      std::fprintf(stderr, "[sf_hip] rank %zu cost %.4f: T=%d block %dx%d rows/thread %d tiles %dx%d\n", i + 1,
+                   ranked[i].first, T, ranked[i].second.BX, ranked[i].second.BY, ranked[i].second.RJ,
+                   ranked[i].second.NJT, ranked[i].second.NKT);
+  return out;
+}
+
+// Pick a tile shape for a fused group by compiling candidates in order of
+// modelled cost and reading the code object's metadata.  A kernel that spills,
+// uses scratch or overflows into AGPRs is rejected: besides being slow, such
+// kernels were observed to produce wrong results on gfx950 / ROCm 7 for
+// programs with device math calls (profiles/r01_config_fuzz.log).  Returns
+// false if no clean shape exists (caller shortens the group or goes generic).
+struct StarChoice {
+  bool ok = false;
+  StarCfg cfg;
+  int ck = -1;
+  // option autotune=<k>: the first k clean candidates in ranked order (the first is
+  // cfg / ck); they are timed on the device before the first execution
+  std::vector<std::pair<StarCfg, int>> alts;
+  std::string sig;
+};
+
+static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& memo,
+                              const std::vector<int>& kernels, DT dt) {
+  const Program& P = pl.P;
+  StarCfg probe;
+  probe.T = (int)kernels.size();
+  const std::string sig = std::to_string(fnv1a(gen_star(P, kernels, probe).source));
+  auto it = memo.find(sig);
+  if (it != memo.end()) return it->second;
+  const std::string prefix = std::string("sf_star") + (P.n[1] == 1 ? "2d_" : "3d_") + short_of(dt) + "_t" +
+                             std::to_string(kernels.size());
+  StarChoice out;
+  std::vector<StarCfg> ranked;
+  try {
+    ranked = rank_star_cfgs(pl, (int)kernels.size(), dt);
+  } catch (const Error&) {
+    memo[sig] = out;
+    return out;
+  }
+  const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
+                      (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
+  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
+  int rejected = 0, sgpr_rejects = 0;
+  for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {  // compile errors rarely depend on the shape
+    ranked[ci].lds_bytes = star_lds_bytes(ranked[ci], dt);
+    StarKernelSource g = gen_star(P, kernels, ranked[ci]);
+    int ck = -1;
+    try {
+      ck = intern_kernel(pl, prefix, g.source);
+    } catch (const Error& e) {
+      // a shape the compiler rejects is no candidate (a pinned shape reports it);
+      // the group is shortened and in the end the generic kernel takes over
+      if (pinned || e.status != SF_ERR_COMPILE) throw;
+      if (pl.opt.get("debug", 0) != 0)
+        std::fprintf(stderr, "[sf_hip] candidate %zu/%zu rejected by the compiler: %.200s\n", ci + 1,
+                     ranked.size(), e.what());
+      ++rejected;
+      continue;
+    }
+    const CompiledKernel& k = pl.kernels[ck];
+    if (pl.opt.get("debug", 0) != 0)
+      std::fprintf(stderr, "[sf_hip] candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d sgpr spill %d late exec restores %d\n",
+                   ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs,
+                   k.agprs, k.spills, k.scratch, k.sgpr_spills, k.late_exec_restores);
+    (void)sgpr_rejects;  // (star kernels: SGPR spills do depend on the shape -- hotspot 512^3: shapes 1-3 spill, 4 does not)
+    if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
+      if (!out.ok) {
+        out.ok = true;
+        out.cfg = ranked[ci];
+        out.ck = ck;
+      }
+      out.alts.push_back({ranked[ci], ck});
+      if (pinned || (long long)out.alts.size() >= std::max<long long>(1, pl.opt.get("autotune", 0))) break;
+    }
+  }
+  out.sig = sig;
+  memo[sig] = out;
+  return out;
+}
+
+// Extra compiler flags of the compact kernels: without the SLP vectoriser hipcc
+// keeps the 26 adds of a box stencil scalar instead of pairing them into
+// v_pk_add_f32, whose operand pairs it has to assemble with moves (option compact.slp).
+static std::string compact_flags(const sf_plan& pl) {
+  return pl.opt.get("compact.slp", 0) != 0 ? "" : "-fno-slp-vectorize";
+}
+
+// The same for a group of compact operators (kernels/compact3d.h).
+static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>& memo, const std::vector<int>& kernels,
+                                 DT dt) {
+  const Program& P = pl.P;
+  StarCfg probe;
+  probe.T = (int)kernels.size();
+  const std::string sig = "compact" + std::to_string(fnv1a(gen_compact(P, kernels, probe).source));
+  auto it = memo.find(sig);
+  if (it != memo.end()) return it->second;
+  const std::string prefix = std::string(P.n[1] == 1 ? "sf_compact2d_" : "sf_compact3d_") + short_of(dt) + "_t" +
+                             std::to_string(kernels.size());
+  StarChoice out;
+  std::vector<StarCfg> ranked;
+  try {
+    ranked = rank_star_cfgs(pl, (int)kernels.size(), dt, &probe);
+  } catch (const Error&) {
+    memo[sig] = out;
+    return out;
+  }
+  const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
+                      (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
+  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
+  int rejected = 0, sgpr_rejects = 0;
+  // Dense 3-D groups (box-like: every operator reads 18 or more of the 27 offsets of one field)
+  // are bound by vector-instruction issue; letting the scheduler mix the rows of a step is worth
+  // +4 % there (27-point box 512^3: 7.49 -> 7.75e5, profiles/r02_synth_box.log) and costs 12
+  // registers, so the unfenced form is tried first and the fenced one if it does not come out clean.
+  bool dense = P.n[1] != 1 && !pl.opt.kv.count("k1.fence");
+  for (size_t si = 0; dense && si < kernels.size(); ++si) {
+    CompactShape sh;
+    const std::string want = si == 0 ? std::string() : P.kernels[kernels[si - 1]].name;
+    dense = compact_eligible(P, P.kernels[kernels[si]], &sh, want) && sh.extra.empty() &&
+            __builtin_popcount(sh.need) >= 18;
+  }
+  for (size_t ci2 = 0; ci2 < 2 * tries && rejected < 2; ++ci2) {
+    const size_t ci = ci2 / 2;
+    if (!dense && (ci2 & 1)) continue;
+    if (dense) ranked[ci].row_fence = (int)(ci2 & 1);
+    StarKernelSource g = gen_compact(P, kernels, ranked[ci]);
+    int ck = -1;
+    try {
+      ck = intern_kernel(pl, prefix, g.source, compact_flags(pl));
+    } catch (const Error& e) {
+      if (pinned || e.status != SF_ERR_COMPILE) throw;
+      if (pl.opt.get("debug", 0) != 0)
+        std::fprintf(stderr, "[sf_hip] compact candidate %zu/%zu rejected by the compiler: %.400s\n", ci + 1,
+                     ranked.size(), e.what());
+      ++rejected;
+      continue;
+    }
+    const CompiledKernel& k = pl.kernels[ck];
+    if (pl.opt.get("debug", 0) != 0)
+      std::fprintf(stderr,
+                   "[sf_hip] compact candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d "
+                   "scratch %d sgpr spill %d late exec restores %d lds %d\n",
+                   ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs, k.agprs,
+                   k.spills, k.scratch, k.sgpr_spills, k.late_exec_restores, k.lds);
+    // scalar registers are spent on the group's windows and descriptors more than on the
+    // tile shape: four shapes that spill them settle it for this group length
+    if (kernel_unsafe(k) && ++sgpr_rejects >= 4) break;
+    if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
+      if (!out.ok) {
+        out.ok = true;
+        out.cfg = ranked[ci];
+        out.ck = ck;
+      }
+      out.alts.push_back({ranked[ci], ck});
+      if (pinned || (long long)out.alts.size() >= std::max<long long>(1, pl.opt.get("autotune", 0))) break;
+    }
+  }
+  out.sig = sig;
+  memo[sig] = out;
+  return out;
+}
+
+// One line of sf_plan_describe per launch.
+static void describe_step(std::ostringstream& desc, const sf_plan& pl, const Step& st) {
+  const Program& P = pl.P;
+  const DT dt = P.kernels[st.kernels[0]].dt;
+  const CompiledKernel& ck = pl.kernels[st.ck];
+  desc << "  launch " << ck.name << ": ";
+  for (int k : st.kernels) desc << P.kernels[k].name << " ";
+  if (st.star)
+    desc << (st.compact ? "[compact windows " + std::to_string(st.cfg.nwin) + " T=" : std::string("[star T=")) << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
+         << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " chunk "
+         << star_chunk_length(pl, st.cfg, dt, (int)pl.n_local) << " lds " << star_lds_bytes(st.cfg, dt)
+         << " B]";
+  else
+    desc << "[point]";
+  desc << " in";
+  for (int b : st.in_bufs) desc << " b" << b;
+  desc << " out b" << st.out_buf << " {vgpr " << ck.vgprs << " agpr " << ck.agprs << " spill " << ck.spills
+       << " scratch " << ck.scratch << "}\n";
+}
+
+// The whole description: header line, one line per launch (long chains: the first ones).
+std::string describe_plan(const sf_plan& pl) {
+  const Program& P = pl.P;
+  std::ostringstream desc;
+  desc << "program " << P.name << ": dims " << P.n[0] << "x" << P.n[1] << "x" << P.n[2] << ", "
+       << P.kernels.size() << " operators, " << pl.steps.size() << " launches, " << pl.buffers.size()
+       << " device buffers\n";
+  for (auto& st : pl.steps) {
+    if (desc.tellp() > 16384) break;  // long chains: describe the first launches only
+    describe_step(desc, pl, st);
+  }
+  return desc.str();
+}
+
+// Values outside an option's range are the caller's mistake and are reported;
+// (a shape no kernel can serve is not: that group falls back to the generic kernel)
+static void validate_options(const sf_plan& pl) {
+  struct Range {
+    const char* key;
+    long long lo, hi;
+  };
+  static const Range ranges[] = {{"k1.pf2", 0, 2}, {"k1.rev", 0, 2},  {"k1.dpp", 0, 4},   {"k1.bio", 0, 3},
+                                 {"k1.ul", 0, 1},  {"k1.db", 0, 1},   {"k1.nt", 0, 3},    {"k1.auxpre", 0, 2},
+                                 {"graph", 0, 1},  {"autotune", 0, 8}};
+  for (const Range& r : ranges) {
+    if (!pl.opt.kv.count(r.key)) continue;
+    const long long v = pl.opt.get(r.key, r.lo);
+    if (v < r.lo || v > r.hi)
+      throw Error(SF_ERR_INVALID, std::string("option ") + r.key + " must lie in [" + std::to_string(r.lo) + ", " +
+                                      std::to_string(r.hi) + "]");
+  }
+  if (pl.opt.kv.count("k1.vk") && pl.opt.get("k1.vk", 4) != 1 && pl.opt.get("k1.vk", 4) != 2 &&
+      pl.opt.get("k1.vk", 4) != 4)
+    throw Error(SF_ERR_INVALID, "k1.vk must be 1, 2 or 4");
+  if (pl.opt.kv.count("k1.pfd") && pl.opt.get("k1.pfd", 1) != 1 && pl.opt.get("k1.pfd", 1) != 3)
+    throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
+}
+
+void build_plan(sf_plan& pl) {
+  const Program& P = pl.P;
+  const int K = (int)P.kernels.size();
+  pl.profile = pl.opt.get("profile", 0) != 0;
+  validate_options(pl);
+
+  // slab of the stream dimension owned by this plan
+  pl.n_local = P.n[0];
+  pl.goff = 0;
+  pl.halo = 0;
+  {
+    const std::string slab = pl.opt.gets("slab", "");
+    if (!slab.empty()) {
+      long long lo, hi, extent = 0;
+      int h;
+      const int got = std::sscanf(slab.c_str(), "%lld:%lld:%d:%lld", &lo, &hi, &h, &extent);
+      if (got < 3 || lo < 0 || hi > P.n[0] || lo >= hi || h < 0 || (got == 4 && extent < 1))
+        throw Error(SF_ERR_INVALID, "option slab=<lo>:<hi>:<halo>[:<planning extent>] out of range");
+      pl.n_local = hi - lo;
+      pl.goff = lo;
+      pl.halo = h;
+      // The ranks of a decomposed run must plan ALIKE (same launch groups, same reach:
+      // they exchange the same planes): everything the planner derives from the slab's
+      // height uses this common extent -- the thinnest slab, given by the caller -- not
+      // the rank's own height.
+      pl.plan_extent = got == 4 ? extent : pl.n_local;
+    }
+  }
+
+  // consumers per field
+  std::map<std::string, int> consumers;
+  for (auto& k : P.kernels) {
+    std::set<std::string> seen;
+    for (auto& a : k.acc)
+      if (seen.insert(a.field).second) consumers[a.field]++;
+  }
+
+  // default fusion depth (measured, profiles/r01_sweep_*): 2 for 3-D f32 (register
+  // budget), 4 for 2-D (3 values of state per stage), 3 for f64 chains
+  long long fuse_default = 2;
+  if (P.n[1] == 1) fuse_default = 4;
+  else if (P.kernels[0].dt == DT::F64) fuse_default = 3;
+  const int fuse = (int)std::max<long long>(1, pl.opt.get("fuse", fuse_default));
+  const bool generic_only = pl.opt.get("generic_only", 0) != 0;
+  // (any row length: the vector width follows it, rank_star_cfgs)
+  const bool star_ok_dims = (P.nd >= 2) && P.n[0] > 1;
+
+  // ---- group kernels into launches
+  std::map<std::string, StarChoice> star_memo;
+  for (int k = 0; k < K;) {
+    Step st;
+    StarShape shape;
+    // (star=0: diagnostics -- star chains then run on the compact kernel)
+    bool star = !generic_only && star_ok_dims && star_eligible(P, P.kernels[k], &shape) && pl.opt.get("star", 1) != 0;
+    if (star && P.n[1] == 1) {
+      for (auto& a : P.kernels[k].acc)
+        if (a.off[1] != 0) star = false;
+    }
+    if (star) {
+      std::vector<int> group{k};
+      std::set<std::string> group_aux(shape.aux.begin(), shape.aux.end());
+      while ((int)group.size() < fuse && k + (int)group.size() < K) {
+        const int cur = group.back(), nxt = cur + 1;
+        const Kernel& kc = P.kernels[cur];
+        StarShape nshape;
+        if (!star_eligible(P, P.kernels[nxt], &nshape)) break;
+        if (nshape.primary != kc.name) break;
+        if (P.field(kc.name).role != Role::Temp) break;
+        if (consumers[kc.name] != 1) break;
+        if (P.kernels[nxt].dt != kc.dt) break;
+        // auxiliary fields must exist in memory: not produced inside this group
+        bool aux_ok = true;
+        for (auto& f : nshape.aux)
+          for (int g : group)
+            if (P.kernels[g].name == f) aux_ok = false;
+        if (!aux_ok) break;
+        // one launch takes kMaxStarAux auxiliary pointers
+        std::set<std::string> all_aux = group_aux;
+        all_aux.insert(nshape.aux.begin(), nshape.aux.end());
+        if ((int)all_aux.size() > kMaxStarAux) break;
+        group_aux.swap(all_aux);
+        group.push_back(nxt);
+      }
+      // longest prefix of the group for which a clean kernel exists
+      StarChoice choice;
+      while (!group.empty()) {
+        choice = select_star(pl, star_memo, group, P.kernels[k].dt);
+        if (choice.ok) break;
+        group.pop_back();
+      }
+      if (choice.ok) {
+        st.star = true;
+        st.kernels = group;
+        st.cfg = choice.cfg;
+        st.ck = choice.ck;
+        st.alts = choice.alts;
+        st.sig = choice.sig;
+      } else {
+        st.kernels.push_back(k);
+      }
+    } else {
+      // compact operators (27-point neighbourhoods, one extra streamed field).  In a slab
+      // run an extra field is one more slab-split field the launch reads across planes:
+      // the runner exchanges every such field at the launch's reach (SlabRunner's rule for
+      // launches that are not a pure chain; the extra field reaches at most T planes)
+      const bool whole_domain = true;
+      const bool compact_dims = ((P.nd == 3 && P.n[1] > 1) || P.nd == 2) && P.n[0] > 1 && pl.opt.get("compact", 1) != 0;
+      CompactShape cshape;
+      bool compact = !generic_only && compact_dims && compact_eligible(P, P.kernels[k], &cshape) &&
+                     (cshape.extra.empty() || whole_domain);
+      if (compact) {
+        std::vector<int> group{k};
+        std::set<std::string> extras;
+        if (!cshape.extra.empty()) extras.insert(cshape.extra);
+        // 2-D groups with diagonal accesses (the 9-point box) are fastest two deep
+        // (profiles/r02_synth_perf.log: 8.7e5 / 8.6e5 / 6.8e5 Mcells/s at depth 2 / 3 / 4;
+        // star-like 2-D groups with extra fields keep the 2-D default of 4); an explicit
+        // fuse= option is followed as given
+        auto diagonal = [](const CompactShape& sh) {
+          return compact_lateral(sh.need, 0) || compact_lateral(sh.need, 2) || compact_lateral(sh.xneed, 0) ||
+                 compact_lateral(sh.xneed, 2);
+        };
+        bool group_diagonal = diagonal(cshape);
+        while ((int)group.size() < fuse && k + (int)group.size() < K) {
+          const int cur = group.back(), nxt = cur + 1;
+          const Kernel& kc = P.kernels[cur];
+          CompactShape nshape;
+          if (!compact_eligible(P, P.kernels[nxt], &nshape, kc.name)) break;
+          if (P.nd == 2 && !pl.opt.kv.count("fuse") && (int)group.size() >= 2 && (group_diagonal || diagonal(nshape))) break;
+          group_diagonal = group_diagonal || diagonal(nshape);
+          if (P.field(kc.name).role != Role::Temp) break;
+          if (consumers[kc.name] != 1) break;
+          if (P.kernels[nxt].dt != kc.dt) break;
+          if (!nshape.extra.empty()) {
+            if (!whole_domain) break;
+            bool produced_inside = false;
+            for (int g : group)
+              if (P.kernels[g].name == nshape.extra) produced_inside = true;
+            if (produced_inside) break;
+            std::set<std::string> all = extras;
+            all.insert(nshape.extra);
+            if ((int)all.size() > kMaxStarAux) break;
+            extras.swap(all);
+          }
+          group.push_back(nxt);
+        }
+        StarChoice choice;
+        while (!group.empty()) {
+          choice = select_compact(pl, star_memo, group, P.kernels[k].dt);
+          if (choice.ok) break;
+          group.pop_back();
+        }
+        if (choice.ok) {
+          st.star = true;
+          st.compact = true;
+          st.kernels = group;
+          st.cfg = choice.cfg;
+          st.ck = choice.ck;
+          st.alts = choice.alts;
+          st.sig = choice.sig;
+        } else {
+          st.kernels.push_back(k);
+        }
+      } else {
+        st.kernels.push_back(k);
+      }
+    }
+    k += (int)st.kernels.size();
+    pl.steps.push_back(st);
+  }
+
+  // ---- buffers with liveness-based reuse (the reference keeps one full-size
+  // transient per intermediate, sdfg_generator.py:626-630; a 1000-stage chain
+  // needs two)
+  auto make_buffer = [&](const Field& f) {
+    Buffer b;
+    b.dt = f.dt;
+    b.slabbed = f.has[0] && P.n[0] > 1;
+    size_t plane = size_of(f.dt);
+    if (f.has[1]) plane *= (size_t)P.n[1];
+    if (f.has[2]) plane *= (size_t)P.n[2];
+    if (b.slabbed) {
+      b.plane_bytes = plane;
+      b.planes = (int)(pl.n_local + 2 * pl.halo);
+    } else {
+      b.plane_bytes = plane * (f.has[0] ? (size_t)P.n[0] : 1);
+      b.planes = 1;
+    }
+    pl.buffers.push_back(b);
+    return (int)pl.buffers.size() - 1;
+  };
+  std::map<std::string, int> buf_of;   // live field -> buffer
+  std::map<std::string, int> last_use; // field -> last step reading it
+  auto step_reads = [&](const Step& st) {
+    std::vector<std::string> r;
+    if (st.compact) {
+      // argument 0: the streamed field of the first stage; then the extra fields in
+      // first-use order (as gen_compact numbers them)
+      for (size_t si = 0; si < st.kernels.size(); ++si) {
+        CompactShape sh;
+        compact_eligible(P, P.kernels[st.kernels[si]], &sh, si == 0 ? std::string() : P.kernels[st.kernels[si - 1]].name);
+        if (si == 0) r.push_back(sh.primary);
+        if (!sh.extra.empty() && std::find(r.begin() + 1, r.end(), sh.extra) == r.end()) r.push_back(sh.extra);
+      }
+    } else if (st.star) {
+      StarShape sh0;
+      star_eligible(P, P.kernels[st.kernels[0]], &sh0);
+      r.push_back(sh0.primary);  // argument 0: the streamed field
+      // then the auxiliary fields in first-use order; a later stage may name the
+      // streamed field itself (centre read at its own plane), which then appears twice
+      for (int k : st.kernels) {
+        StarShape sh;
+        star_eligible(P, P.kernels[k], &sh);
+        for (auto& f : sh.aux)
+          if (std::find(r.begin() + 1, r.end(), f) == r.end()) r.push_back(f);
+      }
+    } else {
+      for (auto& a : P.kernels[st.kernels[0]].acc)
+        if (std::find(r.begin(), r.end(), a.field) == r.end()) r.push_back(a.field);
+    }
+    return r;
+  };
+  for (size_t s = 0; s < pl.steps.size(); ++s)
+    for (auto& f : step_reads(pl.steps[s])) last_use[f] = (int)s;
+
+  pl.input_buf.assign(P.num_inputs, -1);
+  pl.output_buf.assign(P.num_outputs, -1);
+  for (auto& f : P.fields)
+    if (f.role == Role::Input) {
+      const int b = make_buffer(f);
+      buf_of[f.name] = b;
+      pl.input_buf[f.io_index] = b;
+    }
+  std::multimap<std::pair<size_t, int>, int> free_pool;  // (bytes, dt) -> buffer
+  for (size_t s = 0; s < pl.steps.size(); ++s) {
+    Step& st = pl.steps[s];
+    for (auto& f : step_reads(st)) {
+      auto it = buf_of.find(f);
+      if (it == buf_of.end()) throw Error(SF_ERR_INVALID, "field '" + f + "' is read before it is produced");
+      st.in_bufs.push_back(it->second);
+    }
+    const Field& of = P.field(P.kernels[st.kernels.back()].name);
+    int ob = -1;
+    if (of.role == Role::Output) {
+      ob = make_buffer(of);
+      pl.output_buf[of.io_index] = ob;
+    } else {
+      Buffer probe;
+      {
+        // size the candidate without registering it
+        const size_t before = pl.buffers.size();
+        const int tmp = make_buffer(of);
+        probe = pl.buffers[tmp];
+        pl.buffers.resize(before);
+      }
+      auto key = std::make_pair(probe.bytes(), (int)probe.dt);
+      auto it = free_pool.find(key);
+      if (it != free_pool.end()) {
+        ob = it->second;
+        free_pool.erase(it);
+      } else {
+        ob = make_buffer(of);
+      }
+    }
+    st.out_buf = ob;
+    buf_of[of.name] = ob;
+    // release temporaries whose last reader was this step
+    std::set<std::string> released;
+    for (auto& f : step_reads(st)) {
+      const Field& rf = P.field(f);
+      if (rf.role == Role::Temp && last_use[f] == (int)s && released.insert(f).second) {
+        const int b = buf_of[f];
+        free_pool.insert({{pl.buffers[b].bytes(), (int)pl.buffers[b].dt}, b});
+        buf_of.erase(f);
+      }
+    }
+  }
+
+  // ---- generate + compile kernels
+  const double cells = (double)pl.n_local * (double)P.n[1] * (double)P.n[2];
+  for (auto& st : pl.steps) {
+    const DT dt = P.kernels[st.kernels[0]].dt;
+    if (st.star) {
+      if (star_lds_bytes(st.cfg, dt) > 160 * 1024)
+        throw Error(SF_ERR_INVALID, "star kernel: tile needs more than 160 KiB of LDS");
+      StarKernelSource g = st.compact ? gen_compact(P, st.kernels, st.cfg) : gen_star(P, st.kernels, st.cfg);
+      st.scalars = g.scalars;
+      st.scalar_offsets = g.scalar_offsets;
+      st.scalars_bytes = g.scalars_bytes;
+      st.num_aux = (int)g.aux.size();
+      // the generator numbers auxiliary pointers in first-use order over the
+      // fused stages, which is the order step_reads() lists them after the primary
+      {
+        const std::vector<std::string> reads = step_reads(st);
+        if (reads.size() != g.aux.size() + 1) throw Error(SF_ERR_STATE, "star step: auxiliary count mismatch");
+        for (size_t a = 0; a < g.aux.size(); ++a)
+          if (reads[a + 1] != g.aux[a]) throw Error(SF_ERR_STATE, "star step: auxiliary order mismatch");
+      }
+      st.halo_depth = st.cfg.T;
+      st.halo_buf = st.in_bufs[0];
+    } else {
+      // 4 points per thread with aligned vector loads when rows allow it; the
+      // one-point form is kept for short rows and for operators whose vector
+      // form would spill (same acceptance rule as for the star kernels)
+      const bool vec = (P.n[2] % 4 == 0) && pl.opt.get("generic.vec", 1) != 0;
+      const bool xcd = pl.opt.get("generic.xcd", 1) != 0;
+      // non-temporal output stores for fields beyond the Infinity Cache (see rank_star_cfgs)
+      const double out_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] *
+                               (double)P.n[2] * (double)size_of(dt);  // (alike on all ranks of a slab run)
+      const bool nts = pl.opt.get("generic.nt", out_bytes >= 256.0 * 1024 * 1024 ? 1 : 0) != 0;
+      // marching form (a thread walks `generic.ppt` planes with a register window,
+      // default 8) for 3-D programs; generic.march=0 restores the one-plane form
+      const bool march = vec && P.n[0] > 1 && pl.opt.get("generic.march", 1) != 0 && pl.opt.get("generic.bio", 0) == 0 &&
+                         pl.opt.get("generic.fast", 0) == 0;  // (those two are variants of the one-plane form)
+      const int ppt = (int)std::max<long long>(1, std::min<long long>(march ? 256 : 8, pl.opt.get("generic.ppt", march ? 8 : 1)));
+      auto make = [&](bool marching) {
+        return marching ? gen_generic_march(P, st.kernels[0], xcd, nts, ppt)
+               : vec    ? gen_generic_vec(P, st.kernels[0], xcd, nts, march ? 1 : ppt, pl.opt.get("generic.fast", 0) != 0,
+                                          pl.opt.get("generic.bio", 0) != 0)
+                        : gen_generic(P, st.kernels[0], xcd, nts);
+      };
+      GenericKernelSource g = make(march);
+      st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
+      auto unclean = [&](int ck) { return kernel_unsafe(pl.kernels[ck]) || kernel_slow(pl.kernels[ck]); };
+      if (march && unclean(st.ck)) {
+        g = make(false);
+        st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
+      }
+      if (vec && unclean(st.ck)) {
+        g = gen_generic(P, st.kernels[0], xcd, nts);
+        st.ck = intern_kernel(pl, std::string("sf_point_") + short_of(dt), g.source);
+      }
+      // the one-point form is the last resort: VGPR spills there are slow but correct,
+      // a code object with allocator code ahead of an EXEC restore is not acceptable anywhere
+      if (kernel_unsafe(pl.kernels[st.ck]))
+        throw Error(SF_ERR_UNSUPPORTED, "operator '" + P.kernels[st.kernels[0]].name +
+                                            "': the compiler placed register-allocator code ahead of an EXEC "
+                                            "restore in the generated kernel, which gives wrong results on gfx950 "
+                                            "(DESIGN.md 5.1); simplify the operator");
+      st.generic_vk = g.vk;
+      st.generic_ppt = g.planes_per_thread;
+      st.scalars = g.scalars;
+      int depth = 0, hb = -1;
+      for (size_t ai = 0; ai < P.kernels[st.kernels[0]].acc.size(); ++ai) {
+        const Access& a = P.kernels[st.kernels[0]].acc[ai];
+        if (std::abs(a.off[0]) > depth) {
+          depth = std::abs(a.off[0]);
+        }
+      }
+      // exchange descriptor names the first slab-split field read across planes
+      for (size_t r = 0; r < g.reads.size(); ++r)
+        for (auto& a : P.kernels[st.kernels[0]].acc)
+          if (a.field == g.reads[r] && a.off[0] != 0 && hb < 0) hb = st.in_bufs[r];
+      st.halo_depth = depth;
+      st.halo_buf = hb;
+    }
+    // a rank with a neighbour reads `halo_depth` planes of that neighbour's slab:
+    // they must exist in the local buffers (halo = 0 is only valid for a slab that
+    // touches both ends of the global domain)
+    const bool has_neighbour = pl.goff > 0 || pl.goff + pl.n_local < P.n[0];
+    if (has_neighbour && st.halo_buf >= 0 && st.halo_depth > pl.halo)
+      throw Error(SF_ERR_INVALID, "slab halo is shallower than a launch's reach; raise the halo");
+    CompiledKernel& ck = pl.kernels[st.ck];
+    ck.updates_per_launch = cells * (double)st.kernels.size();
+    pl.max_updates_per_launch = std::max(pl.max_updates_per_launch, ck.updates_per_launch);
+    ck.alg_bytes_per_launch = 0;
+    for (int k : st.kernels) ck.alg_bytes_per_launch += cells * 2.0 * (double)size_of(P.kernels[k].dt);
+  }
+  pl.description = describe_plan(pl);
+  pl.scalar_values.assign(P.num_scalar_inputs, 0.0);
+}
+
+}  // namespace sf

@@ -1,4 +1,4 @@
-"""The code objects the library refuses to run (stencilflow_amd/csrc/sf_hip.cpp:
+"""The code objects the library refuses to run (stencilflow_amd/csrc/codecache.cpp:
 count_late_exec_restores): on this toolchain a register-allocator
 copy can end up ahead of the EXEC restore of a join block and then runs for the
 lanes of the `if` body only.  The detector reads the machine code of every compiled

@@ -1,4 +1,4 @@
-"""The classifier behind `count_late_exec_restores` (stencilflow_amd/csrc/sf_hip.cpp) on
+"""The classifier behind `count_late_exec_restores` (stencilflow_amd/csrc/codecache.cpp) on
 hand-made instruction patterns: the compiler's assembly of a small kernel gets a few
 instructions appended behind its `s_endpgm` (never executed, but part of the code the
 library reads), is assembled, and handed to the library in place of the compiler's object

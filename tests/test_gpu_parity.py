@@ -675,7 +675,7 @@ def test_run_program_flags(programs_dir, tmp_path, monkeypatch):
 
 @pytest.mark.parametrize("graph", [0, 1])
 def test_graph_replay_follows_scalar_changes(tmp_path, graph):
-    """Launch-bound chains are replayed as one hipGraph (sf_hip.cpp: execute);
+    """Launch-bound chains are replayed as one hipGraph (csrc/exec.cpp: execute);
     the captured launches carry the scalar arguments by value, so changing a
     scalar input must rebuild the graph.  Same plan, three runs, two scalar
     sets; graph=0 is the plain stream path."""

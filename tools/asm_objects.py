@@ -3,7 +3,7 @@
 compiler's own assembly (hipcc -S, the flags of the library's hipRTC call), as it
 is or with instructions padded, assembled and linked into
 <out>/<variant>/<kernel name>.co.  On the GPU box SF_HIP_OBJECT_DIR=<out>/<variant>
-makes the library run these instead of compiling (sf_hip.cpp: intern_kernel).
+makes the library run these instead of compiling (csrc/codecache.cpp: intern_kernel).
 Purpose: tell a hazard / timing problem (goes away with padding) from a logical
 miscompile (stays) in the code objects that spill SGPRs, DESIGN.md §5.1.
 usage: asm_objects.py <out dir> [variant ...]     variants: asis nop_all nop_sgprw nop_vmem nop_lane,
