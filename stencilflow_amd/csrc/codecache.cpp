@@ -132,17 +132,18 @@ int count_late_exec_restores(const std::vector<char>& code) {
       const std::string t = b == std::string::npos ? "" : cur.text.substr(b);
       auto starts = [&](const char* p) { return t.compare(0, std::strlen(p), p) == 0; };
       char c = 'X';
-      if (starts("s_or_b64 exec, exec, s[") || starts("s_xor_b64 exec, exec, s[") || starts("s_andn2_b64 exec, exec, s[") ||
+      if (starts("s_or_b64 exec, exec, ") || starts("s_xor_b64 exec, exec, ") || starts("s_andn2_b64 exec, exec, ") ||
           starts("s_or_saveexec_b64 ") || starts("s_andn2_saveexec_b64 "))
         c = 'R';  // end of an `if`, `else` entry (two forms), loop exit: the EXEC updates that open a block
+                  // (the saved mask in an SGPR pair or in vcc)
       else if ((starts("s_mov_b32 s") || starts("s_mov_b64 s[") || starts("s_mov_b32 vcc") || starts("s_mov_b64 vcc")) &&
                t.find("exec") == std::string::npos)
         c = 'S';  // a split copy, or a constant: the allocator rematerialises values the same way
       else if (starts("v_readlane_b32 ") || starts("v_writelane_b32 "))
         c = 'S';
-      else if (starts("v_mov_b32_e32 ") || starts("v_mov_b64_e32 ") || starts("v_accvgpr_") || starts("scratch_load_") ||
-               starts("scratch_store_"))
-        c = 'V';
+      else if (starts("v_mov_b32") || starts("v_mov_b64") || starts("v_pk_mov_b32") || starts("v_accvgpr_") ||
+               starts("scratch_load_") || starts("scratch_store_"))
+        c = 'V';  // every encoding of a vector copy (e32 / e64 / dpp / sdwa, packed) and the spill code
       else if (starts("s_nop") || starts("s_waitcnt"))
         c = 'N';
       classes += c;
@@ -174,7 +175,9 @@ static void read_metadata(CompiledKernel& k) {
   // object reports all of them in use (106 on gfx950: every object of the probes that shows the
   // fault; the kernels of the benchmarks report 46-89 and show nothing).  Far below that no
   // allocator code exists, and scalar moves next to a restore are what the program says.
-  k.late_exec_restores = k.sgprs >= 64 ? count_late_exec_restores(k.code) : 0;
+  // (metadata that cannot be read says nothing about the register count: such an object is
+  // disassembled like a large one)
+  k.late_exec_restores = (k.sgprs >= 64 || k.sgprs < 0) ? count_late_exec_restores(k.code) : 0;
 }
 
 // Code objects are cached per process: plans of the same program (slab ranks,
@@ -260,8 +263,12 @@ int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& sou
   // (diagnostics: $SF_HIP_EXTRA_FLAGS adds compiler flags to every kernel, e.g.
   // "-mllvm -amdgpu-spill-sgpr-to-vgpr=0"; they become part of name and cache key)
   std::string flags = flags_in;
+  bool env_flags = false;
   if (const char* extra = std::getenv("SF_HIP_EXTRA_FLAGS"))
-    if (*extra) flags += (flags.empty() ? "" : " ") + std::string(extra);
+    if (*extra) {
+      flags += (flags.empty() ? "" : " ") + std::string(extra);
+      env_flags = true;
+    }
   // (kernels without extra flags keep the names and cache keys they always had)
   const std::string keyed = flags.empty() ? source : flags + "\n" + source;
   auto it = pl.kernel_by_source.find(keyed);
@@ -270,6 +277,7 @@ int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& sou
   k.name = prefix + "_" + hex8(fnv1a(keyed));
   k.source = source;
   k.flags = flags;
+  k.env_flags = env_flags;
   const std::string key = k.name + "\n" + keyed;
   bool cached = false;
   // (diagnostics: $SF_HIP_OBJECT_DIR/<kernel name>.co, a code object assembled by hand --
@@ -279,6 +287,7 @@ int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& sou
     std::ifstream f(std::string(dir) + "/" + k.name + ".co", std::ios::binary);
     if (f) {
       k.code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+      k.foreign = true;
       read_metadata(k);
       pl.kernels.push_back(std::move(k));
       pl.kernel_by_source[keyed] = (int)pl.kernels.size() - 1;

@@ -438,7 +438,13 @@ static void describe_step(std::ostringstream& desc, const sf_plan& pl, const Ste
   desc << " in";
   for (int b : st.in_bufs) desc << " b" << b;
   desc << " out b" << st.out_buf << " {vgpr " << ck.vgprs << " agpr " << ck.agprs << " spill " << ck.spills
-       << " scratch " << ck.scratch << "}\n";
+       << " scratch " << ck.scratch << "}";
+  // results produced under the diagnostic environment switches must not pass for normal runs
+  if (ck.foreign) desc << " [foreign object: $SF_HIP_OBJECT_DIR]";
+  if (ck.env_flags) desc << " [$SF_HIP_EXTRA_FLAGS: " << ck.flags << "]";
+  if (ck.late_exec_restores != 0 && std::getenv("SF_HIP_UNSAFE_SGPR_SPILLS"))
+    desc << " [UNSAFE: EXEC-restore fault tolerated, $SF_HIP_UNSAFE_SGPR_SPILLS]";
+  desc << "\n";
 }
 
 // The whole description: header line, one line per launch (long chains: the first ones).

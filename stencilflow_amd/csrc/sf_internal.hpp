@@ -64,6 +64,8 @@ struct CompiledKernel {
   int vgprs = -1, agprs = -1, sgprs = -1, spills = -1, scratch = -1, lds = -1, sgpr_spills = -1;
   int late_exec_restores = 0;  // see count_late_exec_restores()
   bool from_disk = false;  // the code object came from the on-disk cache
+  bool foreign = false;    // diagnostics: a hand-assembled object from $SF_HIP_OBJECT_DIR took the compiler's place
+  bool env_flags = false;  // diagnostics: compiled with $SF_HIP_EXTRA_FLAGS
 };
 
 struct Buffer {

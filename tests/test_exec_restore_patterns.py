@@ -52,6 +52,16 @@ PATTERNS = {
     # the same ahead of an `else` entry
     "before_else_entry": ("s_and_saveexec_b64 s[0:1], vcc\n ds_read_b32 v1, v2\n v_mov_b32_e32 v3, v4\n"
                           " s_mov_b64 s[4:5], s[10:11]\n s_or_saveexec_b64 s[0:1], s[0:1]\n", 1),
+    # the saved mask in vcc instead of an SGPR pair
+    "restore_from_vcc": ("s_and_saveexec_b64 vcc, vcc\n ds_read_b32 v1, v2\n v_mov_b32_e32 v3, v4\n"
+                         " s_mov_b64 s[4:5], s[10:11]\n s_or_b64 exec, exec, vcc\n", 1),
+    # other encodings of a vector copy between the scalar copy and the restore: packed, VOP3, DPP
+    "packed_copy": ("s_and_saveexec_b64 s[0:1], vcc\n ds_read_b32 v1, v2\n s_mov_b64 s[4:5], s[10:11]\n"
+                    " v_pk_mov_b32 v[2:3], v[4:5], v[6:7] op_sel:[0,1]\n s_or_b64 exec, exec, s[0:1]\n", 1),
+    "e64_copy": ("s_and_saveexec_b64 s[0:1], vcc\n ds_read_b32 v1, v2\n s_mov_b64 s[4:5], s[10:11]\n"
+                 " v_mov_b32_e64 v3, v4\n s_or_b64 exec, exec, s[0:1]\n", 1),
+    "dpp_copy": ("s_and_saveexec_b64 s[0:1], vcc\n ds_read_b32 v1, v2\n s_mov_b64 s[4:5], s[10:11]\n"
+                 " v_mov_b32_dpp v3, v4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_or_b64 exec, exec, s[0:1]\n", 1),
     # an ordinary join
     "plain_join": ("s_and_saveexec_b64 s[0:1], vcc\n ds_read_b32 v1, v2\n v_add_f32_e32 v1, v1, v1\n"
                    " s_or_b64 exec, exec, s[0:1]\n", 0),
@@ -92,14 +102,20 @@ def _object_with(base, label, snippet, sgprs):
     name, text, tmp = base
     assert text.count("s_endpgm") == 1
     text = text.replace("s_endpgm\n", "s_endpgm\n " + snippet, 1)
-    text = re.sub(r"\.amdhsa_next_free_sgpr \d+", ".amdhsa_next_free_sgpr %d" % (sgprs - 6), text)
+    unreadable = sgprs is None  # metadata the library cannot read: the register count is unknown
+    sgprs = 40 if unreadable else sgprs
     text = re.sub(r"\.sgpr_count:\s+\d+", ".sgpr_count:     %d" % sgprs, text)
+    text = re.sub(r"\.amdhsa_next_free_sgpr \d+", ".amdhsa_next_free_sgpr %d" % (sgprs - 6), text)
     out = tmp / label
     out.mkdir(exist_ok=True)
     (out / "k.s").write_text(text)
     subprocess.run([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
                     str(out / "k.s"), "-o", str(out / "k.o")], check=True)
     subprocess.run([LLVM + "/ld.lld", "-shared", str(out / "k.o"), "-o", str(out / (name + ".co"))], check=True)
+    if unreadable:  # (the assembler insists on the key: it is renamed in the finished object)
+        blob = (out / (name + ".co")).read_bytes()
+        assert blob.count(b".sgpr_count") == 1
+        (out / (name + ".co")).write_bytes(blob.replace(b".sgpr_count", b".sgpr_counx"))
     return str(out)
 
 
@@ -116,6 +132,21 @@ def test_objects_far_from_register_exhaustion_are_not_searched(base, label):
     snippet, _ = PATTERNS[label]
     got = _plan_report(SF_HIP_OBJECT_DIR=_object_with(base, "low_pressure_" + label, snippet, 40), SF_HIP_UNSAFE_SGPR_SPILLS="1")
     assert got["resources"]["scratch"] // 1000 == 0
+
+
+def test_an_object_without_readable_metadata_is_searched(base):
+    """`.sgpr_count` missing: the gate cannot tell that the object is far from register
+    exhaustion, so it is disassembled like a large one."""
+    snippet, _ = PATTERNS["split_copy"]
+    got = _plan_report(SF_HIP_OBJECT_DIR=_object_with(base, "no_metadata", snippet, None), SF_HIP_UNSAFE_SGPR_SPILLS="1")
+    assert got["resources"]["scratch"] // 1000 == 1
+
+
+def test_diagnostic_switches_are_named_in_the_description(base):
+    snippet, _ = PATTERNS["split_copy"]
+    got = _plan_report(SF_HIP_OBJECT_DIR=_object_with(base, "marked", snippet, 106), SF_HIP_UNSAFE_SGPR_SPILLS="1")
+    assert "[foreign object" in got["describe"] and "[UNSAFE" in got["describe"]
+    assert "[foreign" not in _plan_report()["describe"]
 
 
 def test_a_flagged_object_is_replaced_by_the_next_form_of_the_kernel(base):
