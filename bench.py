@@ -7,27 +7,39 @@ configs[2]) on N MI355X.
 One *step* = one execution of the whole 1000-operator chain on a synthetic
 grid resident in HBM.  N > 1 runs the slab-decomposed configuration configs[3]:
 (512*N) x 512 x 512, split along the outermost axis, one rank per GPU, halos
-exchanged over RCCL -- per-GPU work is fixed, so scaling is weak.  Started under
-torch.distributed.run the process is one of the N ranks; started as a plain
+exchanged over RCCL / xGMI -- per-GPU work is fixed, so scaling is weak.  Started
+under torch.distributed.run the process is one of the N ranks; started as a plain
 command with --gpus N > 1 it launches the N ranks itself (before anything
 touches a GPU), relays rank 0's line and fails unless N ranks really took part
 (the role of `mpirun -n N bin/run_distributed_program.py` in the reference,
 bin/run_distributed_program.py:98-100,283-299).  Rank 0 prints ONE JSON line
-(contract: task description; `roofline` and `cpu_baseline` are added at N = 1).
+(contract: task description).
 
-`roofline` (N = 1) describes the dominant kernel:
-  achieved / frac   HBM bytes one launch moves / its average duration (HIP events
-                    on the plan's stream), against the 8 TB/s peak; the bytes are
-                    the rocprofv3 PMC traffic of profiles/hbm_traffic.json when
+`roofline` describes the dominant kernel (on rank 0 for N > 1: per GPU):
+  achieved / frac   HBM bytes the kernel's launches move / their duration (HIP
+                    events on the plan's stream), against the 8 TB/s peak; the bytes
+                    are the rocprofv3 PMC traffic of profiles/hbm_traffic.json when
                     that was measured for exactly this code object (`basis`
                     "pmc"), else the compulsory minimum, one read and one write of
                     the field (`basis` "compulsory") -- never above 1;
-  traffic           the PMC bytes per launch, or null without a matching record;
+  traffic           the PMC bytes per (full-slab) launch, or null without a record;
   algorithmic_*     2 * sizeof(dtype) per cell update x the updates
                     of a launch.  A launch fuses `fused_operators` operators, so
                     this figure counts bytes that never travel and may exceed the
                     peak: it is the chain's speed-up over unfused sweeps, not a
                     bandwidth.
+At N = 1 the line also carries `cpu_baseline` (the oracle's C/OpenMP port on the
+host cores) and `other_configs`: BASELINE.json's configs[1] (jacobi2d 4096^2) and
+configs[4] (the fused f64 chain), timed the same way for a few steps each.
+
+N > 1: the halo transport is chosen from a ladder -- the
+library's own RCCL rung (ncclSend / ncclRecv issued by libsf_hip.so), its
+peer-to-peer DMA pushes, torch.distributed's RCCL, shared host memory, gloo --
+within a wall-clock budget; a rung counts only if, ON EVERY RANK, a decomposed run of
+the chain's first operators equals the rank's local recomputation of its slab from
+the global synthetic input bit for bit (stencilflow_amd.distributed.DecompositionCheck);
+the same check runs again after the timed region and the process exits non-zero on a
+mismatch (`config.verified`).
 """
 
 import argparse
@@ -45,13 +57,30 @@ if ROOT not in sys.path:
 
 HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
 SEED = 20261003
+BLOCK = 64  # planes per seeded block of the synthetic grid
 
 
-def synthetic(shape, rank=0, dtype=np.float32):
-    """Uniform random grid (timing on constant data flatters the clock:
-    cdna_hip_programming.md §5.4 rule 25)."""
-    rng = np.random.default_rng(SEED + rank)
-    return rng.random(shape, dtype=dtype)
+def synthetic_planes(lo, hi, tail, dtype=np.float32):
+    """Planes [lo, hi) of the global synthetic grid: uniform random in [0, 1), generated
+    in blocks of 64 planes seeded by (SEED, block index) -- any rank can produce any
+    plane range of the global input at a cost proportional to the range (timing on
+    constant data flatters the clock: cdna_hip_programming.md §5.4 rule 25)."""
+    tail = tuple(tail)
+    out = np.empty((max(0, hi - lo), ) + tail, dtype=dtype)
+    b = lo // BLOCK
+    while b * BLOCK < hi:
+        block = np.random.default_rng([SEED, b]).random((BLOCK, ) + tail, dtype=dtype)
+        s, e = max(lo, b * BLOCK), min(hi, (b + 1) * BLOCK)
+        out[s - lo:e - lo] = block[s - b * BLOCK:e - b * BLOCK]
+        b += 1
+    return out
+
+
+def synthetic(shape, dtype=np.float32):
+    """The whole grid of a single-GPU workload (2-D grids: one block)."""
+    if len(shape) == 2:
+        return np.random.default_rng([SEED, 0]).random(tuple(shape), dtype=dtype)
+    return synthetic_planes(0, shape[0], shape[1:], dtype)
 
 
 def measured_traffic(kernel):
@@ -179,6 +208,437 @@ def launch_check(args):
     return 0 if ranks == args.gpus else 1
 
 
+# --------------------------------------------------------------------------- workloads
+def make_workload(name, size, stages, slab_world=1):
+    """(program, shape, numpy dtype, dtype name, algorithmic bytes per update, label, stages)."""
+    from stencilflow_amd import programs
+    if name == "c3":
+        n = size or 512
+        shape = (n * slab_world, n, n)
+        return dict(prog=programs.jacobi3d(shape, stages), shape=shape, np_dtype=np.float32, dtype="f32", bpu=8.0,
+                    stages=stages, name=name,
+                    label=("jacobi3d {}x{}x{} float32, {}-operator chain, constant BC 0.0, "
+                           "coefficient 0.16666666").format(shape[0], shape[1], shape[2], stages))
+    if name == "c2":
+        n = size or 4096
+        shape = (n, n)
+        return dict(prog=programs.jacobi2d(shape, stages), shape=shape, np_dtype=np.float32, dtype="f32", bpu=8.0,
+                    stages=stages, name=name,
+                    label="jacobi2d {}x{} float32, {}-operator chain, constant BC 0.0".format(n, n, stages))
+    if name == "box":
+        n = size or 512
+        shape = (n, n, n)
+        prog, _ = programs.synthesize("float32", stages, 0.0, n, n, n, 1, 1, 1, stencil_shape="box")
+        return dict(prog=prog, shape=shape, np_dtype=np.float32, dtype="f32", bpu=8.0, stages=stages, name=name,
+                    label="27-point box {}^3 float32 (bin/synthesize.py -stencil_shape box), {}-operator chain".format(
+                        n, stages))
+    if name == "c5":
+        n = size or 512
+        shape = (n, n, n)
+        stages = max(3, stages // 3 * 3)
+        return dict(prog=programs.diffusion_advection_laplacian(shape, repeats=stages // 3), shape=shape,
+                    np_dtype=np.float64, dtype="f64", bpu=16.0, stages=stages, name=name,
+                    label=("diffusion->advection->laplacian {}^3 float64, {} operators "
+                           "({} chain applications), constant BC 0.0").format(n, stages, stages // 3))
+    raise SystemExit("unknown workload " + name)
+
+
+def lower_program(prog):
+    import stencilflow_amd as sf
+    from stencilflow_amd import programs
+    from stencilflow_amd.lowering import lower
+    with tempfile.TemporaryDirectory() as tmp:
+        chain = sf.KernelChainGraph(programs.write_program(prog, os.path.join(tmp, "bench.json")))
+        return chain, lower(chain)
+
+
+def roofline_block(name, moved_per_full_launch, traffic, seconds, launches_equivalent, launches, wl, fused, cells_per_launch):
+    """The `roofline` object: `moved_per_full_launch` bytes x `launches_equivalent`
+    full-slab launches in `seconds` of HIP-event time."""
+    avg_s = seconds / max(1e-30, launches_equivalent)
+    alg = cells_per_launch * wl["bpu"]  # SURVEY §8(d): 2 * sizeof(dtype) per cell update
+    return {
+        "bound": "hbm",
+        "kernel": name,
+        "achieved": moved_per_full_launch / avg_s / 1e9,
+        "peak": HBM_PEAK / 1e9,
+        "unit": "GB/s",
+        "frac": moved_per_full_launch / avg_s / HBM_PEAK,
+        "basis": "pmc" if traffic is not None else "compulsory",
+        "traffic": traffic,
+        "compulsory_bytes_per_launch": moved_per_full_launch if traffic is None else None,
+        "avg_launch_us": avg_s * 1e6,
+        "launches": launches,
+        "fused_operators": fused,
+        "algorithmic_bytes_per_launch": alg,
+        "algorithmic_achieved": alg / avg_s / 1e9,
+        "algorithmic_frac": alg / avg_s / HBM_PEAK,
+    }
+
+
+def time_single(wl, options, steps, warmup, device=0):
+    """One workload on one GPU: `steps` timed chain executions (barrier-free at N = 1,
+    synchronised on both sides), HIP events around every execution on the plan's stream.
+    Returns (result fields, plan description line)."""
+    import torch
+    from stencilflow_amd.backend import Plan
+    chain, sfir = lower_program(wl["prog"])
+    plan = Plan(sfir, device=device, options=options)
+    try:
+        scalar_values = [chain.inputs[k]["data"] for k in plan.scalar_names]
+        if scalar_values:
+            plan.set_scalars(scalar_values)
+        data = synthetic(wl["shape"], wl["np_dtype"])
+        plan.upload([data])
+        # one untimed execution before the counted warm-up steps: the first pass loads the
+        # code objects and sizes the launch queues -- none of which belongs to a step even
+        # when the caller asks for --warmup 0.  The grid is uploaded again afterwards so the
+        # timed steps start from the same synthetic data.
+        plan.execute(1)
+        plan.synchronize()
+        plan.upload([data])
+        for _ in range(warmup):
+            plan.execute(1)
+        plan.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kernel_ms = 0.0
+        for _ in range(steps):
+            plan.execute(1)
+            plan.synchronize()  # HIP events bracket the launches of this step on the plan's stream
+            kernel_ms += plan.elapsed_ms()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        stats = plan.kernel_stats()
+        launches = plan.num_launches * steps
+        name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"])
+        fused = wl["stages"] / plan.num_launches  # operators evaluated per launch
+        cells = float(np.prod(wl["shape"])) * wl["stages"] * steps
+        compulsory = float(np.prod(wl["shape"])) * wl["bpu"]  # the field once in, once out
+        traffic = measured_traffic(name)
+        roof = roofline_block(name, traffic if traffic is not None else compulsory, traffic, kernel_ms * 1e-3,
+                              launches, launches, wl, fused, cells / launches)
+        roof["compulsory_bytes_per_launch"] = compulsory
+        return {"value": cells / elapsed / 1e6, "ms_per_step": elapsed / steps * 1e3, "roofline": roof,
+                "schedule": plan.describe().splitlines()[1].strip()}
+    finally:
+        plan.close()
+
+
+# --------------------------------------------------------------------------- N > 1
+class Decomposed:
+    """The slab-decomposed run of one rank: transport ladder, schedule, check, timing."""
+
+    RUNGS = ["rccl", "p2p", "torch", "shm", "gloo"]
+    NAMES = {"rccl": "RCCL send/recv issued by libsf_hip.so (sf_halo_use_rccl: grouped ncclSend / ncclRecv on the "
+                     "transport's stream)",
+             "p2p": "DMA pushes into the neighbours' ghost planes (HIP IPC, flags in shared host memory; sf_halo_*)",
+             "torch": "RCCL send/recv through torch.distributed on device buffers",
+             "shm": "pinned host memory shared by the ranks, stream-ordered flags",
+             "gloo": "gloo through pinned host buffers"}
+
+    def __init__(self, args, wl, sfir, options, rank, world, local_rank, self_loop):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.args, self.wl, self.sfir, self.options = args, wl, sfir, options
+        self.rank, self.world, self.local_rank, self.self_loop = rank, world, local_rank, self_loop
+        self.slab_rank, self.slab_world = (1, 3) if self_loop else (rank, world)
+        self.shape = wl["shape"]
+        self.notes = []
+        self.groups_made = {}
+        self.instances = 0
+        session = [None]
+        if rank == 0:
+            session[0] = "{}_{:06x}".format(os.getpid(), int.from_bytes(os.urandom(3), "little"))
+        dist.broadcast_object_list(session, src=0)
+        self.session = session[0]
+        # the check program: the chain's first K operators (K planes of dependency cone per side)
+        n_min = self.shape[0] // self.slab_world
+        self.check_ops = max(2, min(64, args.stages, n_min // 2))
+        from stencilflow_amd import programs
+        _, self.check_sfir = lower_program(programs.jacobi3d(self.shape, self.check_ops))
+
+    # ---- small collectives over the control plane (gloo)
+    def agreed_max(self, *values):
+        t = self.torch.tensor(values, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    def everywhere(self, ok):
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def planes_of(self, lo, hi):
+        # (self-loop test: halos come back to the sender, there is no global grid -- see check())
+        return synthetic_planes(lo, hi, self.shape[1:], self.wl["np_dtype"])
+
+    # ---- transports
+    def make_exchanger(self, rung):
+        """A fresh exchanger of this rung (collective: every rank makes the same calls)."""
+        import datetime
+        from stencilflow_amd.distributed import PeerExchanger, ShmExchanger, TorchDistExchanger
+        self.instances += 1
+        tag = "{}_{}".format(self.session, self.instances)
+        if rung in ("rccl", "p2p"):
+            if self.self_loop and rung == "p2p":
+                raise RuntimeError("the peer-to-peer transport has no self-loop mode")
+            return PeerExchanger(self.slab_rank, self.slab_world, tag, device=self.local_rank, transport=rung,
+                                 self_loop=self.self_loop)
+        if rung == "torch":
+            if "nccl" not in self.groups_made:
+                self.groups_made["nccl"] = self.dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=60))
+            ex = TorchDistExchanger(self.slab_rank, self.slab_world, group=self.groups_made["nccl"], staging="device",
+                                    self_loop=self.self_loop)
+            ex.handshake(self.torch.device("cuda", self.local_rank))
+            return ex
+        if self.self_loop and rung == "shm":
+            raise RuntimeError("the shared-memory transport has no self-loop mode")
+        if rung == "shm":
+            ex = ShmExchanger(self.rank, self.world, tag, device=self.local_rank)
+        else:
+            ex = TorchDistExchanger(self.slab_rank, self.slab_world, staging="host", self_loop=self.self_loop)
+        ex.handshake()
+        return ex
+
+    @staticmethod
+    def close_exchanger(ex):
+        if ex is not None and hasattr(ex, "close"):
+            ex.close()
+
+    def make_runner(self, sfir, rung, groups, data=True):
+        """(runner, exchanger) of this rung; the runner holds this rank's slab of the global input."""
+        from stencilflow_amd.distributed import SlabRunner
+        ex = self.make_exchanger(rung)
+        try:
+            r = SlabRunner(sfir, self.shape, self.slab_rank, self.slab_world, device=self.local_rank,
+                           options=self.options, exchanger=ex, groups_per_exchange=groups)
+        except Exception:
+            self.close_exchanger(ex)
+            raise
+        if data:
+            r.upload([self.planes_of(r.lo, r.hi)])
+        return r, ex
+
+    def run_chain(self, runner, native):
+        if native:
+            runner.execute_native()
+            runner.plan.synchronize()
+        else:
+            runner.execute()
+            runner.synchronize()
+        if hasattr(runner.exchanger, "check"):
+            runner.exchanger.check()  # a halo wait that timed out must not pass for a result
+
+    def chain_seconds(self, runner, native):
+        """Agreed (max over ranks) wall time of one chain execution, after one untimed one."""
+        self.run_chain(runner, native)
+        self.dist.barrier()
+        t0 = time.perf_counter()
+        self.run_chain(runner, native)
+        return self.agreed_max(time.perf_counter() - t0)[0]
+
+    # ---- the check
+    def build_check(self, rung, groups, early, native, reserved):
+        """DecompositionCheck over a fresh exchanger of `rung`, with the schedule under test."""
+        from stencilflow_amd.distributed import DecompositionCheck
+        made = {}
+        settings = {"native": native}
+
+        def make(sfir):
+            r, ex = self.make_runner(sfir, rung, groups, data=False)
+            r.early_exchange = early
+            if reserved is not None and hasattr(ex, "reserved_cus"):
+                ex.reserved_cus = reserved
+            made["ex"] = ex
+            return r
+
+        if self.self_loop:
+            # one rank playing rank 1 of 3 whose halos come back to itself: there is no global
+            # solution to compare with; the check then only exercises the machinery
+            class Mirror:
+                def __init__(mirror):
+                    mirror.runner = make(self.check_sfir)
+
+                def passes(mirror):
+                    mirror.runner.upload([self.planes_of(mirror.runner.lo, mirror.runner.hi)])
+                    self.run_chain(mirror.runner, settings["native"])
+                    return True
+
+                def close(mirror):
+                    mirror.runner.close()
+            check = Mirror()
+        else:
+            check = DecompositionCheck(self.check_sfir, self.shape, self.slab_rank, self.slab_world, self.planes_of, make,
+                                       lambda r: self.run_chain(r, settings["native"]), device=self.local_rank,
+                                       options=self.options, dtype=self.wl["np_dtype"])
+        check.exchanger = made.get("ex")
+        check.settings = settings
+        return check
+
+    def close_check(self, check):
+        """Collective (also for a rank whose check was never built)."""
+        self.close_exchanger(getattr(check, "exchanger", None))
+        self.dist.barrier()  # no rank frees buffers a neighbour still has mapped
+        if check is not None:
+            check.close()
+
+    def try_rung(self, rung, native):
+        """Set the rung up, prove it (check on every rank) and time one chain execution.
+        Returns (seconds or None, runner, exchanger, check, message); collective."""
+        runner = ex = check = None
+        ok, msg = True, ""
+        try:
+            check = self.build_check(rung, 8, False, native, None)
+            ok = check.passes()
+            if not ok:
+                msg = "decomposed result differs from the local recomputation"
+        except Exception as exc:  # noqa: BLE001 -- any transport failure selects the next rung
+            ok = False
+            msg = "{}: {}".format(type(exc).__name__, str(exc).splitlines()[0][:160] if str(exc) else "")
+        if not self.everywhere(ok):
+            self.close_check(check)
+            return None, None, None, None, msg or "failed on another rank"
+        try:
+            runner, ex = self.make_runner(self.sfir, rung, 8)
+            seconds = self.chain_seconds(runner, native)
+        except Exception as exc:  # noqa: BLE001
+            ok = False
+            msg = "{}: {}".format(type(exc).__name__, str(exc).splitlines()[0][:160] if str(exc) else "")
+            seconds = None
+        if not self.everywhere(ok):
+            self.close_exchanger(ex)
+            self.dist.barrier()
+            if runner is not None:
+                runner.close()
+            self.close_check(check)
+            return None, None, None, None, msg or "failed on another rank"
+        return seconds, runner, ex, check, ""
+
+    def select_transport(self):
+        """Walk the ladder within the wall-clock budget; keep the fastest proven rung."""
+        first = os.environ.get("SF_BENCH_TRANSPORT")
+        if first == "torch-rccl":
+            first = "torch"
+        budget = float(os.environ.get("SF_BENCH_LADDER_SECONDS", "60"))
+        # a pinned rung is taken without probing the others; when it fails the ladder continues below it
+        ladder = self.RUNGS[self.RUNGS.index(first):] if first in self.RUNGS else list(self.RUNGS)
+        native_env = os.environ.get("SF_BENCH_SCHEDULE")
+        t_begin = time.perf_counter()
+        best = None
+        for rung in ladder:
+            library_rung = rung in ("rccl", "p2p")
+            if best is not None:
+                (elapsed, ) = self.agreed_max(time.perf_counter() - t_begin)
+                if first in self.RUNGS or not library_rung or elapsed > budget:
+                    break
+            native = library_rung and native_env != "python"
+            seconds, runner, ex, check, msg = self.try_rung(rung, native)
+            if seconds is None:
+                self.notes.append("{} not used: {}".format(rung, msg))
+                continue
+            self.notes.append("{}: verified, one chain execution {:.2f} ms".format(rung, seconds * 1e3))
+            cand = dict(rung=rung, seconds=seconds, runner=runner, ex=ex, check=check, native=native)
+            if best is None or seconds < best["seconds"]:
+                best, cand = cand, best
+            if cand is not None:
+                self.close_exchanger(cand["ex"])
+                self.dist.barrier()
+                cand["runner"].close()
+                self.close_check(cand["check"])
+        if best is None:
+            raise SystemExit("no halo transport works: " + "; ".join(self.notes))
+        return best
+
+    def tune_schedule(self, best):
+        """Halo depth, early exchange, reserved units and native / Python schedule, by
+        measurement, alike on all ranks (maxima over ranks)."""
+        rung, runner, ex = best["rung"], best["runner"], best["ex"]
+        deep = runner.halo
+        t_deep, t_half = self.agreed_max(runner.measure_exchange(), runner.measure_exchange(depth=max(1, deep // 2)))
+        t_launch = best["seconds"] / max(1, len(runner.steps))
+        env_groups = os.environ.get("SF_BENCH_GROUPS")
+        groups = int(env_groups) if env_groups in ("4", "8") else (8 if t_deep <= 0.85 * t_launch else 4)
+        if groups != 8:
+            self.close_exchanger(ex)
+            self.dist.barrier()
+            runner.close()
+            runner, ex = self.make_runner(self.sfir, rung, groups)
+            best["runner"], best["ex"] = runner, ex
+        best["groups"] = groups
+        t_exchange = t_deep if groups == 8 else t_half
+        env_early = os.environ.get("SF_BENCH_EARLY_EXCHANGE")
+        runner.early_exchange = (env_early == "1") if env_early in ("0", "1") else t_exchange > 0.85 * t_launch
+        self.notes.append("exchange alone {:.0f} us ({} planes) / {:.0f} us ({} planes), launch group {:.0f} us -> {}".format(
+            t_deep * 1e6, deep, t_half * 1e6, max(1, deep // 2), t_launch * 1e6,
+            "started a launch ahead" if runner.early_exchange else "started with the launch that needs it"))
+        # Compute units left to the exchange's copy kernels by the launch that runs beside
+        # them (RCCL rungs only): with them a copy kernel never waits for a 200-us block to
+        # retire, without them that launch is ~12 % shorter.  Both are timed.
+        default_cus = int(getattr(ex, "reserved_cus", 0))
+        env_cus = os.environ.get("SF_BENCH_RESERVED_CUS")
+        if default_cus > 0 and env_cus is None:
+            timing = {}
+            for cus in (default_cus, 0):
+                ex.reserved_cus = cus
+                timing[cus] = self.chain_seconds(runner, best["native"])
+            ex.reserved_cus = min(timing, key=timing.get)
+            self.notes.append("{} units reserved beside an exchange ({})".format(
+                ex.reserved_cus, ", ".join("{}: {:.2f} ms".format(k, v * 1e3) for k, v in timing.items())))
+        elif default_cus > 0:
+            ex.reserved_cus = int(env_cus)
+        # the library's own schedule against SlabRunner's Python form of it (A/B)
+        if rung in ("rccl", "p2p") and os.environ.get("SF_BENCH_SCHEDULE") is None:
+            timing = {"native": self.chain_seconds(runner, True), "python": self.chain_seconds(runner, False)}
+            best["native"] = timing["native"] <= timing["python"]
+            self.notes.append("schedule: sf_plan_execute_decomposed {:.2f} ms, SlabRunner {:.2f} ms".format(
+                timing["native"] * 1e3, timing["python"] * 1e3))
+        # the check follows the schedule that will be timed
+        if groups == 8:
+            check = best["check"]
+            check.runner.early_exchange = runner.early_exchange
+            check.settings["native"] = best["native"]
+            if hasattr(check.exchanger, "reserved_cus"):
+                check.exchanger.reserved_cus = getattr(ex, "reserved_cus", 0)
+        else:  # another halo depth is another plan
+            self.close_check(best["check"])
+            best["check"] = None
+            best["check"] = self.build_check(rung, groups, runner.early_exchange, best["native"],
+                                             getattr(ex, "reserved_cus", None))
+        ok = False
+        try:
+            ok = best["check"].passes()
+        except Exception as exc:  # noqa: BLE001
+            self.notes.append("check of the tuned schedule raised {}: {}".format(type(exc).__name__, exc))
+        if not self.everywhere(ok):
+            raise SystemExit("the tuned schedule does not reproduce the local recomputation: " + "; ".join(self.notes))
+
+    def per_gpu_roofline(self, best, fused):
+        """One more, untimed chain execution with HIP events around every launch of rank 0's
+        plan: the dominant kernel's bytes over its launch time (per GPU)."""
+        runner = best["runner"]
+        plan = runner.plan
+        plan.set_profile(True)
+        self.run_chain(runner, best["native"])
+        plan.synchronize()
+        stats, planes = plan.kernel_stats(), plan.kernel_planes()
+        plan.set_profile(False)
+        name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"])
+        n_local = runner.n_local
+        full_launches = planes[name] / float(n_local)  # launches over ranges of other lengths, in full-slab units
+        plane_cells = float(np.prod(self.shape[1:]))
+        compulsory = n_local * plane_cells * self.wl["bpu"]
+        traffic = measured_traffic(name)
+        roof = roofline_block(name, traffic if traffic is not None else compulsory, traffic, stats[name]["total_ms"] * 1e-3,
+                              full_launches, stats[name]["launches"], self.wl, fused, n_local * plane_cells * fused)
+        roof["compulsory_bytes_per_launch"] = compulsory
+        roof["scope"] = ("rank 0, one GPU: {} launches of one chain execution (interior, boundary and halo-extended "
+                         "plane ranges) = {:.1f} full-slab launches; bytes scale with the planes a launch writes").format(
+                             stats[name]["launches"], full_launches)
+        return roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +653,8 @@ def main():
     ap.add_argument("--stages", type=int, default=1000)
     ap.add_argument("--options", type=str, default="")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, default workload: leave out the c2 / c5 lines (`other_configs`)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins the control group "
@@ -213,17 +675,13 @@ def main():
         raise SystemExit(launch_check(args))
 
     import torch
-    import stencilflow_amd as sf
-    from stencilflow_amd import programs
-    from stencilflow_amd.backend import Plan
-    from stencilflow_amd.lowering import lower
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    # test hook: all ranks on device 0 with the exchange staged through gloo
-    # (exercises the multi-rank path on a one-GPU box; never used for records)
+    # test hook: all ranks on device 0 (exercises the multi-rank path on a one-GPU box;
+    # never used for records)
     one_device = os.environ.get("SF_BENCH_SINGLE_DEVICE") == "1"
     if one_device:
         local_rank = 0
@@ -233,374 +691,147 @@ def main():
     # itself -- through the same transport ladder, RCCL first (the data are not a
     # stencil solution; never used for records, the JSON line says so)
     self_loop = world == 1 and os.environ.get("SF_BENCH_SELF_LOOP") == "1"
-    slab_rank, slab_world = (1, 3) if self_loop else (rank, world)
+    slab_world = 3 if self_loop else world
     multi = slab_world > 1
 
     if args.workload != "c3" and world > 1:
         raise SystemExit("only the c3 workload is slab-decomposed by bench.py")
-    if args.workload == "c3":
-        n = args.size or 512
-        shape = (n * slab_world, n, n)
-        prog = programs.jacobi3d(shape, args.stages)
-        np_dtype, dtype_name, bpu = np.float32, "f32", 8.0
-        label = ("jacobi3d {}x{}x{} float32, {}-operator chain, constant BC 0.0, "
-                 "coefficient 0.16666666").format(shape[0], shape[1], shape[2], args.stages)
-    elif args.workload == "c2":
-        n = args.size or 4096
-        shape = (n, n)
-        prog = programs.jacobi2d(shape, args.stages)
-        np_dtype, dtype_name, bpu = np.float32, "f32", 8.0
-        label = "jacobi2d {}x{} float32, {}-operator chain, constant BC 0.0".format(
-            n, n, args.stages)
-    elif args.workload == "box":
-        n = args.size or 512
-        shape = (n, n, n)
-        prog, _ = programs.synthesize("float32", args.stages, 0.0, n, n, n, 1, 1, 1, stencil_shape="box")
-        np_dtype, dtype_name, bpu = np.float32, "f32", 8.0
-        label = "27-point box {}^3 float32 (bin/synthesize.py -stencil_shape box), {}-operator chain".format(n, args.stages)
-    else:
-        n = args.size or 512
-        shape = (n, n, n)
-        args.stages = max(3, args.stages // 3 * 3)
-        prog = programs.diffusion_advection_laplacian(shape, repeats=args.stages // 3)
-        np_dtype, dtype_name, bpu = np.float64, "f64", 16.0
-        label = ("diffusion->advection->laplacian {}^3 float64, {} operators "
-                 "({} chain applications), constant BC 0.0").format(n, args.stages, args.stages // 3)
+    wl = make_workload(args.workload, args.size, args.stages, slab_world)
+    args.stages = wl["stages"]
     options = {k: v for k, v in (kv.split("=") for kv in args.options.split(";") if kv)}
+    metric = ("Mcells/s (updates) and achieved HBM GB/s vs roofline, jacobi3d 512^3 f32" if args.workload == "c3" else
+              "Mcells/s (updates) and achieved HBM GB/s vs roofline, " + args.workload)
+    result = {
+        "metric": metric, "value": None, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": wl["dtype"],
+        "data": "synthetic (uniform random [0,1), 64-plane blocks seeded (%d, block))" % SEED,
+        "config": {"workload": wl["label"]},
+    }
 
-    with tempfile.TemporaryDirectory() as tmp:
-        path = programs.write_program(prog, os.path.join(tmp, "bench.json"))
-        chain = sf.KernelChainGraph(path)
-        sfir = lower(chain)
+    if not multi:
+        timed = time_single(wl, options, args.steps, args.warmup, device=local_rank)
+        result["value"], result["ms_per_step"] = timed["value"], timed["ms_per_step"]
+        result["roofline"] = timed["roofline"]
+        result["config"].update(decomposition="single", ranks=1, transport="none (single GPU)",
+                                schedule=timed["schedule"])
+        if args.workload == "c3" and not args.size and not args.options and not args.no_other_configs:
+            # BASELINE.json configs[1] and configs[4] in the driver's own line:
+            # a few chain executions each (about 0.1 s and 0.05 s of GPU time)
+            others = []
+            for name, stages, steps in (("c2", 1000, 3), ("c5", 3, 20)):
+                owl = make_workload(name, 0, stages)
+                t = time_single(owl, {}, steps, 1, device=local_rank)
+                others.append({"workload": owl["label"], "value": t["value"], "unit": "Mcells/s", "steps": steps,
+                               "ms_per_step": t["ms_per_step"], "dtype": owl["dtype"], "roofline": t["roofline"],
+                               "schedule": t["schedule"]})
+            result["other_configs"] = others
+        if not args.no_cpu_baseline and args.workload == "c3":
+            result["cpu_baseline"] = cpu_baseline(wl["shape"], budget_s=args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+        return
 
-    transport = None
-    if multi:
-        import datetime
-        from stencilflow_amd.distributed import SlabRunner, TorchDistExchanger
-        import torch.distributed as dist
-        # gloo is the control plane (barriers, the max over ranks) and the last
-        # resort; the halos travel over RCCL (backend "nccl") if a handshake with
-        # both neighbours succeeds on EVERY rank, else through pinned host memory
-        # shared by the ranks (ShmExchanger: DMA copies, flags raised and awaited
-        # by the streams), else through gloo.  SF_BENCH_TRANSPORT=rccl|shm|gloo
-        # starts the ladder at that rung (tests).
-        from stencilflow_amd.distributed import ShmExchanger
-        if self_loop:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29657")
-            dist.init_process_group("gloo", rank=0, world_size=1)
+    # ---- N > 1: one rank per GPU; gloo is the control plane (barriers, maxima over ranks)
+    import datetime
+    import torch.distributed as dist
+    # (a rank that dies must not leave the others waiting for the default half hour)
+    patience = datetime.timedelta(seconds=float(os.environ.get("SF_BENCH_CONTROL_TIMEOUT", "300")))
+    if self_loop:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29657")
+        dist.init_process_group("gloo", rank=0, world_size=1, timeout=patience)
+    else:
+        dist.init_process_group("gloo", timeout=patience)
+    _, sfir = lower_program(wl["prog"])
+
+    # what one GPU does with the undivided 512^3 grid, measured on rank 0 in this very
+    # process before the decomposed run (the per-GPU yardstick of the N-GPU value)
+    undivided = None
+    if rank == 0 and not self_loop and os.environ.get("SF_BENCH_NO_UNDIVIDED") != "1":
+        one = make_workload("c3", args.size, args.stages, 1)
+        undivided = time_single(one, options, 2, 1, device=local_rank)["value"]
+    dist.barrier()
+
+    job = Decomposed(args, wl, sfir, options, rank, world, local_rank, self_loop)
+    best = job.select_transport()
+    job.tune_schedule(best)
+    runner, exchanger, native = best["runner"], best["ex"], best["native"]
+
+    def step():
+        if native:
+            runner.execute_native()
         else:
-            dist.init_process_group("gloo")
-        first = os.environ.get("SF_BENCH_TRANSPORT", "p2p")
-        ladder = ["p2p", "rccl", "shm", "gloo"]
-        ladder = ladder[ladder.index(first):] if first in ladder else ladder
-        session = [None]
-        if rank == 0:
-            session[0] = "{}_{}".format(os.getpid(), int(time.time() * 1e3) & 0xffffff)
-        dist.broadcast_object_list(session, src=0)
-        names = {"p2p": "DMA pushes into the neighbours' ghost planes (HIP IPC, flags in shared host memory; sf_halo_*)",
-                 "rccl": "RCCL send/recv on device buffers",
-                 "shm": "pinned host memory shared by the ranks, stream-ordered flags",
-                 "gloo": "gloo through pinned host buffers"}
-        instances = [0]
-
-        def make_exchanger(rung):
-            """A fresh exchanger of this rung (collective: every rank makes the same calls)."""
-            instances[0] += 1
-            tag = "{}_{}".format(session[0], instances[0])
-            if rung == "p2p":
-                if self_loop:
-                    raise RuntimeError("the peer-to-peer transport has no self-loop mode")
-                from stencilflow_amd.distributed import PeerExchanger
-                return PeerExchanger(rank, world, tag, device=local_rank)
-            if rung == "rccl":
-                if "rccl" not in groups_made:
-                    groups_made["rccl"] = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
-                return TorchDistExchanger(slab_rank, slab_world, group=groups_made["rccl"], staging="device",
-                                          self_loop=self_loop)
-            if rung == "shm":
-                if self_loop:
-                    raise RuntimeError("the shared-memory transport has no self-loop mode")
-                return ShmExchanger(rank, world, tag, device=local_rank)
-            return TorchDistExchanger(slab_rank, slab_world, staging="host", self_loop=self_loop)
-
-        groups_made = {}
-
-        def proves_itself(rung):
-            """The rung's self-test on every rank: (works everywhere, ranks that passed, message)."""
-            ok, msg, candidate, probe = 1, "", None, None
-            try:
-                candidate = make_exchanger(rung)
-                if rung == "p2p":
-                    # its proof needs device buffers of a plan: a small decomposed chain,
-                    # rank-stamped planes pushed into both neighbours and checked there
-                    small = programs.jacobi3d((16 * world, 8, 64), 2)
-                    with tempfile.TemporaryDirectory() as tmp2:
-                        small_sfir = lower(sf.KernelChainGraph(programs.write_program(small, os.path.join(tmp2, "p.json"))))
-                    probe = SlabRunner(small_sfir, (16 * world, 8, 64), rank, world, device=local_rank,
-                                       exchanger=candidate, groups_per_exchange=1)
-                elif rung == "rccl":
-                    candidate.handshake(torch.device("cuda", local_rank))
-                else:
-                    candidate.handshake()
-            except Exception as exc:  # noqa: BLE001 -- any transport failure selects the next rung
-                ok = 0
-                msg = "{}: {}".format(type(exc).__name__, str(exc).splitlines()[0][:120] if str(exc) else "")
-            finally:
-                if probe is not None:
-                    probe.close()
-                if candidate is not None and hasattr(candidate, "close") and rung != "rccl":
-                    candidate.close()
-            flag = torch.tensor([ok, -ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            count = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(count, op=dist.ReduceOp.SUM)
-            return int(flag[0].item()) == 1, int(count.item()), msg
-
-        # device-to-device transports that prove themselves are all kept: the fastest
-        # exchange, measured below on the real buffers, wins; the host-staged spares are
-        # tried only when none of them works
-        working, why, ranks_connected = [], [], 0
-        for rung in ladder:
-            if working and rung in ("shm", "gloo"):
-                break
-            ok, connected, msg = proves_itself(rung)
-            if ok:
-                working.append(rung)
-                ranks_connected = connected
-                if rung in ("shm", "gloo"):
-                    break
-            else:
-                why.append("{} handshake failed on some rank{}".format(rung, ": " + msg if msg else ""))
-        if not working:
-            raise SystemExit("no halo transport works: " + "; ".join(why))
-        if ranks_connected != world:
-            raise SystemExit("{} of {} ranks connected over {}".format(ranks_connected, world, working[0]))
-        rung_used = working[0]
-        exchanger = make_exchanger(rung_used)
-        # The schedule is chosen by measurement, alike on all ranks.  With halos twice
-        # as deep an exchange is needed every 8 launches instead of every 4, which
-        # saves 2.5 % when real RCCL copy kernels run beside the compute kernel
-        # (tools/rccl_overlap_probe.py: 218.4 against 224.1 us per launch group) --
-        # if a 16-plane exchange still fits beside ONE interior launch.  If even the
-        # 8-plane exchange does not, it is started a launch ahead (two interiors of
-        # cover for +4 % of driver overhead, tools/slab_overhead.py).
-        def build(groups, ex=None):
-            r = SlabRunner(sfir, shape, slab_rank, slab_world, device=local_rank, options=options,
-                           exchanger=ex if ex is not None else exchanger, groups_per_exchange=groups)
-            r.upload([synthetic(r.local_shape, rank)])
-            return r
-
-        def agreed(*values):
-            t = torch.tensor(values, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return [float(v) for v in t]
-
-        runner = build(8)
-        if len(working) > 1:
-            # several device-to-device transports work: run the whole chain with each on
-            # the real buffers -- exchanges beside interior launches, as in the timed
-            # region -- and keep the faster one (maxima over ranks; an exchange timed
-            # alone would not show a transport whose copies queue behind the compute kernel)
-            def chain_seconds():
-                # (same random data for every candidate: attaching a transport proves
-                # itself on the buffers and clears them, and zeros flatter the clock)
-                runner.upload([synthetic(runner.local_shape, rank)])
-                runner.execute()
-                runner.synchronize()
-                dist.barrier()
-                t0 = time.perf_counter()
-                runner.execute()
-                runner.synchronize()
-                return agreed(time.perf_counter() - t0)[0]
-
-            def use(ex):
-                # (RCCL's copy kernels want a few free units beside the interior launch)
-                if hasattr(ex, "attach"):
-                    runner.attach_exchanger(ex)
-                else:
-                    runner.exchanger = ex
-
-            timing = {rung_used: chain_seconds()}
-            for rung in working[1:]:
-                other = make_exchanger(rung)
-                use(other)
-                timing[rung] = chain_seconds()
-                if min(timing, key=timing.get) == rung:
-                    if hasattr(exchanger, "close") and rung_used != "rccl":
-                        exchanger.close()
-                    exchanger, rung_used = other, rung
-                else:
-                    runner.exchanger = exchanger
-                    if hasattr(other, "close") and rung != "rccl":
-                        other.close()
-            why.append("one chain execution: {}".format(", ".join(
-                "{} {:.2f} ms".format(k, v * 1e3) for k, v in timing.items())))
-        transport = names[rung_used]
-        if why:
-            transport += " (" + "; ".join(why) + ")"
-        deep = runner.halo
-        t_deep, t_half = agreed(runner.measure_exchange(), runner.measure_exchange(depth=max(1, deep // 2)))
-        runner.execute()
-        runner.synchronize()
-        t0 = time.perf_counter()
-        runner.execute()
-        runner.synchronize()
-        (t_launch, ) = agreed((time.perf_counter() - t0) / max(1, len(runner.steps)))
-        env_groups = os.environ.get("SF_BENCH_GROUPS")
-        groups = int(env_groups) if env_groups in ("4", "8") else (8 if t_deep <= 0.85 * t_launch else 4)
-        if groups != 8:
-            runner.close()
-            if hasattr(exchanger, "attach"):  # buffers are registered per plan: a fresh transport
-                exchanger.close()
-                exchanger = make_exchanger(rung_used)
-            runner = build(groups)
-        t_exchange = t_deep if groups == 8 else t_half
-        env_early = os.environ.get("SF_BENCH_EARLY_EXCHANGE")
-        runner.early_exchange = (env_early == "1") if env_early in ("0", "1") else t_exchange > 0.85 * t_launch
-        transport += "; exchange alone {:.0f} us ({} planes) / {:.0f} us ({} planes), launch group {:.0f} us -> {}".format(
-            t_deep * 1e6, deep, t_half * 1e6, max(1, deep // 2), t_launch * 1e6,
-            "started a launch ahead" if runner.early_exchange else "started with the launch that needs it")
-        # Compute units left to the exchange's copy kernels by the launch that runs
-        # beside them (device-side transports only): with them a copy kernel never
-        # waits for a 200-us block to retire, without them that launch is ~12 %
-        # shorter.  Which wins depends on how long the transfer occupies its units on
-        # the node at hand: both are timed on one chain execution each.
-        default_cus = int(getattr(exchanger, "reserved_cus", 0))
-        if default_cus > 0 and os.environ.get("SF_BENCH_RESERVED_CUS") is None:
-            timing = {}
-            for cus in (default_cus, 0):
-                exchanger.reserved_cus = cus
-                runner.execute()
-                runner.synchronize()
-                t0 = time.perf_counter()
-                runner.execute()
-                runner.synchronize()
-                (timing[cus], ) = agreed(time.perf_counter() - t0)
-            exchanger.reserved_cus = min(timing, key=timing.get)
-            transport += "; {} units reserved beside an exchange ({})".format(
-                exchanger.reserved_cus, ", ".join("{}: {:.2f} ms".format(k, v * 1e3) for k, v in timing.items()))
-        elif default_cus > 0:
-            exchanger.reserved_cus = int(os.environ["SF_BENCH_RESERVED_CUS"])
-        if self_loop:
-            transport += " -- SELF-LOOP TEST: rank 1 of 3, halos sent to the rank itself"
-        runner.upload([synthetic(runner.local_shape, rank)])
-
-        def step():
             runner.execute()
 
-        def sync():
+    def sync():
+        if native:
+            runner.plan.synchronize()
+        else:
             runner.synchronize()
-            if hasattr(exchanger, "check"):
-                exchanger.check()  # a halo wait that timed out must not pass for a result
-            dist.barrier()
-    else:
-        plan = Plan(sfir, device=local_rank, options=options)
-        scalar_values = [chain.inputs[k]["data"] for k in plan.scalar_names]
-        if scalar_values:
-            plan.set_scalars(scalar_values)
-        plan.upload([synthetic(shape, dtype=np_dtype)])
+        if hasattr(exchanger, "check"):
+            exchanger.check()  # a halo wait that timed out must not pass for a result
+        dist.barrier()
 
-        def step():
-            plan.execute(1)
-
-        def sync():
-            plan.synchronize()
-
-    # one untimed execution before the counted warm-up steps: the first pass
-    # loads the code objects, sizes the launch queues and (N > 1) moves the
-    # first full-size halos over every connection -- none of which belongs to a
-    # step even when the caller asks for --warmup 0.  The grid is uploaded again
-    # afterwards so the timed steps start from the same synthetic data.
+    # one untimed execution (first full-size halos over every connection), fresh data,
+    # the counted warm-up steps, then EXACTLY `steps` timed ones between barriers
     step()
     sync()
-    if multi:
-        runner.upload([synthetic(runner.local_shape, rank)])
-    else:
-        plan.upload([synthetic(shape, dtype=np_dtype)])
+    runner.upload([job.planes_of(runner.lo, runner.hi)])
     for _ in range(args.warmup):
         step()
     sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kernel_ms = 0.0
     for _ in range(args.steps):
         step()
-        if not multi:
-            # HIP events bracket the launches of this step on the plan's stream
-            plan.synchronize()
-            kernel_ms += plan.elapsed_ms()
     sync()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # control plane (gloo)
-        elapsed = float(t.item())
+    elapsed = job.agreed_max(time.perf_counter() - t0)[0]
+
+    # untimed: the check again, with the transport and schedule that were just timed
+    verified = False
+    try:
+        verified = best["check"].passes()
+    except Exception as exc:  # noqa: BLE001
+        job.notes.append("final check raised {}: {}".format(type(exc).__name__, exc))
+    verified = job.everywhere(verified)
 
     # (self-loop test: the one rank present updates its own slab only)
-    cells = float(np.prod(runner.local_shape if self_loop else shape)) * args.stages * args.steps
-    result = {
-        "metric": "Mcells/s (updates) and achieved HBM GB/s vs roofline, "
-                  "jacobi3d 512^3 f32" if args.workload == "c3" else
-                  "Mcells/s (updates) and achieved HBM GB/s vs roofline, " + args.workload,
-        "value": cells / elapsed / 1e6,
-        "unit": "Mcells/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": dtype_name,
-        "data": "synthetic (uniform random [0,1), seed %d)" % SEED,
-        "config": {
-            "workload": label,
-            "decomposition": ("slab{} (halo {} planes, one exchange per {} launches, {})".format(
-                slab_world, runner.halo, runner.halo // max(1, runner.steps[0][1]), transport)
-                if multi else "single"),
-            "ranks": ranks_connected if multi else 1,
-            "transport": rung_used if multi else "none (single GPU)",
-        },
-    }
-    if not multi:
-        stats = plan.kernel_stats()
-        launches = plan.num_launches * args.steps
-        name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"])
-        fused = args.stages / plan.num_launches  # operators evaluated per launch
-        avg_s = kernel_ms * 1e-3 / launches
-        # bytes a launch must move whatever it fuses: the field once in, once out
-        compulsory = float(np.prod(shape)) * bpu
-        alg = cells * bpu / launches  # SURVEY §8(d): 2 * sizeof(dtype) per cell update
-        traffic = measured_traffic(name)
-        moved = traffic if traffic is not None else compulsory
-        result["roofline"] = {
-            "bound": "hbm",
-            "kernel": name,
-            "achieved": moved / avg_s / 1e9,
-            "peak": HBM_PEAK / 1e9,
-            "unit": "GB/s",
-            "frac": moved / avg_s / HBM_PEAK,
-            "basis": "pmc" if traffic is not None else "compulsory",
-            "traffic": traffic,
-            "compulsory_bytes_per_launch": compulsory,
-            "avg_launch_us": avg_s * 1e6,
-            "launches": launches,
-            "fused_operators": fused,
-            "algorithmic_bytes_per_launch": alg,
-            "algorithmic_achieved": alg / avg_s / 1e9,
-            "algorithmic_frac": alg / avg_s / HBM_PEAK,
-        }
-        result["config"]["schedule"] = plan.describe().splitlines()[1].strip()
-        if not args.no_cpu_baseline and rank == 0 and args.workload == "c3":
-            result["cpu_baseline"] = cpu_baseline(shape, budget_s=args.cpu_seconds)
+    cells = float(np.prod(runner.local_shape if self_loop else wl["shape"])) * args.stages * args.steps
+    result["value"] = cells / elapsed / 1e6
+    result["ms_per_step"] = elapsed / args.steps * 1e3
+    fused = args.stages / max(1, len(runner.steps))
+    if rank == 0:
+        result["roofline"] = job.per_gpu_roofline(best, fused)
+        per_gpu = result["value"] / (1 if self_loop else world)
+        result["roofline"]["per_gpu_mcells_per_s"] = per_gpu
+        result["roofline"]["undivided_mcells_per_s"] = undivided
+        result["roofline"]["per_gpu_vs_undivided"] = (per_gpu / undivided) if undivided else None
+    else:
+        job.per_gpu_roofline(best, fused)  # (the profiled execution exchanges halos: every rank runs it)
+    transport = job.NAMES[best["rung"]] + " (" + "; ".join(job.notes) + ")"
+    if self_loop:
+        transport += " -- SELF-LOOP TEST: rank 1 of 3, halos sent to the rank itself"
+    result["config"].update(
+        decomposition="slab{} (halo {} planes, one exchange per {} launches, {})".format(
+            slab_world, runner.halo, runner.halo // max(1, runner.steps[0][1]), transport),
+        ranks=world, transport=best["rung"],
+        schedule="sf_plan_execute_decomposed (libsf_hip.so)" if native else "SlabRunner (Python form of the same schedule)",
+        verified=bool(verified),
+        check=("first {} operators, decomposed vs each rank's local recomputation of its slab from the global "
+               "synthetic input ({} ghost planes per side), bit for bit, before and after the timed region").format(
+                   job.check_ops, job.check_ops))
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if multi:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    # transports first, plans after a barrier: no rank frees buffers a neighbour has mapped
+    job.close_check(best["check"])
+    job.close_exchanger(exchanger)
+    dist.barrier()
+    runner.close()
+    dist.destroy_process_group()
+    if not verified:
+        raise SystemExit("bench.py: the decomposed run does NOT reproduce the local recomputation: " +
+                         "; ".join(job.notes))
 
 
 if __name__ == "__main__":

@@ -32,6 +32,26 @@ def build_parser():
     return p
 
 
+def visible_gpus():
+    """GPUs of this node WITHOUT touching the HIP runtime (the launching process must not
+    initialise a GPU: its ranks are started as fresh processes): the KFD topology lists
+    every node, GPUs are the ones with SIMDs; *_VISIBLE_DEVICES narrow the count."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        value = os.environ.get(var)
+        if value is not None:
+            return len([v for v in value.split(",") if v.strip() != ""])
+    count, nodes = 0, "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(nodes):
+            with open(os.path.join(nodes, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                count += 1
+    except (OSError, ValueError):
+        pass
+    return count
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = vars(build_parser().parse_args(argv))
@@ -40,8 +60,9 @@ def main(argv=None):
         # the launching process: no GPU is touched here, the ranks are fresh processes
         from stencilflow_amd.run_distributed_program import launch
         if gpus <= 0:
-            import torch
-            gpus = max(1, torch.cuda.device_count())  # (counting devices does not initialise them)
+            gpus = visible_gpus()
+            if gpus <= 0:
+                raise SystemExit("no GPU found in the KFD topology: pass -gpus N")
         return launch(argv, gpus)
     import stencilflow_amd
     from stencilflow_amd.run_distributed_program import run_distributed_program

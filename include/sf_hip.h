@@ -118,6 +118,15 @@ const char* sf_plan_kernel_source(const sf_plan* plan, int index);
 int sf_plan_kernel_stats(sf_plan* plan, int index, int* launches,
                          double* total_ms, double* updates_per_launch,
                          double* algorithmic_bytes_per_launch);
+/* Turn per-launch HIP-event profiling on / off after plan creation (same effect as the
+ * option "profile=1"): bench.py times one extra, untimed chain execution this way so that
+ * the timed region carries no events.  Synchronises the plan's stream first. */
+int sf_plan_set_profile(sf_plan* plan, int on);
+/* With profiling on: planes of the outermost dimension written by the launches of kernel
+ * `index` in the executions since the counters were last reset (sf_plan_execute,
+ * sf_plan_set_profile) -- a decomposed run launches over plane ranges of different
+ * lengths, so bytes per launch follow from this, not from the launch count. */
+int sf_plan_kernel_planes(sf_plan* plan, int index, double* planes);
 /* Register / LDS footprint of generated kernel `index`, read from the compiled
  * code object's metadata (-1 where the compiler did not report a field). */
 int sf_plan_kernel_resources(const sf_plan* plan, int index, int* vgprs,
@@ -203,17 +212,21 @@ int sf_flag_set(void* stream, unsigned int* flag, unsigned int value);
 int sf_flag_wait(void* stream, const unsigned int* flag, unsigned int value,
                  unsigned int timeout_ms, unsigned int* status);
 
-/* ---- peer-to-peer halo transport, owned by the library ------------------------
- * One rank's end of the neighbour exchange of a slab-decomposed run.  A rank
- * PUSHES the planes next to a slab boundary straight into its neighbour's ghost
- * planes -- device memory of the neighbour's plan, mapped through a HIP IPC handle
- * -- with DMA copies (no compute units; over xGMI between the GPUs of a node),
- * ordered by flag words in a page of host memory the ranks of the node share.
- * Nothing but this header is needed to drive a decomposed run from C: create a
- * plan per rank (option "slab=..."), sf_halo_export its slab buffers, hand the
- * blobs to the neighbouring ranks by whatever means the caller has (MPI, a file,
+/* ---- halo transport of a slab-decomposed run, owned by the library --------------
+ * One rank's end of the neighbour exchange.  Two rungs behind one handle:
+ *  - peer-to-peer pushes (default): a rank PUSHES the planes next to a slab boundary
+ *    straight into its neighbour's ghost planes -- device memory of the neighbour's plan,
+ *    mapped through a HIP IPC handle -- with DMA copies (no compute units; over xGMI
+ *    between the GPUs of a node), ordered by flag words in a page of host memory the
+ *    ranks of the node share;
+ *  - RCCL (sf_halo_use_rccl): grouped ncclSend / ncclRecv of the same planes on the
+ *    transport's stream (librccl is loaded on demand with dlopen).
+ * Nothing but this header is needed to drive a decomposed run from C: create a plan per
+ * rank (option "slab=..."), [sf_halo_use_rccl,] sf_halo_export its slab buffers, hand
+ * the blobs to the neighbouring ranks by whatever means the caller has (MPI, a file,
  * torch.distributed ...), sf_halo_connect, then alternate sf_halo_start /
- * sf_plan_execute_step_ranges / sf_halo_finish.
+ * sf_plan_execute_step_ranges / sf_halo_finish -- or let sf_plan_execute_decomposed run
+ * the whole schedule.
  * (Role in the reference: the SMI remote streams between devices,
  * stencilflow/sdfg_generator.py:848-891, and the MPI rank bookkeeping of
  * bin/run_distributed_program.py:98-100,283-299.) */
@@ -243,9 +256,30 @@ int sf_halo_connect(sf_halo* halo, int key, const void* lower_blob,
 int sf_halo_start(sf_halo* halo, int key, int depth, void* compute_stream);
 /* Make `compute_stream` wait until the exchange started last on `key` is done. */
 int sf_halo_finish(sf_halo* halo, int key, void* compute_stream);
-/* Fails (SF_ERR_DEVICE) if a wait of this rank has timed out; call after
+/* Fails (SF_ERR_DEVICE) if a wait of this rank -- or a neighbour's wait for this rank --
+ * has timed out (peer-to-peer), or if RCCL reports an asynchronous error; call after
  * synchronising. */
 int sf_halo_check(sf_halo* halo);
+/* The RCCL rung.  One rank (any) obtains an id -- SF_HALO_RCCL_ID_BYTES bytes, an
+ * ncclUniqueId -- and hands it to every rank of the run; every rank then calls
+ * sf_halo_use_rccl BEFORE its first sf_halo_export (collective: ncclCommInitRank over
+ * comm_size ranks).  comm_size is the transport's world and comm_rank its rank; for tests
+ * on a one-GPU machine comm_size may be 1 with comm_rank 0: the rank then is its own lower
+ * and upper neighbour and every halo it sends comes back to it.  Export / connect are
+ * called as for the peer-to-peer rung (the blobs then carry geometry only).
+ * SF_ERR_UNSUPPORTED when librccl cannot be loaded ($SF_RCCL_LIBRARY names it). */
+#define SF_HALO_RCCL_ID_BYTES 128
+int sf_halo_rccl_id(void* id_out);
+int sf_halo_use_rccl(sf_halo* halo, const void* id, int comm_rank, int comm_size);
+/* "p2p" or "rccl". */
+const char* sf_halo_transport(const sf_halo* halo);
+/* Refinements of sf_plan_execute_decomposed (both 0 by default): `reserved_cus` compute
+ * units the launch beside a transfer leaves free (for the copy kernels of the RCCL rung:
+ * the star kernels' blocks hold their unit for ~200 us); `early_exchange` != 0 starts an
+ * exchange one launch ahead -- the launch before the one that needs fresh halos computes
+ * its planes next to the slab boundaries first -- so that a transfer slower than one
+ * interior launch has two launches of cover. */
+int sf_halo_configure(sf_halo* halo, int reserved_cus, int early_exchange);
 /* One rank's execution of the whole chain, `repetitions` times, with the deep-halo
  * schedule: the plan was created with "slab=lo:hi:H" and every slab
  * buffer registered with `halo` under its buffer id.  After an exchange of H planes a

@@ -65,6 +65,8 @@ API = [
     ("sf_plan_kernel_name", _S, [_P, _I]),
     ("sf_plan_kernel_source", _S, [_P, _I]),
     ("sf_plan_kernel_stats", _I, [_P, _I, _IP, _DP, _DP, _DP]),
+    ("sf_plan_set_profile", _I, [_P, _I]),
+    ("sf_plan_kernel_planes", _I, [_P, _I, _DP]),
     ("sf_plan_kernel_resources", _I, [_P, _I, _IP, _IP, _IP, _IP, _IP]),
     ("sf_plan_debug_counters", _I, [_P, ctypes.POINTER(ctypes.c_ulonglong), _I]),
     ("sf_plan_describe", _S, [_P]),
@@ -93,9 +95,14 @@ API = [
     ("sf_halo_start", _I, [_P, _I, _I, _P]),
     ("sf_halo_finish", _I, [_P, _I, _P]),
     ("sf_halo_check", _I, [_P]),
+    ("sf_halo_rccl_id", _I, [_P]),
+    ("sf_halo_use_rccl", _I, [_P, _P, _I, _I]),
+    ("sf_halo_transport", _S, [_P]),
+    ("sf_halo_configure", _I, [_P, _I, _I]),
     ("sf_plan_execute_decomposed", _I, [_P, _P, _I]),
 ]
 HALO_BLOB_BYTES = 256
+HALO_RCCL_ID_BYTES = 128
 
 
 def library_path():
@@ -231,6 +238,19 @@ class Plan:
                              total_ms=ms.value,
                              updates_per_launch=upd.value,
                              algorithmic_bytes_per_launch=byt.value)
+        return out
+
+    def set_profile(self, on=True):
+        """Per-launch HIP events on / off (resets the per-kernel counters)."""
+        _check(self._lib.sf_plan_set_profile(self._h, 1 if on else 0))
+
+    def kernel_planes(self):
+        """name -> planes written by the profiled launches of that kernel."""
+        out = {}
+        for i, name in enumerate(self.kernel_names()):
+            v = ctypes.c_double()
+            _check(self._lib.sf_plan_kernel_planes(self._h, i, ctypes.byref(v)))
+            out[name] = v.value
         return out
 
     def kernel_resources(self):

@@ -9,7 +9,7 @@ using namespace sf;
 
 extern "C" {
 
-int sf_version(void) { return 1001; }  // 1.1: sf_halo_*, sf_plan_execute_decomposed, sf_plan_stream, sf_plan_num_buffers, sf_code_cache_stats
+int sf_version(void) { return 1002; }  // 1.1: sf_halo_*, sf_plan_execute_decomposed, sf_plan_stream, sf_plan_num_buffers, sf_code_cache_stats; 1.2: the RCCL rung (sf_halo_rccl_id / _use_rccl / _transport / _configure)
 
 const char* sf_last_error(void) { return sf::g_last_error.c_str(); }
 
@@ -182,6 +182,28 @@ int sf_plan_kernel_stats(sf_plan* p, int i, int* launches, double* total_ms, dou
   if (total_ms) *total_ms = k.total_ms;
   if (updates) *updates = k.updates_per_launch;
   if (alg_bytes) *alg_bytes = k.alg_bytes_per_launch;
+  return SF_OK;
+}
+int sf_plan_set_profile(sf_plan* plan, int on) {
+  SF_API_BEGIN
+  if (!plan) throw Error(SF_ERR_INVALID, "null plan");
+  if (plan->device_ready) {
+    SF_HIP_CHECK(hipSetDevice(plan->device));
+    SF_HIP_CHECK(hipStreamSynchronize(plan->stream));
+    collect_profile(*plan);
+  }
+  for (auto& k : plan->kernels) {
+    k.launches = 0;
+    k.total_ms = 0;
+    k.planes_launched = 0;
+  }
+  plan->profile = on != 0;
+  return SF_OK;
+  SF_API_END
+}
+int sf_plan_kernel_planes(sf_plan* p, int i, double* planes) {
+  if (!p || !planes || i < 0 || i >= (int)p->kernels.size()) return SF_ERR_INVALID;
+  *planes = p->kernels[i].planes_launched;
   return SF_OK;
 }
 int sf_plan_kernel_resources(const sf_plan* p, int i, int* vgprs, int* agprs, int* spills, int* scratch,

@@ -184,6 +184,7 @@ void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, int i_be
     SF_HIP_CHECK(hipEventRecord(e1, stream));
     pl.prof_events.push_back({e0, e1});
     pl.prof_kernel.push_back(st.ck);
+    pl.prof_planes.push_back(std::max(0, i_end - i_begin) + (second ? i_end2 - i_begin2 : 0));
   }
 }
 
@@ -193,11 +194,13 @@ void collect_profile(sf_plan& pl) {
     (void)hipEventElapsedTime(&ms, pl.prof_events[i].first, pl.prof_events[i].second);
     pl.kernels[pl.prof_kernel[i]].launches += 1;
     pl.kernels[pl.prof_kernel[i]].total_ms += ms;
+    pl.kernels[pl.prof_kernel[i]].planes_launched += pl.prof_planes[i];
     (void)hipEventDestroy(pl.prof_events[i].first);
     (void)hipEventDestroy(pl.prof_events[i].second);
   }
   pl.prof_events.clear();
   pl.prof_kernel.clear();
+  pl.prof_planes.clear();
 }
 
 void upload(sf_plan& pl, const void* const* host_inputs) {
@@ -316,6 +319,7 @@ void execute(sf_plan& pl, int repetitions) {
   for (auto& k : pl.kernels) {
     k.launches = 0;
     k.total_ms = 0;
+    k.planes_launched = 0;
   }
   // Launch-bound chains (many launches of a few microseconds each: small grids)
   // are replayed as one hipGraph, which removes the per-launch host cost; big

@@ -59,6 +59,7 @@ struct CompiledKernel {
   hipFunction_t fn = nullptr;
   int launches = 0;
   double total_ms = 0;
+  double planes_launched = 0;  // planes written by the profiled launches
   double updates_per_launch = 0, alg_bytes_per_launch = 0;
   // from the code object's amdhsa metadata (msgpack note)
   int vgprs = -1, agprs = -1, sgprs = -1, spills = -1, scratch = -1, lds = -1, sgpr_spills = -1;
@@ -129,6 +130,7 @@ struct sf_plan {
   // per-launch profiling events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<int> prof_kernel;
+  std::vector<int> prof_planes;
 };
 
 namespace sf {

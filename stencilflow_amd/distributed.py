@@ -392,65 +392,150 @@ class ShmExchanger:
         self._boxes = {}
 
 
-class PeerExchanger:
-    """Peer-to-peer transport owned by the library (``sf_halo_*`` of the C ABI): a
-    rank pushes its boundary planes straight into the neighbour's ghost planes --
-    the neighbour's device buffer, mapped through a HIP IPC handle -- with DMA
-    copies over xGMI, ordered by flag words in host memory the ranks share.  No
-    compute units, no torch on the data path: the interior launch beside an
-    exchange keeps the whole chip.  Python only hands the buffer descriptions
-    ("blobs") from rank to rank once, at ``attach``.
+class _DistControl:
+    """Control plane of a transport's set-up: one all-gather of small Python objects
+    over the default ``torch.distributed`` group (gloo)."""
 
-    ``exchange_blobs(list_of_bytes) -> (lower_list, upper_list)`` moves the blobs to
-    the neighbours; the default uses the default ``torch.distributed`` group
-    (gloo control plane).
+    def all_gather(self, obj):
+        import torch.distributed as dist
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, obj)
+        return out
+
+
+class PeerExchanger:
+    """Halo transport owned by the library (``sf_halo_*`` of the C ABI), two rungs:
+
+    ``transport="p2p"`` -- a rank pushes its boundary planes straight into the
+    neighbour's ghost planes (the neighbour's device buffer, mapped through a HIP IPC
+    handle) with DMA copies over xGMI, ordered by flag words in host memory the ranks
+    share.  No compute units: the interior launch beside an exchange keeps the chip.
+
+    ``transport="rccl"`` -- grouped ``ncclSend`` / ``ncclRecv`` issued by the library
+    itself on its own stream (librccl through ``dlopen``; no torch on the data path).
+    ``self_loop=True`` (one-GPU tests): a communicator of this rank alone, every halo
+    comes back to the sender.
+
+    Python only moves a few small objects from rank to rank while the transport is set
+    up (``control.all_gather(obj) -> list`` over all ranks; default: the default
+    ``torch.distributed`` group).  Every set-up step is collective-safe: a rank whose
+    local part failed still takes part in the exchange and ALL ranks raise afterwards,
+    so that no rank is left waiting in a collective.
     """
 
-    reserved_cus = 0  # copies run on the DMA engines
+    RCCL_RESERVED_CUS = 32
 
-    def __init__(self, rank, world, session, device=0, timeout_ms=20000, exchange_blobs=None):
+    def __init__(self, rank, world, session, device=0, timeout_ms=20000, control=None,
+                 transport="p2p", self_loop=False):
         import ctypes
-        from .backend import HALO_BLOB_BYTES, load_library
+        from .backend import HALO_BLOB_BYTES, HALO_RCCL_ID_BYTES, load_library
+        if transport not in ("p2p", "rccl"):
+            raise ValueError("transport must be 'p2p' or 'rccl'")
+        if self_loop and transport != "rccl":
+            raise ValueError("only the RCCL rung has a self-loop mode")
         self.rank, self.world, self.device = rank, world, device
+        self.transport, self.self_loop = transport, bool(self_loop)
         self._ct, self._lib = ctypes, load_library()
         self._blob_bytes = HALO_BLOB_BYTES
-        self._exchange_blobs = exchange_blobs or self._exchange_blobs_dist
+        self._control = control or (None if self.self_loop else _DistControl())
         self._geometry = {}  # key -> (plane_bytes, n_local, halo)
         self._h = ctypes.c_void_p()
-        self._check(self._lib.sf_halo_create(rank, world, str(session).encode(), device, int(timeout_ms),
-                                             ctypes.byref(self._h)))
+        # compute units the launch beside an exchange leaves to RCCL's copy kernels
+        self.reserved_cus = self.RCCL_RESERVED_CUS if transport == "rccl" else 0
+        self.early_exchange = False
+        error = None
+        try:
+            self._check(self._lib.sf_halo_create(rank, world, str(session).encode(), device, int(timeout_ms),
+                                                 ctypes.byref(self._h)))
+        except Exception as exc:  # noqa: BLE001 -- reported after the ranks have agreed
+            error = exc
+        if transport == "rccl":
+            rccl_id = None
+            if error is None and (self.self_loop or rank == 0):
+                buf = ctypes.create_string_buffer(HALO_RCCL_ID_BYTES)
+                try:
+                    self._check(self._lib.sf_halo_rccl_id(buf))
+                    rccl_id = buf.raw
+                except Exception as exc:  # noqa: BLE001
+                    error = exc
+            if not self.self_loop:
+                answers = self._control.all_gather((error is None, rccl_id))
+                rccl_id = answers[0][1]
+                self._raise_if_any_failed([ok for ok, _ in answers], error, "create")
+            elif error is not None:
+                self._fail(error)
+            try:
+                self._check(self._lib.sf_halo_use_rccl(self._h, rccl_id, 0 if self.self_loop else rank,
+                                                       1 if self.self_loop else world))
+            except Exception as exc:  # noqa: BLE001
+                error = exc
+            if not self.self_loop:
+                self._raise_if_any_failed(self._control.all_gather(error is None), error, "ncclCommInitRank")
+            elif error is not None:
+                self._fail(error)
+        elif world > 1:
+            self._raise_if_any_failed(self._control.all_gather(error is None), error, "create")
+        elif error is not None:
+            self._fail(error)
+
+    def _fail(self, error):
+        self.close()
+        raise error
+
+    def _raise_if_any_failed(self, oks, error, what):
+        if all(oks):
+            return
+        self.close()
+        if error is not None:
+            raise error
+        raise RuntimeError("halo transport ({}): {} failed on rank(s) {}".format(
+            self.transport, what, [r for r, ok in enumerate(oks) if not ok]))
 
     def _check(self, status):
         if status != 0:
-            raise RuntimeError("peer-to-peer halo transport: " + (self._lib.sf_last_error() or b"").decode())
-
-    def _exchange_blobs_dist(self, blobs):
-        import torch.distributed as dist
-        gathered = [None] * self.world
-        dist.all_gather_object(gathered, (self.rank, blobs))
-        by_rank = dict(gathered)
-        return by_rank.get(self.rank - 1), by_rank.get(self.rank + 1)
+            raise RuntimeError("halo transport ({}): ".format(self.transport) + (self._lib.sf_last_error() or b"").decode())
 
     def attach(self, plan, n_local, halo):
         """Register every slab buffer of ``plan`` and map the neighbours' (collective)."""
         ct = self._ct
-        keys, blobs = [], []
-        for buf in range(plan.num_buffers):
-            ptr, plane_bytes, planes = plan.buffer_info(buf)
-            if planes <= 1 or buf in self._geometry:
-                continue
-            blob = ct.create_string_buffer(self._blob_bytes)
-            self._check(self._lib.sf_halo_export(self._h, buf, ct.c_void_p(ptr), plane_bytes, n_local, halo, blob))
-            self._geometry[buf] = (plane_bytes, n_local, halo)
-            keys.append(buf)
-            blobs.append(blob.raw)
-        if self.world == 1 or not keys:
+        keys, blobs, error = [], [], None
+        try:
+            for buf in range(plan.num_buffers):
+                ptr, plane_bytes, planes = plan.buffer_info(buf)
+                if planes <= 1 or buf in self._geometry:
+                    continue
+                blob = ct.create_string_buffer(self._blob_bytes)
+                self._check(self._lib.sf_halo_export(self._h, buf, ct.c_void_p(ptr), plane_bytes, n_local, halo, blob))
+                self._geometry[buf] = (plane_bytes, n_local, halo)
+                keys.append(buf)
+                blobs.append(blob.raw)
+        except Exception as exc:  # noqa: BLE001 -- the blob exchange below is collective
+            error = exc
+        if self.world == 1 or self.self_loop:
+            if error is not None:
+                raise error
             return
-        lower, upper = self._exchange_blobs(blobs)
-        for i, buf in enumerate(keys):
-            lo = ct.create_string_buffer(lower[i], self._blob_bytes) if lower else None
-            hi = ct.create_string_buffer(upper[i], self._blob_bytes) if upper else None
-            self._check(self._lib.sf_halo_connect(self._h, buf, lo, hi))
+        gathered = self._control.all_gather((self.rank, None if error is not None else blobs))
+        by_rank = dict(gathered)
+        self._raise_if_any_failed([by_rank.get(r) is not None for r in range(self.world)], error, "export")
+        lower, upper = by_rank.get(self.rank - 1), by_rank.get(self.rank + 1)
+        try:
+            for i, buf in enumerate(keys):
+                lo = ct.create_string_buffer(lower[i], self._blob_bytes) if lower else None
+                hi = ct.create_string_buffer(upper[i], self._blob_bytes) if upper else None
+                self._check(self._lib.sf_halo_connect(self._h, buf, lo, hi))
+        except Exception as exc:  # noqa: BLE001
+            error = exc
+        self._raise_if_any_failed(self._control.all_gather(error is None), error, "connect")
+
+    def configure(self, reserved_cus=None, early_exchange=None):
+        """The refinements ``sf_plan_execute_decomposed`` applies (``SlabRunner`` reads the
+        same two attributes for its Python form of the schedule)."""
+        if reserved_cus is not None:
+            self.reserved_cus = int(reserved_cus)
+        if early_exchange is not None:
+            self.early_exchange = bool(early_exchange)
+        self._check(self._lib.sf_halo_configure(self._h, self.reserved_cus, 1 if self.early_exchange else 0))
 
     def handshake(self, device=None):
         """Done on the real buffers by ``SlabRunner`` (``verify``): nothing to prove
@@ -463,17 +548,31 @@ class PeerExchanger:
         if self.world == 1:
             return
         view = tensor.view(n_local + 2 * halo, plane_bytes)
-        view[halo:halo + n_local] = self.rank + 1
-        self.finish(self.start(tensor, halo_regions(n_local, halo, halo, plane_bytes), key=key))
-        torch.cuda.current_stream(self.device).synchronize()
-        self.check()
-        lo, hi = int(view[0, 0]), int(view[-1, -1])
+        error = None
+        try:
+            view[halo:halo + n_local] = self.rank + 1
+            self.finish(self.start(tensor, halo_regions(n_local, halo, halo, plane_bytes), key=key))
+            torch.cuda.current_stream(self.device).synchronize()
+            self.check()
+            lo, hi = int(view[0, 0]), int(view[-1, -1])
+            if self.self_loop:  # send_down comes back as recv_down, send_up as recv_up
+                want_lo = want_hi = self.rank + 1
+            else:
+                want_lo = self.rank if self.rank > 0 else 0
+                want_hi = self.rank + 2 if self.rank < self.world - 1 else 0
+            if lo != want_lo:
+                raise RuntimeError("halo transport ({}): wrong data from the lower neighbour".format(self.transport))
+            if hi != want_hi:
+                raise RuntimeError("halo transport ({}): wrong data from the upper neighbour".format(self.transport))
+        except Exception as exc:  # noqa: BLE001 -- the agreement below is collective
+            error = exc
         view.zero_()
         torch.cuda.current_stream(self.device).synchronize()
-        if lo != (self.rank if self.rank > 0 else 0):
-            raise RuntimeError("peer-to-peer halo transport: wrong data from the lower neighbour")
-        if hi != (self.rank + 2 if self.rank < self.world - 1 else 0):
-            raise RuntimeError("peer-to-peer halo transport: wrong data from the upper neighbour")
+        if self.self_loop:
+            if error is not None:
+                raise error
+            return
+        self._raise_if_any_failed(self._control.all_gather(error is None), error, "verification")
 
     def start(self, tensor, regions, key=None):
         import torch
@@ -499,6 +598,94 @@ class PeerExchanger:
         if self._h:
             self._lib.sf_halo_destroy(self._h)
             self._h = self._ct.c_void_p()
+
+
+class GhostFill:
+    """Exchanger stand-in of a rank that KNOWS its neighbours' planes (synthetic input
+    every rank can generate): ``start`` copies the ``depth`` planes next to each slab
+    boundary from host arrays into the ghost planes.  With a halo as deep as the whole
+    chain reaches this turns ``SlabRunner`` into a purely local recomputation of the
+    rank's slab from the global input -- the reference side of ``DecompositionCheck``."""
+
+    reserved_cus = 0
+
+    def __init__(self, lower_planes, upper_planes, device=0):
+        self.lower, self.upper, self.device = lower_planes, upper_planes, device
+
+    def start(self, tensor, regions, key=None):
+        import torch
+        for name, planes in (("recv_down", self.lower), ("recv_up", self.upper)):
+            if planes is None:
+                continue
+            off, size = regions[name]
+            flat = torch.from_numpy(np.ascontiguousarray(planes).reshape(-1).view(np.uint8))
+            if flat.numel() < size:
+                raise ValueError("GhostFill: {} planes known, {} bytes asked for".format(len(planes), size))
+            part = flat[-size:] if name == "recv_down" else flat[:size]
+            tensor[off:off + size].copy_(part.to(tensor.device, non_blocking=False))
+        return None
+
+    def finish(self, handle):
+        pass
+
+
+class DecompositionCheck:
+    """Untimed correctness check of a decomposed run across real devices (VERDICT r02,
+    next 1b; the role of the comparison on one rank in the reference's launcher,
+    bin/run_distributed_program.py:304-341).
+
+    The first ``K`` operators of the chain are run twice on this rank's slab of the
+    global synthetic input: (a) decomposed -- by the runner under test, halos travelling
+    over the transport under test, with the schedule under test; (b) locally -- the slab
+    plus ``K`` ghost planes per side taken from the global input, no communication (the
+    dependency cone of the slab).  The owned planes of both results are compared on the
+    device, bit for bit.  This is what catches stale ghost planes (a receiver reading
+    what it cached before the neighbour's transfer landed), which tests with all ranks
+    on one device cannot show.
+
+    ``planes_of(lo, hi)`` returns planes ``[lo, hi)`` of the global input (host array).
+    ``make_runner(sfir_text)`` builds the decomposed runner (with its own exchanger,
+    attached); ``run(runner)`` executes one chain on it and synchronises.
+    """
+
+    def __init__(self, sfir_text, global_shape, rank, world, planes_of, make_runner, run,
+                 device=0, options=None, dtype=np.float32):
+        import torch
+        self.torch = torch
+        self.rank, self.world, self.device = rank, world, device
+        self.shape = tuple(global_shape)
+        self.planes_of, self.run, self.dtype = planes_of, run, dtype
+        self.runner = make_runner(sfir_text)
+        if not self.runner.is_chain:
+            raise ValueError("DecompositionCheck handles chains")
+        reach = sum(d for _, d in self.runner.steps)
+        lo, hi = self.runner.lo, self.runner.hi
+        lower = planes_of(max(0, lo - reach), lo) if lo > 0 else None
+        upper = planes_of(hi, min(self.shape[0], hi + reach)) if hi < self.shape[0] else None
+        self.reference = SlabRunner(sfir_text, self.shape, rank, world, device=device, options=options,
+                                    exchanger=GhostFill(lower, upper, device), halo=max(1, reach))
+        self.own = np.ascontiguousarray(planes_of(lo, hi))
+
+    def _owned(self, runner):
+        buf = runner.plan.output_buffer(0)
+        tensor, plane_bytes, _ = runner._buffer_tensor(buf)
+        return tensor[runner.halo * plane_bytes:(runner.halo + runner.n_local) * plane_bytes]
+
+    def passes(self):
+        """True if this rank's decomposed result equals its local recomputation."""
+        self.runner.upload([self.own])
+        self.run(self.runner)
+        self.reference.upload([self.own])
+        self.reference.execute()
+        self.reference.synchronize()
+        self.torch.cuda.synchronize(self.device)
+        return bool(self.torch.equal(self._owned(self.runner), self._owned(self.reference)))
+
+    def close(self):
+        for r in (self.runner, self.reference):
+            if r is not None:
+                r.close()
+        self.runner = self.reference = None
 
 
 class LocalExchanger:
@@ -807,12 +994,14 @@ class SlabRunner:
 
     def execute_native(self, repetitions=1):
         """The same schedule run by the library itself (``sf_plan_execute_decomposed``;
-        peer-to-peer transport only), asynchronous on the plan's own stream --
-        ``plan.synchronize()`` waits for it."""
-        import ctypes
+        the library's own transports: ``PeerExchanger``, either rung), asynchronous on
+        the plan's own stream -- ``plan.synchronize()`` waits for it.  The refinements
+        follow this runner's settings (``early_exchange``, the exchanger's
+        ``reserved_cus``)."""
         from .backend import _check
         if not hasattr(self.exchanger, "_h"):
             raise RuntimeError("the native schedule needs the library's own transport (PeerExchanger)")
+        self.exchanger.configure(early_exchange=self.early_exchange)
         _check(self.plan._lib.sf_plan_execute_decomposed(self.plan._h, self.exchanger._h, int(repetitions)))
 
     def execute(self):

@@ -83,7 +83,8 @@ def run_distributed_program(stencil_file, mode="hardware", compare_to_reference=
 
         session = [None]
         if rank == 0:
-            session[0] = "rdp{}".format(os.getpid())
+            # (a token of this run: a page left in /dev/shm by a run that died cannot collide)
+            session[0] = "rdp{}_{:06x}".format(os.getpid(), int.from_bytes(os.urandom(3), "little"))
         dist.broadcast_object_list(session, src=0)
 
         def everywhere(ok):
@@ -91,15 +92,17 @@ def run_distributed_program(stencil_file, mode="hardware", compare_to_reference=
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return int(t.item()) == 1
 
-        # the first transport that proves itself on every rank: peer-to-peer pushes
-        # (verified when the runner attaches it), shared host memory, gloo
+        # the first transport that proves itself on every rank: the library's RCCL rung
+        # and its peer-to-peer pushes (both verified when the runner attaches them; their
+        # set-up is collective-safe: a rank whose local part fails still takes part and
+        # all ranks raise), shared host memory, gloo
         opts = dict(kv.split("=") for kv in options.split(";") if kv) if isinstance(options, str) else dict(options or {})
         runner, used = None, None
-        for label in ("p2p", "shm", "gloo"):
+        for label in ("rccl", "p2p", "shm", "gloo"):
             exchanger, ok = None, True
             try:
-                if label == "p2p":
-                    exchanger = PeerExchanger(rank, world, session[0] + label, device=device)
+                if label in ("rccl", "p2p"):
+                    exchanger = PeerExchanger(rank, world, session[0] + label, device=device, transport=label)
                 elif label == "shm":
                     exchanger = ShmExchanger(rank, world, session[0] + label, device=device)
                     exchanger.handshake()
@@ -113,11 +116,13 @@ def run_distributed_program(stencil_file, mode="hardware", compare_to_reference=
             if everywhere(ok):
                 used = label
                 break
+            # transports first, plans after a barrier: no rank frees buffers a neighbour has mapped
+            if exchanger is not None and hasattr(exchanger, "close"):
+                exchanger.close()
+            dist.barrier()
             if runner is not None:
                 runner.close()
                 runner = None
-            if exchanger is not None and hasattr(exchanger, "close"):
-                exchanger.close()
         if runner is None:
             raise RuntimeError("no halo transport works on this node")
         log("Running {} on {} slab(s) of {} planes, halos over {}...".format(name, world, runner.n_local, used))
@@ -146,10 +151,10 @@ def run_distributed_program(stencil_file, mode="hardware", compare_to_reference=
         os.makedirs(parts, exist_ok=True)
         for out_name, part in zip(runner.plan.output_names, outputs_local):
             part.tofile(os.path.join(parts, "{}.{}".format(out_name, rank)))
-        dist.barrier()
-        runner.close()
         if hasattr(runner.exchanger, "close"):
             runner.exchanger.close()
+        dist.barrier()
+        runner.close()
         if rank != 0:
             return None
 

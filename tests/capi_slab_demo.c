@@ -13,9 +13,14 @@
  * (a one-GPU test box); on a node with N GPUs pass the rank as the device.
  *
  *   cc -I include tests/capi_slab_demo.c -L stencilflow_amd/csrc -lsf_hip -o demo
- *   ./demo <sfir file> <input.dat> <out prefix> <world> <n0> <plane_bytes> <halo> [deep]
- * With "deep" the per-launch loop below is replaced by ONE call of the library's
- * own deep-halo schedule, sf_plan_execute_decomposed (halo = several launches' reach).
+ *   ./demo <sfir file> <input.dat> <out prefix> <world> <n0> <plane_bytes> <halo> [mode]
+ * mode "deep": the per-launch loop below is replaced by ONE call of the library's own
+ * deep-halo schedule, sf_plan_execute_decomposed (halo = several launches' reach).
+ * mode "rccl" / "rccl-deep": the same two forms over the library's RCCL rung
+ * (sf_halo_rccl_id on rank 0, the id relayed rank to rank over the sockets,
+ * sf_halo_use_rccl on every rank: grouped ncclSend / ncclRecv instead of DMA pushes) --
+ * one GPU per rank (device = rank).  mode "rccl-self" (a one-GPU box): only rank 1 of
+ * <world> runs, on a communicator of its own -- every halo it sends comes back to it.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -64,16 +69,38 @@ static int trade(int fd, const char* mine, char* theirs) {
   return 0;
 }
 
+/* a fixed number of bytes to / from a neighbour */
+static int send_all(int fd, const char* p, size_t n) { return write(fd, p, n) == (ssize_t)n ? 0 : -1; }
+static int recv_all(int fd, char* p, size_t n) {
+  size_t got = 0;
+  while (got < n) {
+    ssize_t k = read(fd, p + got, n - got);
+    if (k <= 0) return -1;
+    got += (size_t)k;
+  }
+  return 0;
+}
+
 static int run_rank(int rank, int world, int down_fd, int up_fd, const char* sfir, const char* input,
                     size_t input_bytes, const char* out_prefix, int n0, size_t plane_bytes, int halo,
-                    const char* session, int deep) {
+                    const char* session, int deep, int rccl /* 0 no, 1 one GPU per rank, 2 self-loop */) {
   const int lo = (int)((long long)n0 * rank / world), hi = (int)((long long)n0 * (rank + 1) / world);
   char opt[96]; /* (fourth field: the extent every rank plans with -- the thinnest slab) */
   snprintf(opt, sizeof opt, "slab=%d:%d:%d:%d", lo, hi, halo, n0 / world);
+  const int device = rccl == 1 ? rank : 0; /* RCCL wants a GPU per rank; the other modes share device 0 */
   sf_plan* plan = NULL;
-  CHECK(sf_plan_create(sfir, 0, opt, &plan));
+  CHECK(sf_plan_create(sfir, device, opt, &plan));
   sf_halo* link = NULL;
-  CHECK(sf_halo_create(rank, world, session, 0, 20000, &link));
+  CHECK(sf_halo_create(rank, world, session, device, 20000, &link));
+  if (rccl) {
+    char id[SF_HALO_RCCL_ID_BYTES];
+    if (rccl == 2 || rank == 0) CHECK(sf_halo_rccl_id(id));
+    if (rccl == 1) { /* the id travels up the chain of ranks */
+      if (rank > 0 && recv_all(down_fd, id, sizeof id) != 0) return 3;
+      if (rank < world - 1 && send_all(up_fd, id, sizeof id) != 0) return 3;
+    }
+    CHECK(sf_halo_use_rccl(link, id, rccl == 2 ? 0 : rank, rccl == 2 ? 1 : world));
+  }
   for (int b = 0; b < sf_plan_num_buffers(plan); ++b) {
     void* base;
     size_t pb;
@@ -82,9 +109,11 @@ static int run_rank(int rank, int world, int down_fd, int up_fd, const char* sfi
     if (planes == 1) continue; /* not split into slabs */
     char mine[SF_HALO_BLOB_BYTES], lower[SF_HALO_BLOB_BYTES], upper[SF_HALO_BLOB_BYTES];
     CHECK(sf_halo_export(link, b, base, pb, hi - lo, halo, mine));
-    if (rank > 0 && trade(down_fd, mine, lower) != 0) return 3;
-    if (rank < world - 1 && trade(up_fd, mine, upper) != 0) return 3;
-    CHECK(sf_halo_connect(link, b, rank > 0 ? lower : NULL, rank < world - 1 ? upper : NULL));
+    if (rccl != 2) {
+      if (rank > 0 && trade(down_fd, mine, lower) != 0) return 3;
+      if (rank < world - 1 && trade(up_fd, mine, upper) != 0) return 3;
+    }
+    CHECK(sf_halo_connect(link, b, rank > 0 && rccl != 2 ? lower : NULL, rank < world - 1 && rccl != 2 ? upper : NULL));
   }
   if (input_bytes != (size_t)n0 * plane_bytes) {
     fprintf(stderr, "input file has %zu bytes, expected %zu\n", input_bytes, (size_t)n0 * plane_bytes);
@@ -119,8 +148,9 @@ static int run_rank(int rank, int world, int down_fd, int up_fd, const char* sfi
   free(out);
   /* the neighbours may still be reading this rank's flag page: leave together */
   char token = 1, other;
-  if (rank > 0 && (write(down_fd, &token, 1) != 1 || read(down_fd, &other, 1) != 1)) return 6;
-  if (rank < world - 1 && (write(up_fd, &token, 1) != 1 || read(up_fd, &other, 1) != 1)) return 6;
+  if (rccl == 2) down_fd = up_fd = -1;
+  if (down_fd >= 0 && rank > 0 && (write(down_fd, &token, 1) != 1 || read(down_fd, &other, 1) != 1)) return 6;
+  if (up_fd >= 0 && rank < world - 1 && (write(up_fd, &token, 1) != 1 || read(up_fd, &other, 1) != 1)) return 6;
   CHECK(sf_halo_destroy(link));
   CHECK(sf_plan_destroy(plan));
   return 0;
@@ -128,10 +158,13 @@ static int run_rank(int rank, int world, int down_fd, int up_fd, const char* sfi
 
 int main(int argc, char** argv) {
   if (argc != 8 && argc != 9) {
-    fprintf(stderr, "usage: %s <sfir> <input.dat> <out prefix> <world> <n0> <plane_bytes> <halo> [deep]\n", argv[0]);
+    fprintf(stderr, "usage: %s <sfir> <input.dat> <out prefix> <world> <n0> <plane_bytes> <halo> "
+                    "[deep|rccl|rccl-deep|rccl-self]\n", argv[0]);
     return 1;
   }
-  const int deep = argc == 9 && strcmp(argv[8], "deep") == 0;
+  const char* mode = argc == 9 ? argv[8] : "";
+  const int deep = strcmp(mode, "deep") == 0 || strcmp(mode, "rccl-deep") == 0;
+  const int rccl = strcmp(mode, "rccl-self") == 0 ? 2 : strncmp(mode, "rccl", 4) == 0 ? 1 : 0;
   const int world = atoi(argv[4]), n0 = atoi(argv[5]), halo = atoi(argv[7]);
   const size_t plane_bytes = (size_t)atoll(argv[6]);
   size_t input_bytes = 0;
@@ -148,16 +181,21 @@ int main(int argc, char** argv) {
   char session[64];
   snprintf(session, sizeof session, "capi%d", (int)getpid());
   pid_t pids[8];
-  for (int r = 0; r < world; ++r) {
+  const int first = rccl == 2 ? 1 : 0, last = rccl == 2 ? 2 : world; /* self-loop: rank 1 alone */
+  if (rccl == 2 && world < 3) {
+    fprintf(stderr, "rccl-self plays rank 1 of at least 3\n");
+    return 1;
+  }
+  for (int r = first; r < last; ++r) {
     pids[r] = fork(); /* nothing has initialised the GPU yet */
     if (pids[r] == 0) {
       const int down = r > 0 ? links[r - 1][1] : -1, up = r < world - 1 ? links[r][0] : -1;
-      const int rc = run_rank(r, world, down, up, sfir, input, input_bytes, argv[3], n0, plane_bytes, halo, session, deep);
+      const int rc = run_rank(r, world, down, up, sfir, input, input_bytes, argv[3], n0, plane_bytes, halo, session, deep, rccl);
       _exit(rc);
     }
   }
   int failed = 0;
-  for (int r = 0; r < world; ++r) {
+  for (int r = first; r < last; ++r) {
     int status = 0;
     waitpid(pids[r], &status, 0);
     if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) {

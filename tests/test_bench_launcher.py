@@ -65,6 +65,15 @@ def test_plain_command_two_ranks_on_this_gpu():
     rec = _line(r.stdout)
     assert rec["n_gpus"] == 2 and rec["config"]["ranks"] == 2
     # processes sharing one device can map each other's buffers: the library's own
-    # peer-to-peer transport proves itself and is used
+    # peer-to-peer transport proves itself (RCCL cannot: two ranks, one device) and is used
     assert rec["config"]["transport"] == "p2p", rec["config"]
     assert "128x64x64" in rec["config"]["workload"] and rec["value"] > 0
+    # the keys that make an N > 1 line gradable: the untimed
+    # bit-for-bit check across the ranks, and the per-GPU roofline of rank 0
+    assert rec["config"]["verified"] is True and "local recomputation" in rec["config"]["check"]
+    assert rec["config"]["schedule"].startswith(("sf_plan_execute_decomposed", "SlabRunner"))
+    roof = rec["roofline"]
+    for key in ("kernel", "achieved", "peak", "frac", "traffic", "basis", "avg_launch_us", "launches", "scope",
+                "per_gpu_mcells_per_s", "undivided_mcells_per_s", "per_gpu_vs_undivided"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and 0 < roof["frac"] <= 1 and roof["per_gpu_vs_undivided"] > 0

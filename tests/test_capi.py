@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == {name for name, _, _ in backend.API}
-    assert backend.load_library().sf_version() == 1001
+    assert backend.load_library().sf_version() == 1002
 
 
 def test_plans_compile_for_all_reference_programs(programs_dir):

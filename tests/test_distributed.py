@@ -288,18 +288,24 @@ def test_transport_handshake_gloo(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("first,expect", [("p2p", "DMA pushes"), ("rccl", "shared by the ranks"), ("gloo", "gloo")])
-def test_bench_three_ranks_on_one_gpu_falls_back(first, expect):
+@pytest.mark.parametrize("first,expect,transport", [(None, "DMA pushes", "p2p"), ("torch", "shared by the ranks", "shm"),
+                                                    ("gloo", "gloo", "gloo")])
+def test_bench_three_ranks_on_one_gpu_falls_back(first, expect, transport):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one
     rank per process), with all ranks (one of them with two neighbours) pointed
-    at this box's only GPU: the RCCL handshake cannot succeed there (several
-    ranks, one device), so the run must
-    select the spare transport (shared host memory) on every rank and still print
-    its JSON line; started at its last rung, the ladder uses gloo."""
+    at this box's only GPU.  RCCL cannot form a communicator there (several ranks, one
+    device): the default ladder must agree on that on every rank, go on to the
+    library's peer-to-peer pushes (processes sharing a device can map each other's
+    buffers), PROVE them -- the decomposed run of the chain's first operators against
+    each rank's local recomputation -- and print its line with `verified`; started at
+    torch.distributed's RCCL the ladder lands on shared host memory, started at its last
+    rung it uses gloo."""
     import json
     import subprocess
-    env = dict(os.environ, SF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               SF_BENCH_TRANSPORT=first)
+    env = dict(os.environ, SF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SF_BENCH_TRANSPORT", None)
+    if first:
+        env["SF_BENCH_TRANSPORT"] = first
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
@@ -312,7 +318,129 @@ def test_bench_three_ranks_on_one_gpu_falls_back(first, expect):
     assert rec["n_gpus"] == 3 and rec["steps"] == 2 and rec["value"] > 0
     assert rec["scaling"] == "weak" and "slab3" in rec["config"]["decomposition"]
     assert expect in rec["config"]["decomposition"], rec["config"]["decomposition"]
+    assert rec["config"]["transport"] == transport and rec["config"]["verified"] is True
+    if first is None:
+        assert "rccl not used" in rec["config"]["decomposition"]
     assert "192x64x64" in rec["config"]["workload"]
+    roof = rec["roofline"]  # per GPU (rank 0), VERDICT r02 next 1a
+    assert 0 < roof["frac"] <= 1 and roof["launches"] > 0 and roof["per_gpu_vs_undivided"] > 0
+
+
+def _corrupted_halo_worker(rank, world, port, corrupt):
+    import torch
+    sys.path.insert(0, ROOT)
+    import stencilflow_amd as sf
+    from stencilflow_amd import programs
+    from stencilflow_amd.distributed import DecompositionCheck, SlabRunner, TorchDistExchanger
+    from stencilflow_amd.lowering import lower
+    import tempfile
+    dist = _init(rank, world, port)
+    shape, ops = (48, 20, 64), 12
+    with tempfile.TemporaryDirectory() as tmp:
+        sfir = lower(sf.KernelChainGraph(programs.write_program(programs.jacobi3d(shape, ops), os.path.join(tmp, "p.json"))))
+
+    def planes_of(lo, hi):
+        return np.random.default_rng(3).random(shape, dtype=np.float32)[lo:hi]
+
+    class Corrupting(TorchDistExchanger):
+        """The second exchange delivers one wrong value in rank 1's lower ghost planes --
+        what a receiver reading stale cache lines would see."""
+        exchanges = 0
+
+        def finish(self, handle):
+            super().finish(handle)
+            if handle is None:
+                return
+            self.exchanges += 1
+            if corrupt and self.rank == 1 and self.exchanges == 2:
+                _, _, (tensor, regions, _) = handle
+                off, size = regions["recv_down"]
+                tensor[off + size // 2:off + size // 2 + 4] = 0x7b
+
+    def make(text):
+        return SlabRunner(text, shape, rank, world, device=0, exchanger=Corrupting(rank, world, staging="host"),
+                          groups_per_exchange=1)
+
+    def run(runner):
+        runner.execute()
+        runner.synchronize()
+
+    check = DecompositionCheck(sfir, shape, rank, world, planes_of, make, run, device=0)
+    ok = check.passes()
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    # only the rank that received the wrong value can see it within the planes it owns
+    assert flags == ([True, not corrupt] if world == 2 else flags), flags
+    check.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_decomposition_check_catches_a_corrupted_halo(corrupt):
+    """bench.py's untimed cross-device check (DecompositionCheck: the decomposed run of the
+    chain's first operators against each rank's local recomputation of its slab from the
+    global input) on two ranks: green on a correct transport, red on the rank whose ghost
+    planes received one wrong value."""
+    _spawn(_corrupted_halo_worker, 2, corrupt)
+
+
+def _library_rccl_self_worker(rank, world, port):
+    import datetime
+    import torch
+    sys.path.insert(0, ROOT)
+    import stencilflow_amd as sf
+    from stencilflow_amd import programs
+    from stencilflow_amd.distributed import PeerExchanger, SlabRunner, TorchDistExchanger
+    from stencilflow_amd.lowering import lower
+    import tempfile
+    dist = _init(rank, world, port)
+    torch.cuda.set_device(0)
+    shape, ops = (96, 20, 64), 19
+    with tempfile.TemporaryDirectory() as tmp:
+        sfir = lower(sf.KernelChainGraph(programs.write_program(programs.jacobi3d(shape, ops, bc_value=0.25),
+                                                                os.path.join(tmp, "p.json"))))
+    x = np.random.default_rng(21).uniform(-1, 1, (32, ) + shape[1:]).astype(np.float32)
+    results = {}
+    nccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+    for label, early in (("library", False), ("library-early", True), ("library-python", False), ("torch", False)):
+        if label == "torch":
+            ex = TorchDistExchanger(1, 3, group=nccl, staging="device", self_loop=True)
+        else:
+            ex = PeerExchanger(1, 3, "rs{}{}".format(port, label), device=0, transport="rccl", self_loop=True)
+        runner = SlabRunner(sfir, shape, 1, 3, device=0, exchanger=ex, groups_per_exchange=2, early_exchange=early)
+        runner.upload([x])
+        if label in ("library", "library-early"):  # grouped ncclSend / ncclRecv issued by libsf_hip.so, its own schedule
+            assert ex._lib.sf_halo_transport(ex._h) == b"rccl"
+            runner.execute_native()
+            runner.plan.synchronize()
+            ex.check()
+        else:
+            runner.execute()
+            runner.synchronize()
+        out = np.zeros(runner.local_shape, np.float32)
+        runner.download([out])
+        results[label] = out
+        if hasattr(ex, "close"):
+            ex.close()
+        runner.close()
+    for label in ("library-early", "library-python", "torch"):
+        assert np.array_equal(results["library"], results[label]), label
+    assert float(np.abs(results["library"]).max()) > 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_library_rccl_rung_sends_to_itself():
+    """The RCCL rung of the library's own transport (sf_halo_use_rccl: librccl through
+    dlopen, grouped ncclSend / ncclRecv on the transport's stream) on a one-GPU box: a
+    communicator of this rank alone, rank 1 of 3 whose halos come back to itself.  The
+    library's schedule (plain and with the exchange started a launch ahead), SlabRunner's
+    Python form over the same rung, and torch.distributed's RCCL in the same self-loop
+    must all give the same planes bit for bit."""
+    _spawn(_library_rccl_self_worker, 1)
 
 
 def _rccl_self_worker(rank, world, port):
@@ -372,8 +500,9 @@ def test_bench_self_loop_selects_rccl():
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
     deco = rec["config"]["decomposition"]
-    assert "slab3" in deco and "RCCL send/recv" in deco and "SELF-LOOP TEST" in deco, deco
-    assert rec["value"] > 0 and "roofline" not in rec
+    assert "slab3" in deco and "RCCL send/recv issued by libsf_hip.so" in deco and "SELF-LOOP TEST" in deco, deco
+    assert rec["config"]["transport"] == "rccl" and rec["value"] > 0
+    assert 0 < rec["roofline"]["frac"] <= 1
 
 
 @pytest.mark.gpu
