@@ -717,9 +717,11 @@ def main():
                                 schedule=timed["schedule"])
         if args.workload == "c3" and not args.size and not args.options and not args.no_other_configs:
             # BASELINE.json configs[1] and configs[4] in the driver's own line:
-            # a few chain executions each (about 0.1 s and 0.05 s of GPU time)
+            # a few steps each (about 25 ms and 45 ms of GPU time per step; a step of c5 is 100
+            # applications of the fused chain back to back -- a lone 0.4-ms launch between two
+            # synchronisations runs 20 % slower than the same launch in a stream of launches)
             others = []
-            for name, stages, steps in (("c2", 1000, 3), ("c5", 3, 20)):
+            for name, stages, steps in (("c2", 1000, 3), ("c5", 300, 3)):
                 owl = make_workload(name, 0, stages)
                 t = time_single(owl, {}, steps, 1, device=local_rank)
                 others.append({"workload": owl["label"], "value": t["value"], "unit": "Mcells/s", "steps": steps,
