@@ -70,6 +70,17 @@ int sf_plan_destroy(sf_plan* plan);
 int sf_code_cache_stats(long* disk_hits, long* compiled, long* rebuilt,
                         int drop_process_level);
 
+/* Plan-time self-check.  Before a plan's first use every FUSED kernel whose code object
+ * carries no verdict yet is run once on seeded data (planes next to both ends of the
+ * slab) and compared bit for bit with the same operators evaluated one by one by the
+ * plain generic kernel; the verdict is stored with the code object in both cache levels.
+ * A kernel that differs is never launched: the first use fails with SF_ERR_UNSUPPORTED and
+ * the planner skips the object from then on.  $SF_HIP_SELF_CHECK=0 disables the check.
+ * sf_self_checks_run: fused kernels checked by this process so far;
+ * sf_plan_kernel_verdict: 0 not checked (yet), 1 passed, 2 failed. */
+long sf_self_checks_run(void);
+int sf_plan_kernel_verdict(const sf_plan* plan, int index);
+
 /* Introspection: the argument lists `sf_plan_run` expects, in order.
  * Arrays first (program order), then nothing else: 0-D inputs are scalars. */
 int sf_plan_num_inputs(const sf_plan* plan);   /* array inputs   */

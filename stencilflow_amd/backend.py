@@ -45,6 +45,8 @@ API = [
     ("sf_plan_create", _I, [_S, _I, _S, _PP]),
     ("sf_plan_destroy", _I, [_P]),
     ("sf_code_cache_stats", _I, [ctypes.POINTER(ctypes.c_long)] * 3 + [_I]),
+    ("sf_self_checks_run", ctypes.c_long, []),
+    ("sf_plan_kernel_verdict", _I, [_P, _I]),
     ("sf_plan_num_inputs", _I, [_P]),
     ("sf_plan_num_scalars", _I, [_P]),
     ("sf_plan_num_outputs", _I, [_P]),
@@ -239,6 +241,10 @@ class Plan:
                              updates_per_launch=upd.value,
                              algorithmic_bytes_per_launch=byt.value)
         return out
+
+    def kernel_verdicts(self):
+        """name -> verdict of the plan-time self-check (0 not checked, 1 passed, 2 failed)."""
+        return {name: self._lib.sf_plan_kernel_verdict(self._h, i) for i, name in enumerate(self.kernel_names())}
 
     def set_profile(self, on=True):
         """Per-launch HIP events on / off (resets the per-kernel counters)."""

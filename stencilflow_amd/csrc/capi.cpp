@@ -55,6 +55,8 @@ int sf_plan_destroy(sf_plan* plan) {
     if (plan->debug_buffer) (void)hipFree(plan->debug_buffer);
     for (auto& k : plan->kernels)
       if (k.mod) (void)hipModuleUnload(k.mod);
+    for (auto& k : plan->check_kernels)
+      if (k.mod) (void)hipModuleUnload(k.mod);
     if (plan->chain_graph) (void)hipGraphExecDestroy(plan->chain_graph);
     (void)hipEventDestroy(plan->ev_begin);
     (void)hipEventDestroy(plan->ev_end);
@@ -68,6 +70,12 @@ int sf_plan_destroy(sf_plan* plan) {
 int sf_code_cache_stats(long* disk_hits, long* compiled, long* rebuilt, int drop_process_level) {
   sf::code_cache_stats(disk_hits, compiled, rebuilt, drop_process_level != 0);
   return SF_OK;
+}
+
+long sf_self_checks_run(void) { return sf::self_checks_run(); }
+
+int sf_plan_kernel_verdict(const sf_plan* p, int i) {
+  return (p && i >= 0 && i < (int)p->kernels.size()) ? p->kernels[i].verdict : SF_ERR_INVALID;
 }
 
 int sf_plan_num_inputs(const sf_plan* p) { return p ? p->P.num_inputs : SF_ERR_INVALID; }

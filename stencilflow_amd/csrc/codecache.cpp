@@ -218,46 +218,106 @@ static std::string disk_cache_path(const std::string& key) {
   return dir + "/" + name + ".co";
 }
 
-// Cache file = 24-byte header {magic "SFCO0002", payload bytes, FNV-1a of the
-// payload} + the code object.  A file that is truncated, damaged or of another
-// format is deleted and the kernel recompiled.
-static const char kCacheMagic[9] = "SFCO0002";
+// Cache file = 32-byte header {magic "SFCO0003", payload bytes, FNV-1a of the payload,
+// verdict of the plan-time self-check (0 not checked, 1 passed, 2 failed)} + the code
+// object.  A file that is truncated, damaged or of another format is deleted and the
+// kernel recompiled.
+static const char kCacheMagic[9] = "SFCO0003";
+static const size_t kCacheHeader = 32;
 
-static bool read_cache_file(const std::string& path, std::vector<char>& code) {
+static bool read_cache_file(const std::string& path, std::vector<char>& code, int* verdict = nullptr) {
   std::ifstream f(path, std::ios::binary);
   if (!f) return false;
   std::vector<char> blob((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
   f.close();
-  bool ok = blob.size() > 24 && std::memcmp(blob.data(), kCacheMagic, 8) == 0;
+  bool ok = blob.size() > kCacheHeader && std::memcmp(blob.data(), kCacheMagic, 8) == 0;
+  uint64_t v = 0;
   if (ok) {
     uint64_t size = 0, hash = 0;
     std::memcpy(&size, blob.data() + 8, 8);
     std::memcpy(&hash, blob.data() + 16, 8);
-    ok = size == blob.size() - 24 && size > 4 && std::memcmp(blob.data() + 24, "\177ELF", 4) == 0 &&
-         hash == fnv1a(std::string(blob.data() + 24, blob.size() - 24));
+    std::memcpy(&v, blob.data() + 24, 8);
+    ok = size == blob.size() - kCacheHeader && size > 4 && v <= 2 &&
+         std::memcmp(blob.data() + kCacheHeader, "\177ELF", 4) == 0 &&
+         hash == fnv1a(std::string(blob.data() + kCacheHeader, blob.size() - kCacheHeader));
   }
   if (!ok) {
     std::remove(path.c_str());  // stale or corrupt: never hand it to the loader
     return false;
   }
-  code.assign(blob.begin() + 24, blob.end());
+  code.assign(blob.begin() + kCacheHeader, blob.end());
+  if (verdict) *verdict = (int)v;
   return true;
 }
 
-static void write_cache_file(const std::string& path, const std::vector<char>& code) {
+static void write_cache_file(const std::string& path, const std::vector<char>& code, int verdict = 0) {
   const std::string tmp = path + "." + std::to_string((long)getpid());
   std::ofstream f(tmp, std::ios::binary);
   if (!f) return;
-  const uint64_t size = code.size(), hash = fnv1a(std::string(code.data(), code.size()));
+  const uint64_t size = code.size(), hash = fnv1a(std::string(code.data(), code.size())), v = (uint64_t)verdict;
   f.write(kCacheMagic, 8);
   f.write(reinterpret_cast<const char*>(&size), 8);
   f.write(reinterpret_cast<const char*>(&hash), 8);
+  f.write(reinterpret_cast<const char*>(&v), 8);
   f.write(code.data(), (std::streamsize)code.size());
   f.close();
   if (!f || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
 }
 
+static std::map<std::string, int> g_verdicts;  // process level, beside g_code_cache (same mutex)
+
 static std::atomic<long> g_cache_hits{0}, g_cache_misses{0}, g_cache_recompiles{0};
+
+// Code object for `source` (+ flags) through the process level and the disk level of the
+// cache, compiled when neither has it.  The kernel belongs to no plan yet.
+CompiledKernel compile_cached(const std::string& prefix, const std::string& source, const std::string& flags) {
+  const std::string keyed = flags.empty() ? source : flags + "\n" + source;
+  CompiledKernel k;
+  k.name = prefix + "_" + hex8(fnv1a(keyed));
+  k.source = source;
+  k.flags = flags;
+  const std::string key = k.name + "\n" + keyed;
+  k.cache_key = key;
+  bool cached = false;
+  {
+    std::lock_guard<std::mutex> lock(g_code_cache_mutex);
+    auto c = g_code_cache.find(key);
+    if (c != g_code_cache.end()) {
+      k.code = c->second;
+      k.verdict = g_verdicts.count(key) ? g_verdicts[key] : 0;
+      cached = true;
+    }
+  }
+  if (!cached) {
+    // second level: code objects on disk, keyed by source, name and hipRTC version
+    const std::string path = disk_cache_path(key);
+    if (!path.empty()) cached = read_cache_file(path, k.code, &k.verdict);
+    if (cached) {
+      k.from_disk = true;
+      ++g_cache_hits;
+    } else {
+      compile_kernel(k);
+      ++g_cache_misses;
+      if (!path.empty()) write_cache_file(path, k.code);
+    }
+    std::lock_guard<std::mutex> lock(g_code_cache_mutex);
+    g_code_cache[key] = k.code;
+    g_verdicts[key] = k.verdict;
+  }
+  read_metadata(k);
+  return k;
+}
+
+void record_verdict(CompiledKernel& k, int verdict) {
+  k.verdict = verdict;
+  if (k.foreign || k.cache_key.empty()) return;  // (hand-assembled diagnostics objects are never cached)
+  {
+    std::lock_guard<std::mutex> lock(g_code_cache_mutex);
+    g_verdicts[k.cache_key] = verdict;
+  }
+  const std::string path = disk_cache_path(k.cache_key);
+  if (!path.empty()) write_cache_file(path, k.code, verdict);
+}
 
 int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& source, const std::string& flags_in) {
   // (diagnostics: $SF_HIP_EXTRA_FLAGS adds compiler flags to every kernel, e.g.
@@ -274,50 +334,25 @@ int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& sou
   auto it = pl.kernel_by_source.find(keyed);
   if (it != pl.kernel_by_source.end()) return it->second;
   CompiledKernel k;
-  k.name = prefix + "_" + hex8(fnv1a(keyed));
-  k.source = source;
-  k.flags = flags;
-  k.env_flags = env_flags;
-  const std::string key = k.name + "\n" + keyed;
-  bool cached = false;
+  bool have = false;
   // (diagnostics: $SF_HIP_OBJECT_DIR/<kernel name>.co, a code object assembled by hand --
   // e.g. the compiler's own output with instructions padded or moved, tools/asm_objects.py --
   // takes the place of the compiler's; nothing is cached)
   if (const char* dir = std::getenv("SF_HIP_OBJECT_DIR")) {
-    std::ifstream f(std::string(dir) + "/" + k.name + ".co", std::ios::binary);
+    const std::string name = prefix + "_" + hex8(fnv1a(keyed));
+    std::ifstream f(std::string(dir) + "/" + name + ".co", std::ios::binary);
     if (f) {
+      k.name = name;
+      k.source = source;
+      k.flags = flags;
       k.code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
       k.foreign = true;
       read_metadata(k);
-      pl.kernels.push_back(std::move(k));
-      pl.kernel_by_source[keyed] = (int)pl.kernels.size() - 1;
-      return (int)pl.kernels.size() - 1;
+      have = true;
     }
   }
-  {
-    std::lock_guard<std::mutex> lock(g_code_cache_mutex);
-    auto c = g_code_cache.find(key);
-    if (c != g_code_cache.end()) {
-      k.code = c->second;
-      cached = true;
-    }
-  }
-  if (!cached) {
-    // second level: code objects on disk, keyed by source, name and hipRTC version
-    const std::string path = disk_cache_path(key);
-    if (!path.empty()) cached = read_cache_file(path, k.code);
-    if (cached) {
-      k.from_disk = true;
-      ++g_cache_hits;
-    } else {
-      compile_kernel(k);
-      ++g_cache_misses;
-      if (!path.empty()) write_cache_file(path, k.code);
-    }
-    std::lock_guard<std::mutex> lock(g_code_cache_mutex);
-    g_code_cache[key] = k.code;
-  }
-  read_metadata(k);
+  if (!have) k = compile_cached(prefix, source, flags);
+  k.env_flags = env_flags;
   pl.kernels.push_back(std::move(k));
   pl.kernel_by_source[keyed] = (int)pl.kernels.size() - 1;
   return (int)pl.kernels.size() - 1;
@@ -336,7 +371,9 @@ bool kernel_unsafe(const CompiledKernel& k) {
   static const bool tolerate = std::getenv("SF_HIP_UNSAFE_SGPR_SPILLS") != nullptr;
   // (SF_HIP_STRICT_SGPR_SPILLS=1: round 2's first criterion, any SGPR spill, on top)
   static const bool strict = std::getenv("SF_HIP_STRICT_SGPR_SPILLS") != nullptr;
-  return (k.late_exec_restores > 0 || ((strict || k.late_exec_restores < 0) && k.sgpr_spills > 0)) && !tolerate;
+  // (an object the plan-time self-check has seen differ from the generic operator kernels -- verdict 2,
+  // remembered in both cache levels -- is wrong whatever the detector says)
+  return k.verdict == 2 || ((k.late_exec_restores > 0 || ((strict || k.late_exec_restores < 0) && k.sgpr_spills > 0)) && !tolerate);
 }
 bool kernel_slow(const CompiledKernel& k) {
   return std::max(0, k.spills) + std::max(0, k.scratch) + std::max(0, k.agprs) > 0;
@@ -349,10 +386,13 @@ void recompile_kernel(CompiledKernel& k) {
   compile_kernel(k);
   ++g_cache_recompiles;
   k.from_disk = false;
+  k.verdict = 0;  // another object: to be checked again
+  k.cache_key = key;
   read_metadata(k);
   {
     std::lock_guard<std::mutex> lock(g_code_cache_mutex);
     g_code_cache[key] = k.code;
+    g_verdicts[key] = 0;
   }
   if (!path.empty()) write_cache_file(path, k.code);
 }
@@ -364,6 +404,7 @@ void code_cache_stats(long* disk_hits, long* compiled, long* rebuilt, bool drop_
   if (drop_process_level) {
     std::lock_guard<std::mutex> lock(g_code_cache_mutex);
     g_code_cache.clear();
+    g_verdicts.clear();
   }
 }
 

@@ -4,13 +4,17 @@
 #include "sf_internal.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <set>
 #include <sstream>
 
 namespace sf {
 
 // ---------------------------------------------------------------- runtime
 void ensure_device(sf_plan& pl) {
+  if (!pl.poisoned.empty()) throw Error(SF_ERR_UNSUPPORTED, pl.poisoned);
   if (pl.device_ready) {
     // every entry point runs on the plan's device, whatever device the calling
     // thread used last (one thread may drive plans on several GPUs)
@@ -57,6 +61,7 @@ void ensure_device(sf_plan& pl) {
   SF_HIP_CHECK(hipMemsetAsync(pl.debug_buffer, 0, 64, pl.stream));
   SF_HIP_CHECK(hipStreamSynchronize(pl.stream));
   pl.device_ready = true;
+  self_check(pl);
 }
 
 static void store_scalar(char* dst, DT dt, double v) {
@@ -364,6 +369,278 @@ void execute(sf_plan& pl, int repetitions) {
     for (auto& st : pl.steps) launch_step(pl, st, 0, pl.stream);
   SF_HIP_CHECK(hipEventRecord(pl.ev_end, pl.stream));
   pl.timed = true;
+}
+
+// ---------------------------------------------------------------- plan-time self-check
+// The second guard against a wrong code object (the first is the EXEC-restore detector of
+// codecache.cpp, a heuristic over the machine code): every FUSED kernel (star3d.h /
+// compact3d.h) that has no verdict yet is run once, before the plan's first use, on seeded
+// data over the planes next to both ends of the slab, and its result is compared bit for
+// bit with the same operators evaluated one by one by the plain generic kernel
+// (gen_generic: one point per thread, every access guarded as the reference's tasklet
+// guards it, stencilflow/stencil/cpu.py:71-102) -- two independent product kernels, no
+// oracle involved.  The verdict travels with the code object through both cache levels
+// (cache files "SFCO0003"), so only the first plan for a shape pays (one hipRTC
+// compilation per distinct operator, microseconds of launches).  A kernel that differs is
+// never launched: the plan's first use fails with SF_ERR_UNSUPPORTED, and the planner
+// skips the object from then on (kernel_unsafe), taking the next tile shape.
+// $SF_HIP_SELF_CHECK=0 turns the check off.
+namespace {
+
+__device__ __forceinline__ unsigned sf_check_hash(unsigned long long i, unsigned seed) {
+  unsigned long long x = (i + 0x9E3779B97F4A7C15ull) * (0xBF58476D1CE4E5B9ull + 2ull * seed);
+  x ^= x >> 29;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 32;
+  return (unsigned)x;
+}
+// dt: 0 f32, 1 f64, 2 i32, 3 i64 -- values in [-1, 1) (integers: -8 .. 7)
+__global__ void sf_check_fill(void* p, unsigned long long n, unsigned seed, int dt) {
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned h = sf_check_hash(i, seed);
+    if (dt == 0) static_cast<float*>(p)[i] = (float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    else if (dt == 1) static_cast<double*>(p)[i] = (double)h * (1.0 / 2147483648.0) - 1.0;
+    else if (dt == 2) static_cast<int*>(p)[i] = (int)(h & 15u) - 8;
+    else static_cast<long long*>(p)[i] = (long long)(h & 15u) - 8;
+  }
+}
+// words that differ (tol == 0: bit for bit; else floats within tol relative, for groups with
+// device math calls whose last bits are not promised to agree between two kernels)
+__global__ void sf_check_diff(const void* a, const void* b, unsigned long long n, int dt, double tol, unsigned* count) {
+  unsigned bad = 0;
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    if (dt == 0 || dt == 2) {
+      const unsigned x = static_cast<const unsigned*>(a)[i], y = static_cast<const unsigned*>(b)[i];
+      if (x == y) continue;
+      if (tol > 0 && dt == 0) {
+        const float fx = __uint_as_float(x), fy = __uint_as_float(y);
+        if (fabsf(fx - fy) <= (float)tol * fmaxf(fabsf(fx), fabsf(fy))) continue;
+      }
+      ++bad;
+    } else {
+      const unsigned long long x = static_cast<const unsigned long long*>(a)[i],
+                               y = static_cast<const unsigned long long*>(b)[i];
+      if (x == y) continue;
+      if (tol > 0 && dt == 1) {
+        const double fx = __longlong_as_double((long long)x), fy = __longlong_as_double((long long)y);
+        if (fabs(fx - fy) <= tol * 1e-6 * fmax(fabs(fx), fabs(fy))) continue;
+      }
+      ++bad;
+    }
+  }
+  if (bad) atomicAdd(count, bad);
+}
+
+std::atomic<long> g_self_checks{0};
+
+int dt_code(DT dt) { return dt == DT::F32 ? 0 : dt == DT::F64 ? 1 : dt == DT::I32 ? 2 : 3; }
+
+bool calls_device_math(const Kernel& K) {
+  static const char* const names[] = {"sin(", "cos(", "tan(", "sinh(", "cosh(", "tanh(", "exp(", "log(", "pow(", "sqrt(",
+                                      "sinf(", "cosf(", "tanf(", "sinhf(", "coshf(", "tanhf(", "expf(", "logf(", "powf(", "sqrtf("};
+  std::string text = K.ret;
+  for (auto& l : K.lets) text += " " + l.expr;
+  for (const char* n : names)
+    if (text.find(n) != std::string::npos) return true;
+  return false;
+}
+
+}  // namespace
+
+long self_checks_run() { return g_self_checks.load(); }
+
+// Compare the fused launch `st` with its operators run one by one, over planes [b, e).
+static unsigned long long self_check_range(sf_plan& pl, const Step& st, std::vector<CompiledKernel*>& refs,
+                                           const std::vector<GenericKernelSource>& gens, int b, int e) {
+  const Program& P = pl.P;
+  const int T = (int)st.kernels.size();
+  const DT dt = P.kernels[st.kernels[0]].dt;
+  const int n = (int)pl.n_local, halo = pl.halo, goff = (int)pl.goff;
+  const Buffer& primary = pl.buffers[st.in_bufs[0]];
+  const size_t plane_bytes = primary.plane_bytes;
+  // planes a launch may touch: inside the global domain and inside the buffers
+  const int q_lo = std::max(-halo, -goff), q_hi = std::min(n + halo, (int)(P.n[0] - goff));
+  const int lo_s = std::max(q_lo, b - T), hi_s = std::min(q_hi, e + T);
+  std::vector<void*> scratch(T, nullptr);
+  unsigned* d_count = nullptr;
+  unsigned long long bad = 0;
+  try {
+    for (int s = 0; s < T; ++s) SF_HIP_CHECK(hipMalloc(&scratch[s], (size_t)(hi_s - lo_s) * plane_bytes));
+    SF_HIP_CHECK(hipMalloc((void**)&d_count, sizeof(unsigned)));
+    SF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned), pl.stream));
+    // the fused launch
+    launch_ranges(pl, st, b, e, 0, 0, pl.stream);
+    // the operators one by one; operator s of the group produces planes [b - (T-1-s), e + (T-1-s))
+    for (int s = 0; s < T; ++s) {
+      const Kernel& K = P.kernels[st.kernels[s]];
+      const GenericKernelSource& g = gens[s];
+      const int rb = std::max(q_lo, b - (T - 1 - s)), re = std::min(q_hi, e + (T - 1 - s));
+      // (a scratch buffer holds planes [lo_s, hi_s): the kernels index planes from the start of a slab
+      // buffer, so they are handed the address plane -halo would have)
+      auto virtual_base = [&](void* p) { return (void*)((char*)p - (long long)(lo_s + halo) * (long long)plane_bytes); };
+      std::vector<void*> ptrs;
+      for (auto& name : g.reads) {
+        void* p = nullptr;
+        if (s > 0 && name == P.kernels[st.kernels[s - 1]].name) {
+          p = virtual_base(scratch[s - 1]);
+        } else {
+          for (size_t r = 0; r < st.read_names.size(); ++r)
+            if (st.read_names[r] == name) p = pl.buffers[st.in_bufs[r]].d;
+        }
+        if (!p) throw Error(SF_ERR_STATE, "self-check: operator '" + K.name + "' reads '" + name + "', which the launch does not");
+        ptrs.push_back(p);
+      }
+      ptrs.push_back(virtual_base(scratch[s]));
+      std::vector<void*> args;
+      for (auto& p : ptrs) args.push_back(&p);
+      alignas(16) char scalar_store[512];
+      if (g.scalars.size() * 8 > sizeof scalar_store) throw Error(SF_ERR_UNSUPPORTED, "too many scalar inputs for one launch");
+      size_t off = 0;
+      for (int sc_ix : g.scalars) {
+        const Scalar& sc = P.scalars[sc_ix];
+        const double v = pl.scalar_values[sc.input_index];
+        switch (sc.dt) {
+          case DT::F32: { float x = (float)v; std::memcpy(scalar_store + off, &x, 4); break; }
+          case DT::F64: { std::memcpy(scalar_store + off, &v, 8); break; }
+          case DT::I32: { int x = (int)v; std::memcpy(scalar_store + off, &x, 4); break; }
+          default: { long long x = (long long)v; std::memcpy(scalar_store + off, &x, 8); break; }
+        }
+        args.push_back(scalar_store + off);
+        off += 8;
+      }
+      int a_n = n, a_halo = halo, a_goff = goff, a_b = rb, a_e = re;
+      args.push_back(&a_n);
+      args.push_back(&a_halo);
+      args.push_back(&a_goff);
+      args.push_back(&a_b);
+      args.push_back(&a_e);
+      const long long plane = P.n[1] * P.n[2];
+      if (re > rb)
+        SF_HIP_CHECK(hipModuleLaunchKernel(refs[s]->fn, (unsigned)((plane + 255) / 256), (unsigned)(re - rb), 1, 256, 1, 1, 0,
+                                           pl.stream, args.data(), nullptr));
+    }
+    const Buffer& out = pl.buffers[st.out_buf];
+    const unsigned long long words = (unsigned long long)(e - b) * plane_bytes / size_of(dt);
+    bool math = false;
+    for (int k : st.kernels) math = math || calls_device_math(P.kernels[k]);
+    hipLaunchKernelGGL(sf_check_diff, dim3(1024), dim3(256), 0, pl.stream,
+                       (const void*)((char*)out.d + (size_t)(b + halo) * plane_bytes),
+                       (const void*)((char*)scratch[T - 1] + (size_t)(b - lo_s) * plane_bytes), words, dt_code(dt),
+                       math ? 1e-6 : 0.0, d_count);
+    SF_HIP_CHECK(hipGetLastError());
+    unsigned h_count = 0;
+    SF_HIP_CHECK(hipMemcpyAsync(&h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, pl.stream));
+    SF_HIP_CHECK(hipStreamSynchronize(pl.stream));
+    bad = h_count;
+  } catch (...) {
+    (void)hipStreamSynchronize(pl.stream);
+    for (void* p : scratch)
+      if (p) (void)hipFree(p);
+    if (d_count) (void)hipFree(d_count);
+    throw;
+  }
+  for (void* p : scratch) (void)hipFree(p);
+  (void)hipFree(d_count);
+  return bad;
+}
+
+void self_check(sf_plan& pl) {
+  if (const char* env = std::getenv("SF_HIP_SELF_CHECK"))
+    if (std::string(env) == "0") return;
+  // fused launches whose code object carries no verdict yet (one per distinct object)
+  std::vector<Step> todo;
+  std::set<int> seen;
+  for (const Step& st : pl.steps) {
+    if (!st.star) continue;
+    auto consider = [&](const StarCfg& cfg, int ck) {
+      if (pl.kernels[ck].verdict != 0 || !seen.insert(ck).second) return;
+      Step probe = st;
+      probe.cfg = cfg;
+      probe.ck = ck;
+      todo.push_back(probe);
+    };
+    consider(st.cfg, st.ck);
+    for (auto& alt : st.alts) consider(alt.first, alt.second);
+  }
+  if (todo.empty()) return;
+  const Program& P = pl.P;
+  const int n = (int)pl.n_local;
+  // the state the check borrows: profiling off, seeded scalars, seeded fields
+  const bool profile = pl.profile, scalars_set = pl.scalars_set;
+  const std::vector<double> scalars = pl.scalar_values;
+  const int reserved = pl.reserved_cus;
+  pl.profile = false;
+  pl.reserved_cus = 0;
+  for (size_t i = 0; i < pl.scalar_values.size(); ++i) pl.scalar_values[i] = 0.0625 * (double)(i + 1) - 0.28125;
+  pl.scalars_set = true;
+  std::set<int> dirty;
+  std::string failed;
+  try {
+    for (Step& st : todo) {
+      const int T = (int)st.kernels.size();
+      // reference operators: compiled on demand, loaded beside the plan's kernels
+      std::vector<GenericKernelSource> gens;
+      std::vector<CompiledKernel*> refs;
+      const size_t first = pl.check_kernels.size();
+      for (int k : st.kernels) {
+        gens.push_back(gen_generic(P, k, false, false));
+        pl.check_kernels.push_back(compile_cached(std::string("sf_check_") + short_of(P.kernels[k].dt), gens.back().source, ""));
+      }
+      for (size_t i = first; i < pl.check_kernels.size(); ++i) {
+        CompiledKernel& k = pl.check_kernels[i];
+        if (kernel_unsafe(k)) throw Error(SF_ERR_UNSUPPORTED, "self-check: the reference kernel itself is flagged");
+        SF_HIP_CHECK(hipModuleLoadData(&k.mod, k.code.data()));
+        SF_HIP_CHECK(hipModuleGetFunction(&k.fn, k.mod, k.name.c_str()));
+      }
+      for (size_t i = first; i < pl.check_kernels.size(); ++i) refs.push_back(&pl.check_kernels[i]);
+      // seeded data in everything the launch reads (whole buffers: ghost planes included)
+      for (size_t r = 0; r < st.in_bufs.size(); ++r) {
+        Buffer& buf = pl.buffers[st.in_bufs[r]];
+        const unsigned long long elems = buf.bytes() / size_of(buf.dt);
+        hipLaunchKernelGGL(sf_check_fill, dim3(1024), dim3(256), 0, pl.stream, buf.d, elems, (unsigned)(17 + st.in_bufs[r]),
+                           dt_code(buf.dt));
+        SF_HIP_CHECK(hipGetLastError());
+        dirty.insert(st.in_bufs[r]);
+      }
+      dirty.insert(st.out_buf);
+      // planes next to both ends of the slab (all of it when it is thin)
+      const int span = 6 + 2 * T;
+      unsigned long long bad = 0;
+      if (n <= 2 * span) {
+        bad = self_check_range(pl, st, refs, gens, 0, n);
+      } else {
+        bad = self_check_range(pl, st, refs, gens, 0, span);
+        bad += self_check_range(pl, st, refs, gens, n - span, n);
+      }
+      ++g_self_checks;
+      record_verdict(pl.kernels[st.ck], bad == 0 ? 1 : 2);
+      if (bad != 0 && failed.empty())
+        failed = pl.kernels[st.ck].name + " (" + std::to_string(bad) + " results differ from the operators run one by one)";
+    }
+  } catch (...) {
+    pl.profile = profile;
+    pl.reserved_cus = reserved;
+    pl.scalar_values = scalars;
+    pl.scalars_set = scalars_set;
+    for (int b : dirty) (void)hipMemsetAsync(pl.buffers[b].d, 0, pl.buffers[b].bytes(), pl.stream);
+    (void)hipStreamSynchronize(pl.stream);
+    throw;
+  }
+  pl.profile = profile;
+  pl.reserved_cus = reserved;
+  pl.scalar_values = scalars;
+  pl.scalars_set = scalars_set;
+  // the buffers as ensure_device left them
+  for (int b : dirty) SF_HIP_CHECK(hipMemsetAsync(pl.buffers[b].d, 0, pl.buffers[b].bytes(), pl.stream));
+  SF_HIP_CHECK(hipStreamSynchronize(pl.stream));
+  if (!failed.empty()) {
+    pl.poisoned = "plan-time self-check: the fused kernel " + failed +
+                  "; the code object is marked and will not be used again -- create the plan once more (the planner "
+                  "takes the next tile shape)";
+    throw Error(SF_ERR_UNSUPPORTED, pl.poisoned);
+  }
 }
 
 }  // namespace sf

@@ -725,6 +725,7 @@ void build_plan(sf_plan& pl) {
       auto it = buf_of.find(f);
       if (it == buf_of.end()) throw Error(SF_ERR_INVALID, "field '" + f + "' is read before it is produced");
       st.in_bufs.push_back(it->second);
+      st.read_names.push_back(f);
     }
     const Field& of = P.field(P.kernels[st.kernels.back()].name);
     int ob = -1;

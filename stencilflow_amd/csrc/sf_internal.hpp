@@ -65,6 +65,11 @@ struct CompiledKernel {
   int vgprs = -1, agprs = -1, sgprs = -1, spills = -1, scratch = -1, lds = -1, sgpr_spills = -1;
   int late_exec_restores = 0;  // see count_late_exec_restores()
   bool from_disk = false;  // the code object came from the on-disk cache
+  // verdict of the plan-time self-check (exec.cpp: self_check): 0 not checked yet, 1 equal to the generic
+  // operator kernels bit for bit on a seeded tile, 2 differed -- never launched again; travels with the
+  // code object through both cache levels
+  int verdict = 0;
+  std::string cache_key;   // name + flags + source: the key of both cache levels
   bool foreign = false;    // diagnostics: a hand-assembled object from $SF_HIP_OBJECT_DIR took the compiler's place
   bool env_flags = false;  // diagnostics: compiled with $SF_HIP_EXTRA_FLAGS
 };
@@ -96,6 +101,7 @@ struct Step {
   std::string note;
   std::vector<std::pair<StarCfg, int>> alts;  // autotune candidates (tile shape, compiled kernel)
   std::string sig;                            // steps with the same signature share the choice
+  std::vector<std::string> read_names;        // the fields behind in_bufs, same order
 };
 
 }  // namespace sf
@@ -126,11 +132,13 @@ struct sf_plan {
   int halo = 0;
   std::string description;
   bool autotuned = false;
+  std::string poisoned;  // a failed plan-time self-check: every later use of the plan reports it
   void* debug_buffer = nullptr;  // diagnostic builds (option stamp=1): 8 x uint64
   // per-launch profiling events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<int> prof_kernel;
   std::vector<int> prof_planes;
+  std::vector<sf::CompiledKernel> check_kernels;  // reference operators of the self-check (loaded modules)
 };
 
 namespace sf {
@@ -144,6 +152,10 @@ int count_late_exec_restores(const std::vector<char>& code);
 bool kernel_unsafe(const CompiledKernel& k);
 bool kernel_slow(const CompiledKernel& k);
 void code_cache_stats(long* disk_hits, long* compiled, long* rebuilt, bool drop_process_level);
+// a kernel that belongs to no plan's kernel list (the self-check's reference operators): both cache levels
+CompiledKernel compile_cached(const std::string& prefix, const std::string& source, const std::string& flags);
+// store the self-check's verdict with the code object (process and disk level)
+void record_verdict(CompiledKernel& k, int verdict);
 
 // ---- planner.cpp: launch groups, tile search, buffers
 void build_plan(sf_plan& pl);
@@ -161,6 +173,8 @@ void upload(sf_plan& pl, const void* const* host_inputs);
 void download(sf_plan& pl, void* const* host_outputs);
 void autotune(sf_plan& pl);
 void execute(sf_plan& pl, int repetitions);
+void self_check(sf_plan& pl);
+long self_checks_run();
 
 }  // namespace sf
 

@@ -18,6 +18,14 @@ CPU_SEEDS = list(range(100, 124))
 GPU_SEEDS = list(range(100, 160))
 
 
+@pytest.fixture(autouse=True)
+def _no_plan_time_self_check(monkeypatch):
+    """Hundreds of one-off programs: the plan-time self-check (one hipRTC compilation per distinct
+    operator for its reference kernels) would double this module's time, and what it checks -- fused
+    against generic kernels -- these tests check against the oracle anyway."""
+    monkeypatch.setenv("SF_HIP_SELF_CHECK", "0")
+
+
 @pytest.mark.parametrize("seed", CPU_SEEDS)
 def test_oracles_agree_on_random_programs(seed, tmp_path):
     prog = random_program(seed)
