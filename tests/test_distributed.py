@@ -224,9 +224,9 @@ def _c4_worker(rank, world, port, shape, stages, transport, out_dir):
         path = programs.write_program(programs.jacobi3d(shape, stages), os.path.join(tmp, "c4.json"))
         sfir = lower(sf.KernelChainGraph(path))
     runner = SlabRunner(sfir, shape, rank, world, device=0, exchanger=exchanger)
+    from tests.test_gpu_parity import c4_input
     lo, hi = slab_bounds(shape[0], rank, world)
-    x = np.random.default_rng(4000 + rank).random((hi - lo, ) + tuple(shape[1:]), dtype=np.float32)
-    runner.upload([x])
+    runner.upload([c4_input(lo, hi)])
     runner.execute()
     runner.synchronize()
     exchanger.check()
@@ -239,34 +239,20 @@ def _c4_worker(rank, world, port, shape, stages, transport, out_dir):
     dist.destroy_process_group()
 
 
-_C4_ORACLE = {}
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("transport", ["p2p", "shm"])
 def test_full_c4_grid_across_processes(transport, tmp_path):
-    """C4's grid (4096 x 512 x 512 float32) for 200 operators across four processes
+    """C4's grid (4096 x 512 x 512 float32) for 120 operators across four processes
     (the box admits six on its one GPU), halos over the library's peer-to-peer
     transport and over the shared-memory spare, deep-halo schedule with overlapped
-    exchange: all 1.07 billion results against the C oracle.  What a real 8-GPU run
-    adds to this is the xGMI wire."""
-    from oracle import c_oracle
-    from stencilflow_amd import programs
+    exchange: all 1.07 billion results against the C oracle (computed once per session,
+    shared with tests/test_gpu_parity.py's eight-slab test).  What a real 8-GPU run adds
+    to this is the xGMI wire."""
     from stencilflow_amd.distributed import slab_bounds
-    shape, stages, block, world = (4096, 512, 512), 200, 8, 4
-    _spawn(_c4_worker, world, shape, stages, transport, str(tmp_path))
-    if "want" not in _C4_ORACLE:
-        x = np.concatenate([np.random.default_rng(4000 + r).random(
-            (slab_bounds(shape[0], r, world)[1] - slab_bounds(shape[0], r, world)[0], ) + shape[1:], dtype=np.float32)
-            for r in range(world)])
-        ref = c_oracle.CompiledReference(programs.jacobi3d(shape, block))
-        from tests.test_gpu_parity import _oracle_threads
-        ref.threads = _oracle_threads()  # (the boxes show 256 CPUs under a 16-CPU quota)
-        want = x
-        for _ in range(stages // block):
-            want = ref.run({"a": want})["b%d" % (block - 1)]
-        _C4_ORACLE["want"] = want
-    want = _C4_ORACLE["want"]
+    from tests.test_gpu_parity import C4_SHAPE, C4_STAGES, c4_oracle
+    shape, world = C4_SHAPE, 4
+    _spawn(_c4_worker, world, shape, C4_STAGES, transport, str(tmp_path))
+    want = c4_oracle()
     for r in range(world):
         lo, hi = slab_bounds(shape[0], r, world)
         got = np.fromfile(str(tmp_path / "slab{}.dat".format(r)), np.float32).reshape((hi - lo, ) + shape[1:])

@@ -807,19 +807,46 @@ def test_full_c5_configuration_bit_exact():
     assert np.array_equal(got, want)
 
 
+C4_SHAPE, C4_STAGES = (4096, 512, 512), 120
+_C4 = {}
+
+
+def c4_input(lo=0, hi=C4_SHAPE[0]):
+    """Planes [lo, hi) of the C4 test grid: 512-plane blocks seeded 4000 + block (every rank of
+    a decomposed run can make its own slab)."""
+    parts = []
+    for b in range(lo // 512, -(-hi // 512)):
+        block = np.random.default_rng(4000 + b).random((512, ) + C4_SHAPE[1:], dtype=np.float32)
+        parts.append(block[max(lo, 512 * b) - 512 * b:min(hi, 512 * (b + 1)) - 512 * b])
+    return parts[0] if len(parts) == 1 else np.concatenate(parts)
+
+
+def c4_oracle():
+    """The C oracle's result for the C4 grid after C4_STAGES operators, computed once per test
+    session (the in-process and the multi-process C4 tests compare with the same array)."""
+    if "want" not in _C4:
+        from oracle import c_oracle
+        block = 8
+        ref = c_oracle.CompiledReference(programs.jacobi3d(C4_SHAPE, block))
+        ref.threads = _oracle_threads()
+        want = c4_input()
+        for _ in range(C4_STAGES // block):
+            want = ref.run({"a": want})["b%d" % (block - 1)]
+        _C4["want"] = want
+    return _C4["want"]
+
+
 def test_full_c4_grid_eight_slabs_bit_exact():
     """C4's grid -- 4096 x 512 x 512 float32 split into eight 512-plane slabs,
     deep halos, overlapped exchange with reserved compute units -- for the
-    first 200 operators of the chain, all 1.07 billion results against the C
+    first 120 operators of the chain, all 1.07 billion results against the C
     oracle.  The eight ranks share this GPU; halos are copied by the in-process
     exchanger (tests/test_distributed.py::test_full_c4_grid_across_processes runs
     the same grid over the peer-to-peer and the shared-memory transport)."""
     import tempfile
-    from oracle import c_oracle
     from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
     from stencilflow_amd.lowering import lower
-    shape, stages, block, world = (4096, 512, 512), 200, 8, 8
-    x = np.random.default_rng(SEED + 34).random(shape, dtype=np.float32)
+    shape, stages, world = C4_SHAPE, C4_STAGES, 8
     with tempfile.TemporaryDirectory() as tmp:
         path = programs.write_program(programs.jacobi3d(shape, stages), os.path.join(tmp, "c4.json"))
         sfir = lower(sf.KernelChainGraph(path))
@@ -830,7 +857,7 @@ def test_full_c4_grid_eight_slabs_bit_exact():
     runners = [SlabRunner(sfir, shape, r, world, exchanger=views[r]) for r in range(world)]
     assert runners[0].is_chain and runners[0].halo == 8 and runners[3].n_local == 512
     for r in runners:
-        r.upload([x[r.lo:r.hi]])
+        r.upload([c4_input(r.lo, r.hi)])
     run_lockstep(runners)
     got = np.empty(shape, np.float32)
     for r in runners:
@@ -838,12 +865,7 @@ def test_full_c4_grid_eight_slabs_bit_exact():
         r.download([part])
         got[r.lo:r.hi] = part
         r.close()
-    ref = c_oracle.CompiledReference(programs.jacobi3d(shape, block))
-    ref.threads = _oracle_threads()
-    want = x
-    for _ in range(stages // block):
-        want = ref.run({"a": want})["b%d" % (block - 1)]
-    assert np.array_equal(got, want)
+    assert np.array_equal(got, c4_oracle())
 
 
 def test_degenerate_programs(tmp_path):

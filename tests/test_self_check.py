@@ -27,7 +27,7 @@ with tempfile.TemporaryDirectory() as tmp:
     path = programs.write_program(programs.jacobi3d(shape, 4, bc_value=0.5), os.path.join(tmp, "p.json"))
     sfir = lower(sf.KernelChainGraph(path))
 out = {}
-plan = Plan(sfir)
+plan = Plan(sfir, options=os.environ.get("SF_TEST_OPTIONS") or None)
 name = [n for n in plan.kernel_names() if n.startswith("sf_star3d")][0]
 out["name"], out["source"] = name, plan.kernel_source(plan.kernel_names().index(name))
 if mode == "source":
@@ -51,7 +51,7 @@ out["nonzero"] = bool(np.abs(y).max() > 0)
 plan.close()
 if mode == "twice":
     backend.code_cache_stats(drop_process_level=True)   # the next plan goes to disk
-    again = Plan(sfir)
+    again = Plan(sfir, options=os.environ.get("SF_TEST_OPTIONS") or None)
     again.run([x], [y])
     out["checks_after_second_plan"] = lib.sf_self_checks_run()
     out["verdicts_second_plan"] = again.kernel_verdicts()
@@ -91,9 +91,13 @@ def test_the_check_can_be_switched_off(tmp_path):
 @pytest.mark.gpu
 def test_a_wrong_code_object_is_caught_before_its_first_use(tmp_path):
     """The compiler's own assembly of the fused kernel with ONE arithmetic instruction changed
-    (a double-precision add turned into a multiply), assembled and handed to the library in the
-    compiler's place: the detector has nothing to say about it, the self-check refuses it."""
-    info = _run("source", SF_HIP_CACHE_DIR="off")
+    (a double-precision add of one loop phase turned into a multiply: one element of one row of
+    a quarter of the planes goes wrong), assembled and handed to the library in the compiler's
+    place: the detector has nothing to say about it, the self-check refuses it.  (The tile shape is
+    pinned to four thread rows so that every instruction of the step loop computes stored rows
+    for some thread -- with a single thread row most rows of a tile are halo rows.)"""
+    pinned = {"SF_TEST_OPTIONS": "k1.bx=64;k1.by=4;k1.rj=5"}
+    info = _run("source", SF_HIP_CACHE_DIR="off", **pinned)
     name = info["name"]
     src = tmp_path / "k.hip"
     src.write_text(info["source"])
@@ -120,10 +124,10 @@ def test_a_wrong_code_object_is_caught_before_its_first_use(tmp_path):
     subprocess.run([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
                     str(good / "k.s"), "-o", str(good / "k.o")], check=True)
     subprocess.run([LLVM + "/ld.lld", "-shared", str(good / "k.o"), "-o", str(good / (name + ".co"))], check=True)
-    ok = _run("once", SF_HIP_CACHE_DIR="off", SF_HIP_OBJECT_DIR=str(good))
+    ok = _run("once", SF_HIP_CACHE_DIR="off", SF_HIP_OBJECT_DIR=str(good), **pinned)
     assert ok["error"] is None and ok["verdicts"][name] == 1
     # ... with the changed instruction it is refused, and stays refused
-    bad = _run("once", SF_HIP_CACHE_DIR="off", SF_HIP_OBJECT_DIR=str(out))
+    bad = _run("once", SF_HIP_CACHE_DIR="off", SF_HIP_OBJECT_DIR=str(out), **pinned)
     assert bad["error"] is not None and "self-check" in bad["error"], bad
     assert bad["error"].startswith("ValueError") and bad["verdicts"][name] == 2
     assert bad["second_use"] is not None and "self-check" in bad["second_use"]
