@@ -16,6 +16,13 @@ namespace sf {
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 size_t star_lds_bytes(const StarCfg& c, DT dt) {
+  if (c.R == 2) {
+    // kernels/wstar3d.h: two images, each with the first / last two rows of every thread row per
+    // window and four edge words per row and wave (one virtual wave at either end)
+    const size_t rows = c.noj ? 0 : (size_t)c.T * c.BY * 4 * c.BX * c.VK;
+    const size_t edge = (size_t)c.T * c.BY * c.RJ * (c.BX / 64 + 2) * 4;
+    return 2 * std::max<size_t>(1, rows + edge) * size_of(dt);
+  }
   if (c.compact) {
     // kernels/compact3d.h: per window a ring of images (first / last row of every
     // thread row + the wave-edge columns of every row incl. two virtual waves)
@@ -43,6 +50,8 @@ static int star_regs_estimate(const StarCfg& c, DT dt) {
   // spills after all is rejected by select_star from its metadata.
   const int words = (dt == DT::F64) ? 2 : 1;
   const int P = c.RJ * c.VK;
+  if (c.R == 2)  // five planes per window; fitted to the code objects of round 3 (f32 T = 2: P = 16 -> 218)
+    return 5 * c.T * P * words + 42 + P;
   if (c.compact)  // three live planes per window, one more in flight per loaded window; fitted to
                   // the code objects of round 2 (box, T = 2: P = 16 -> 180, P = 20 -> 212)
     return (3 * c.nwin + 1 + c.nwin - c.T) * P * words + 52 + P;
@@ -65,14 +74,14 @@ static int star_blocks_per_cu(const StarCfg& c, DT dt) {
 
 static void star_finish_cfg(StarCfg& c, const Program& P, int T) {
   const long long tkh = (long long)c.BX * c.VK;
-  const int hk = round_up(T, c.VK);
+  const int hk = round_up(T * c.R, c.VK);
   c.ktiled = (tkh != P.n[2]);
   c.HK = c.ktiled ? hk : 0;
   c.NKT = c.ktiled ? (int)((P.n[2] + (tkh - 2 * c.HK) - 1) / (tkh - 2 * c.HK)) : 1;
   if (c.noj) {
     c.NJT = 1;
   } else {
-    const int tji = c.BY * c.RJ - 2 * T;
+    const int tji = c.BY * c.RJ - 2 * T * c.R;
     if (tji < 1) throw Error(SF_ERR_INVALID, "star kernel: tile has no interior rows (raise k1.by / k1.rj)");
     c.NJT = (int)((P.n[1] + tji - 1) / tji);
   }
@@ -87,7 +96,7 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
   const int slots = std::max(1, 256 - reserved_cus) * std::max(1, star_blocks_per_cu(c, dt));
   double best = 1e30;
   int best_li = range;
-  const int max_nch = std::max(1, range / std::max(1, 2 * c.T));
+  const int max_nch = std::max(1, range / std::max(1, 2 * c.T * c.R));
   for (int nch = 1; nch <= std::min(max_nch, 4096); ++nch) {
     const int li = (range + nch - 1) / nch;
     const int real_nch = (range + li - 1) / li;
@@ -100,7 +109,7 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
       // 92-row chunks).  Below that, time follows the chunk length; above it,
       // the warm-up redundancy.
       const double waves_per_simd = (double)blocks * (double)(c.BX / 64) / 1024.0;
-      const double warm = (double)(li + 2 * c.T + (c.reverse ? c.T - 1 : 0)) / (double)li;
+      const double warm = (double)(li + 2 * c.T * c.R + (c.reverse ? c.T - 1 : 0)) / (double)li;
       const double cost = warm * std::max(1.0, 3.0 / waves_per_simd);
       if (cost < best - 1e-12) {
         best = cost;
@@ -111,7 +120,7 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
     }
     const long long rounds = (blocks + slots - 1) / slots;
     const double quant = (double)(rounds * slots) / (double)blocks;
-    const double warm = (double)(li + 2 * c.T + (c.reverse ? c.T - 1 : 0)) / (double)li;
+    const double warm = (double)(li + 2 * c.T * c.R + (c.reverse ? c.T - 1 : 0)) / (double)li;
     // more rounds amortise the tail when block times differ
     const double cost = warm * quant * (1.0 + 0.02 / (double)rounds);
     if (cost < best - 1e-12) {
@@ -146,6 +155,7 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   if (!pl.opt.kv.count("k1.vk"))
     while (base.VK > 1 && P.n[2] % base.VK != 0) base.VK /= 2;
   if (P.n[2] % base.VK != 0) throw Error(SF_ERR_INVALID, "innermost extent must be a multiple of k1.vk");
+  if (base.R == 2 && base.VK < 2) throw Error(SF_ERR_INVALID, "wide stars need vectors of two or more elements");
   base.n0g = P.n[0];
   base.n1 = P.n[1];
   base.n2 = P.n[2];
@@ -163,7 +173,7 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   // the memory operations in flight, a wave no longer drains them once per step,
   // and stage-1-first with the four-slot input ring overtakes it: C2 +10 %
   // (profiles/r01_sweep_17_buffer_io.log); k1.rev=1 remains available
-  base.reverse = base.compact ? 1 : (int)pl.opt.get("k1.rev", 0);
+  base.reverse = base.compact ? 1 : base.R == 2 ? 0 : (int)pl.opt.get("k1.rev", 0);
   // input planes: 0 = loaded into the window slot stage 1 has just freed, 1 = into
   // staging registers a step earlier and copied, 2 = four-slot input ring (two
   // steps to land, no copy; the step loop is unrolled by 4)
@@ -223,7 +233,8 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
         c.BX = bx;
         c.RJ = rj;
         c.BY = by;
-        if (!c.noj && by * rj - 2 * T < 1) continue;
+        if (!c.noj && by * rj - 2 * T * c.R < 1) continue;
+        if (c.R == 2 && !c.noj && rj < 2) continue;  // a thread row publishes its first and last two rows
         star_finish_cfg(c, P, T);
         if (star_lds_bytes(c, dt) > 160 * 1024) continue;
         const bool pinned = pin_bx && pin_by && pin_rj;
@@ -241,7 +252,7 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
             (!c.noj && star_blocks_per_cu(c, dt) == 1) ? (double)((waves + 3) / 4 * 4) / (double)waves : 1.0;
         // 2-D: a one-wave block needs neither LDS nor a barrier; wider blocks exchange
         // their edge columns through LDS every step (measured 10-30 % slower on C2)
-        const double edge_rows = c.noj ? (c.BX > 64 ? 1.2 : 1.0) : 1.0 + 0.8 / (double)c.RJ;
+        const double edge_rows = c.noj ? (c.BX > 64 ? 1.2 : 1.0) : 1.0 + 0.8 * c.R / (double)c.RJ;
         // ties go to the larger block (fewer barriers per point)
         const double cost = jcost * kcost * chunk_cost * simd_balance * edge_rows *
                             (1.0 + 1e-4 / (double)(c.BX * c.BY * c.RJ));
@@ -324,6 +335,64 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
                    ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs,
                    k.agprs, k.spills, k.scratch, k.sgpr_spills, k.late_exec_restores);
     (void)sgpr_rejects;  // (star kernels: SGPR spills do depend on the shape -- hotspot 512^3: shapes 1-3 spill, 4 does not)
+    if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
+      if (!out.ok) {
+        out.ok = true;
+        out.cfg = ranked[ci];
+        out.ck = ck;
+      }
+      out.alts.push_back({ranked[ci], ck});
+      if (pinned || (long long)out.alts.size() >= std::max<long long>(1, pl.opt.get("autotune", 0))) break;
+    }
+  }
+  out.sig = sig;
+  memo[sig] = out;
+  return out;
+}
+
+// The same for a group of radius-2 star operators (kernels/wstar3d.h).
+static StarChoice select_wide(sf_plan& pl, std::map<std::string, StarChoice>& memo, const std::vector<int>& kernels, DT dt) {
+  const Program& P = pl.P;
+  StarCfg probe;
+  probe.T = (int)kernels.size();
+  probe.R = 2;
+  probe.noj = (P.n[1] == 1);
+  const std::string sig = "wide" + std::to_string(fnv1a(gen_wide(P, kernels, probe).source));
+  auto it = memo.find(sig);
+  if (it != memo.end()) return it->second;
+  const std::string prefix = std::string(P.n[1] == 1 ? "sf_wstar2d_" : "sf_wstar3d_") + short_of(dt) + "_t" +
+                             std::to_string(kernels.size());
+  StarChoice out;
+  std::vector<StarCfg> ranked;
+  try {
+    ranked = rank_star_cfgs(pl, (int)kernels.size(), dt, &probe);
+  } catch (const Error&) {
+    memo[sig] = out;
+    return out;
+  }
+  const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
+                      (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
+  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
+  int rejected = 0;
+  for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {
+    StarKernelSource g = gen_wide(P, kernels, ranked[ci]);
+    int ck = -1;
+    try {
+      ck = intern_kernel(pl, prefix, g.source);
+    } catch (const Error& e) {
+      if (pinned || e.status != SF_ERR_COMPILE) throw;
+      if (pl.opt.get("debug", 0) != 0)
+        std::fprintf(stderr, "[sf_hip] wide candidate %zu/%zu rejected by the compiler: %.400s\n", ci + 1, ranked.size(), e.what());
+      ++rejected;
+      continue;
+    }
+    const CompiledKernel& k = pl.kernels[ck];
+    if (pl.opt.get("debug", 0) != 0)
+      std::fprintf(stderr,
+                   "[sf_hip] wide candidate %zu/%zu T=%d block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d "
+                   "sgpr spill %d late exec restores %d lds %d\n",
+                   ci + 1, ranked.size(), ranked[ci].T, ranked[ci].BX, ranked[ci].BY, ranked[ci].RJ, k.vgprs, k.agprs, k.spills,
+                   k.scratch, k.sgpr_spills, k.late_exec_restores, k.lds);
     if (!kernel_unsafe(k) && (!kernel_slow(k) || (pinned && pl.opt.get("allow_spills", 0) != 0))) {
       if (!out.ok) {
         out.ok = true;
@@ -429,7 +498,7 @@ static void describe_step(std::ostringstream& desc, const sf_plan& pl, const Ste
   desc << "  launch " << ck.name << ": ";
   for (int k : st.kernels) desc << P.kernels[k].name << " ";
   if (st.star)
-    desc << (st.compact ? "[compact windows " + std::to_string(st.cfg.nwin) + " T=" : std::string("[star T=")) << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
+    desc << (st.compact ? "[compact windows " + std::to_string(st.cfg.nwin) + " T=" : st.wide ? std::string("[wide star T=") : std::string("[star T=")) << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
          << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " chunk "
          << star_chunk_length(pl, st.cfg, dt, (int)pl.n_local) << " lds " << star_lds_bytes(st.cfg, dt)
          << " B]";
@@ -543,7 +612,38 @@ void build_plan(sf_plan& pl) {
       for (auto& a : P.kernels[k].acc)
         if (a.off[1] != 0) star = false;
     }
-    if (star) {
+    // radius-2 stars (bin/synthesize.py with an extent of 2): kernels/wstar3d.h, two fused by default
+    // (ten planes of register window per thread: f64 and deeper groups shrink the tile too far)
+    const bool wide = !generic_only && star_ok_dims && pl.opt.get("wide", 1) != 0 && wide_eligible(P, P.kernels[k]);
+    if (wide) {
+      std::vector<int> group{k};
+      const int wfuse = (int)std::max<long long>(1, pl.opt.get("fuse", P.kernels[k].dt == DT::F64 ? 1 : 2));
+      while ((int)group.size() < wfuse && k + (int)group.size() < K) {
+        const int cur = group.back(), nxt = cur + 1;
+        const Kernel& kc = P.kernels[cur];
+        std::string nprimary;
+        if (!wide_eligible(P, P.kernels[nxt], &nprimary) || nprimary != kc.name) break;
+        if (P.field(kc.name).role != Role::Temp || consumers[kc.name] != 1 || P.kernels[nxt].dt != kc.dt) break;
+        group.push_back(nxt);
+      }
+      StarChoice choice;
+      while (!group.empty()) {
+        choice = select_wide(pl, star_memo, group, P.kernels[k].dt);
+        if (choice.ok) break;
+        group.pop_back();
+      }
+      if (choice.ok) {
+        st.star = true;
+        st.wide = true;
+        st.kernels = group;
+        st.cfg = choice.cfg;
+        st.ck = choice.ck;
+        st.alts = choice.alts;
+        st.sig = choice.sig;
+      } else {
+        st.kernels.push_back(k);
+      }
+    } else if (star) {
       std::vector<int> group{k};
       std::set<std::string> group_aux(shape.aux.begin(), shape.aux.end());
       while ((int)group.size() < fuse && k + (int)group.size() < K) {
@@ -680,7 +780,9 @@ void build_plan(sf_plan& pl) {
   std::map<std::string, int> last_use; // field -> last step reading it
   auto step_reads = [&](const Step& st) {
     std::vector<std::string> r;
-    if (st.compact) {
+    if (st.wide) {
+      r.push_back(P.kernels[st.kernels[0]].acc[0].field);  // one field, streamed
+    } else if (st.compact) {
       // argument 0: the streamed field of the first stage; then the extra fields in
       // first-use order (as gen_compact numbers them)
       for (size_t si = 0; si < st.kernels.size(); ++si) {
@@ -771,7 +873,8 @@ void build_plan(sf_plan& pl) {
     if (st.star) {
       if (star_lds_bytes(st.cfg, dt) > 160 * 1024)
         throw Error(SF_ERR_INVALID, "star kernel: tile needs more than 160 KiB of LDS");
-      StarKernelSource g = st.compact ? gen_compact(P, st.kernels, st.cfg) : gen_star(P, st.kernels, st.cfg);
+      StarKernelSource g = st.wide ? gen_wide(P, st.kernels, st.cfg)
+                           : st.compact ? gen_compact(P, st.kernels, st.cfg) : gen_star(P, st.kernels, st.cfg);
       st.scalars = g.scalars;
       st.scalar_offsets = g.scalar_offsets;
       st.scalars_bytes = g.scalars_bytes;
@@ -784,7 +887,7 @@ void build_plan(sf_plan& pl) {
         for (size_t a = 0; a < g.aux.size(); ++a)
           if (reads[a + 1] != g.aux[a]) throw Error(SF_ERR_STATE, "star step: auxiliary order mismatch");
       }
-      st.halo_depth = st.cfg.T;
+      st.halo_depth = st.cfg.T * st.cfg.R;
       st.halo_buf = st.in_bufs[0];
     } else {
       // 4 points per thread with aligned vector loads when rows allow it; the

@@ -86,6 +86,7 @@ struct Buffer {
 struct Step {
   bool star = false;     // plane-streaming launch (star3d.h or, with `compact`, compact3d.h)
   bool compact = false;
+  bool wide = false;  // radius-2 star launch (kernels/wstar3d.h)
   std::vector<int> kernels;    // program kernel indices fused in this launch
   int ck = -1;                 // compiled kernel
   std::vector<int> in_bufs;    // argument order

@@ -266,6 +266,88 @@ def star_program(seed):
     return prog
 
 
+# --- random chains of WIDE-STAR operators (kernels/wstar3d.h): offsets -2..2 along one axis
+# at a time (at least one at distance 2 in most stages; a stage without one is a plain star and
+# breaks the group), scalar / literal coefficients, int / float / shrink boundaries, ternaries
+# on the centre value; 3-D and 2-D, awkward sizes (rows of 4m and 4m+2 elements); only + - *
+# and selects, so every implementation must agree bit for bit -------------------------------
+def wide_program(seed):
+    rng = np.random.default_rng(10_000 + seed)
+    nd = 3 if rng.random() < 0.7 else 2
+    its = ["i", "j", "k"][3 - nd:]
+    if nd == 3:
+        dims = [int(rng.integers(5, 30)), int(rng.integers(3, 45)), 2 * int(rng.integers(4, 90))]
+    else:
+        dims = [int(rng.integers(5, 140)), 2 * int(rng.integers(4, 200))]
+    dtype = "float32" if rng.random() < 0.65 else "float64"
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": [],
+            "dimensions": dims, "program": {}}
+    scalars = []
+    for n in range(int(rng.integers(0, 3))):
+        name = "s%d" % n
+        prog["inputs"][name] = {"data": float(np.round(rng.uniform(-1, 1), 3)), "data_type": dtype, "input_dims": []}
+        scalars.append(name)
+    stages = int(rng.integers(1, 6))
+    prev = "a"
+    for s in range(stages):
+        name = "b%d" % s
+        reach = 2 if rng.random() < 0.85 else 1
+        offs = []
+        for d in range(nd):
+            for o in range(-reach, reach + 1):
+                if o != 0 and rng.random() < 0.7:
+                    offs.append((d, o))
+        if reach == 2 and not any(abs(o) == 2 for _, o in offs):
+            offs.append((int(rng.integers(0, nd)), int(rng.choice([-2, 2]))))
+        if not offs:
+            offs.append((int(rng.integers(0, nd)), 1))
+        if rng.random() < 0.6:
+            offs.append((0, 0))
+        terms = []
+        for t in rng.permutation(len(offs)):
+            d, o = offs[int(t)]
+            idx = [it if e != d or o == 0 else "%s%+d" % (it, o) for e, it in enumerate(its)]
+            acc = "%s[%s]" % (prev, ",".join(idx))
+            r = rng.random()
+            if r < 0.5:
+                terms.append(acc)
+            elif r < 0.8 or not scalars:
+                terms.append("%r*%s" % (float(np.round(rng.uniform(-1, 1), 4)), acc))
+            else:
+                terms.append("%s*%s" % (rng.choice(scalars), acc))
+        expr = terms[0]
+        for t in terms[1:]:
+            expr = "%s %s %s" % (expr, rng.choice(["+", "+", "-"]), t)
+            if rng.random() < 0.25:
+                expr = "(" + expr + ")"
+        coef = rng.random()
+        if coef < 0.5:
+            expr = "%r * (%s)" % (float(np.round(rng.uniform(0.05, 0.2), 8)), expr)
+        elif coef < 0.65 and scalars:
+            expr = "%s * (%s)" % (rng.choice(scalars), expr)
+        if rng.random() < 0.15:
+            centre = "%s[%s]" % (prev, ",".join(its))
+            expr = "(%s) if %s > 0.0 else (%s + 1)" % (expr, centre, expr)
+        kind = rng.random()
+        if kind < 0.1:
+            bc = {"type": "shrink"}
+        elif kind < 0.4:
+            bc = {"type": "constant", "value": int(rng.integers(-1, 3))}
+        else:
+            bc = {"type": "constant", "value": float(rng.choice(EXACT))}
+        prog["program"][name] = {"computation_string": "%s = %s" % (name, expr),
+                                 "boundary_conditions": {prev: bc}, "data_type": dtype}
+        if s < stages - 1 and rng.random() < 0.1:
+            prog["outputs"].append(name)
+        prev = name
+    prog["outputs"].append(prev)
+    text = " ".join(k["computation_string"] for k in prog["program"].values())
+    for name in scalars:
+        if name not in text:
+            del prog["inputs"][name]
+    return prog
+
+
 # --- random chains of COMPACT operators (kernels/compact3d.h): any subset of the 27
 # offsets {-1,0,1}^3 of the previous stage, optionally a second full input field read
 # through such offsets, scalar / literal coefficients, int / float / shrink boundaries,

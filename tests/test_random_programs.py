@@ -119,6 +119,94 @@ def test_hip_matches_oracle_on_random_star_chains(seed, tmp_path):
             assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:400])
 
 
+WIDE_CPU_SEEDS = list(range(0, 8))
+WIDE_GPU_SEEDS = list(range(0, 40))
+
+
+def _wide_case(seed, tmp_path):
+    from tests.random_programs import wide_program
+    prog = wide_program(seed)
+    rng = np.random.default_rng(seed + 11)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    path = programs.write_program(prog, str(tmp_path / "p.json"))
+    return prog, ins, sf.KernelChainGraph(path), {"fuse": int(rng.integers(1, 4))}
+
+
+@pytest.mark.parametrize("seed", WIDE_CPU_SEEDS)
+def test_random_wide_star_chains_plan(seed, tmp_path):
+    """Random chains of radius-2 stars (kernels/wstar3d.h; what the reference's generator emits
+    for an extent of 2, bin/synthesize.py:19-31) are planned onto fused wide-star launches (CPU:
+    hipRTC only) and the two oracles agree on them."""
+    prog, ins, chain, opt = _wide_case(seed, tmp_path)
+    a = npo.run_reference(prog, inputs=ins)
+    b = c_oracle.CompiledReference(prog).run(inputs=ins)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (seed, k)
+    with Plan(lower(chain), options=opt) as plan:
+        import re
+        far = any(re.search(r"[ijk][+-]2\b", k["computation_string"]) for k in prog["program"].values())
+        assert ("[wide star" in plan.describe()) == far, plan.describe()
+        assert sorted(plan.output_names) == sorted(prog["outputs"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", WIDE_GPU_SEEDS)
+def test_hip_matches_oracle_on_random_wide_star_chains(seed, tmp_path):
+    prog, ins, chain, opt = _wide_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain), options=opt) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]])
+                for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:400])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(300, 308)))
+def test_random_wide_star_chains_under_slab_decomposition(seed, tmp_path):
+    """The same chains on two or three in-process slabs of unequal height (a launch of T fused
+    radius-2 operators reaches 2 T planes across a slab boundary)."""
+    from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
+    from tests.random_programs import wide_program
+    prog = wide_program(seed)
+    prog["dimensions"][0] = max(prog["dimensions"][0], 40)
+    rng = np.random.default_rng(seed + 13)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    want = npo.run_reference(prog, inputs=ins)
+    sfir = lower(sf.KernelChainGraph(programs.write_program(prog, str(tmp_path / "p.json"))))
+    shape, world = tuple(prog["dimensions"]), int(rng.integers(2, 4))
+    exch = LocalExchanger(world)
+    runners = [SlabRunner(sfir, shape, r, world, options={"fuse": int(rng.integers(1, 3))}, exchanger=exch.for_rank(r),
+                          groups_per_exchange=int(rng.integers(1, 3))) for r in range(world)]
+    for r in runners:
+        if r.plan.scalar_names:
+            r.plan.set_scalars([ins[n] for n in r.plan.scalar_names])
+        r.upload([np.ascontiguousarray(ins[n][r.lo:r.hi]) for n in r.plan.input_names])
+    run_lockstep(runners)
+    for oi, name in enumerate(runners[0].plan.output_names):
+        got = np.zeros(shape, dtype=want[name].dtype)
+        for r in runners:
+            parts = [np.zeros(r.local_shape, dtype=want[n].dtype) for n in r.plan.output_names]
+            r.download(parts)
+            got[r.lo:r.hi] = parts[oi]
+        assert np.array_equal(got, want[name], equal_nan=True), (seed, name)
+    for r in runners:
+        r.close()
+
+
 COMPACT_CPU_SEEDS = list(range(0, 6))
 COMPACT_GPU_SEEDS = list(range(0, 40))
 

@@ -41,6 +41,11 @@ def main():
         ("box 2-D f32", ("float32", st, 0.0, 8 * n, 8 * n, 0, 1, 1, 0), {"stencil_shape": "box"}),
         ("cross 2-D f32, extra field every 2nd stage", ("float32", st, 0.5, 8 * n, 8 * n, 0, 1, 1, 0), {}),
         ("k-only 2-D f32 (round 1's 'cross 2-D')", ("float32", st, 0.0, 0, 8 * n, 8 * n, 0, 1, 1), {}),
+        # radius-2 stars (extent 2 of the reference generator): kernels/wstar3d.h since round 3
+        ("wide cross 3-D f32 (radius 2)", ("float32", st, 0.0, n, n, n, 2, 2, 2), {}),
+        ("wide diffusion 3-D f32 (radius 2)", ("float32", st, 0.0, n, n, n, 2, 2, 2), {"stencil_shape": "diffusion"}),
+        ("wide cross 3-D f64 (radius 2)", ("float64", st, 0.0, n, n, n, 2, 2, 2), {}),
+        ("wide cross 2-D f32 (radius 2)", ("float32", st, 0.0, 8 * n, 8 * n, 0, 2, 2, 0), {}),
     ]
     rng = np.random.default_rng(5)
     with tempfile.TemporaryDirectory() as tmp:
