@@ -462,7 +462,15 @@ static unsigned long long self_check_range(sf_plan& pl, const Step& st, std::vec
   const size_t plane_bytes = primary.plane_bytes;
   // planes a launch may touch: inside the global domain and inside the buffers
   const int q_lo = std::max(-halo, -goff), q_hi = std::min(n + halo, (int)(P.n[0] - goff));
-  const int lo_s = std::max(q_lo, b - T), hi_s = std::min(q_hi, e + T);
+  // how far each operator reaches along the stream axis, and how far the operators after it do
+  // together: operator s of the group must produce planes [b - after[s + 1], e + after[s + 1])
+  std::vector<int> after(T + 1, 0);
+  for (int s = T - 1; s >= 0; --s) {
+    int reach = 0;
+    for (auto& a : P.kernels[st.kernels[s]].acc) reach = std::max(reach, std::abs(a.off[0]));
+    after[s] = after[s + 1] + reach;  // (after[s] counts operator s itself: what its INPUT must cover)
+  }
+  const int lo_s = std::max(q_lo, b - after[0]), hi_s = std::min(q_hi, e + after[0]);
   std::vector<void*> scratch(T, nullptr);
   unsigned* d_count = nullptr;
   unsigned long long bad = 0;
@@ -472,11 +480,11 @@ static unsigned long long self_check_range(sf_plan& pl, const Step& st, std::vec
     SF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned), pl.stream));
     // the fused launch
     launch_ranges(pl, st, b, e, 0, 0, pl.stream);
-    // the operators one by one; operator s of the group produces planes [b - (T-1-s), e + (T-1-s))
+    // the operators one by one, each over the planes the later ones need of it
     for (int s = 0; s < T; ++s) {
       const Kernel& K = P.kernels[st.kernels[s]];
       const GenericKernelSource& g = gens[s];
-      const int rb = std::max(q_lo, b - (T - 1 - s)), re = std::min(q_hi, e + (T - 1 - s));
+      const int rb = std::max(q_lo, b - after[s + 1]), re = std::min(q_hi, e + after[s + 1]);
       // (a scratch buffer holds planes [lo_s, hi_s): the kernels index planes from the start of a slab
       // buffer, so they are handed the address plane -halo would have)
       auto virtual_base = [&](void* p) { return (void*)((char*)p - (long long)(lo_s + halo) * (long long)plane_bytes); };
@@ -579,7 +587,6 @@ void self_check(sf_plan& pl) {
   std::string failed;
   try {
     for (Step& st : todo) {
-      const int T = (int)st.kernels.size();
       // reference operators: compiled on demand, loaded beside the plan's kernels
       std::vector<GenericKernelSource> gens;
       std::vector<CompiledKernel*> refs;
@@ -606,7 +613,7 @@ void self_check(sf_plan& pl) {
       }
       dirty.insert(st.out_buf);
       // planes next to both ends of the slab (all of it when it is thin)
-      const int span = 6 + 2 * T;
+      const int span = 6 + 2 * st.halo_depth;
       unsigned long long bad = 0;
       if (n <= 2 * span) {
         bad = self_check_range(pl, st, refs, gens, 0, n);

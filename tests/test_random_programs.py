@@ -189,8 +189,9 @@ def test_random_wide_star_chains_under_slab_decomposition(seed, tmp_path):
     sfir = lower(sf.KernelChainGraph(programs.write_program(prog, str(tmp_path / "p.json"))))
     shape, world = tuple(prog["dimensions"]), int(rng.integers(2, 4))
     exch = LocalExchanger(world)
-    runners = [SlabRunner(sfir, shape, r, world, options={"fuse": int(rng.integers(1, 3))}, exchanger=exch.for_rank(r),
-                          groups_per_exchange=int(rng.integers(1, 3))) for r in range(world)]
+    fuse, groups = int(rng.integers(1, 3)), int(rng.integers(1, 3))  # (alike on all ranks)
+    runners = [SlabRunner(sfir, shape, r, world, options={"fuse": fuse}, exchanger=exch.for_rank(r),
+                          groups_per_exchange=groups) for r in range(world)]
     for r in runners:
         if r.plan.scalar_names:
             r.plan.set_scalars([ins[n] for n in r.plan.scalar_names])

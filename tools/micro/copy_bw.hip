@@ -1,10 +1,14 @@
 // copy_bw.hip -- what a plain copy reaches on this chip, in the access shapes the
 // guide quotes (MI355X_MICROARCH.md: 6.29 TB/s for a float4 copy) and in the
 // shapes the stencil kernels use.  Bytes counted = read + written.
-//   hipcc --offload-arch=gfx950 -O3 -o copy_bw copy_bw.hip && ./copy_bw
+//   hipcc --offload-arch=gfx950 -O3 -o copy_bw copy_bw.hip && ./copy_bw [MiB per buffer, default 512]
+// With 64 (the C2 field: two 64 MiB buffers, both resident in the 256 MiB Infinity Cache) every
+// shape is also run PING-PONG -- a -> b, then b -> a, as a chain of launches reads what the previous
+// one wrote -- which is the fabric / MALL ceiling the 2-D kernels work under.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CHECK(x)                                                                  \
@@ -87,8 +91,10 @@ static double time_ms(L launch, int reps) {
   return best;
 }
 
-int main() {
-  const size_t bytes = 512ull << 20;  // the C3 field
+int main(int argc, char** argv) {
+  const size_t mib = argc > 1 ? (size_t)std::atoll(argv[1]) : 512;  // 512 = the C3 field, 64 = the C2 field
+  const size_t bytes = mib << 20;
+  const bool pingpong = mib <= 96;
   const size_t n = bytes / sizeof(f4);
   f4 *in, *out;
   CHECK(hipMalloc(&in, bytes));
@@ -121,6 +127,23 @@ int main() {
     std::snprintf(name, sizeof name, "chunk per block x10 nt store, 512 thr, %d blocks", blocks);
     report(name, time_ms([&] { copy_chunked<10, 1><<<blocks, 512>>>(in, out, n); }, 10));
   }
-  // read-only and write-only
+  if (pingpong) {
+    // a chain of launches, each reading what the previous one wrote (both buffers stay in the Infinity Cache)
+    auto chain = [&](auto one, int reps) {
+      return time_ms([&] { one(in, out); one(out, in); }, reps) / 2.0;
+    };
+    std::printf("-- ping-pong (a -> b, b -> a), %zu MiB per buffer\n", mib);
+    report("pp flat, 256 thr, 1 float4/thread",
+           chain([&](f4* a, f4* b) { copy_flat<<<(unsigned)((n + 255) / 256), 256>>>(a, b, n); }, 20));
+    for (int blocks : {1024, 2048, 3072, 4096, 8192}) {
+      char name[128];
+      std::snprintf(name, sizeof name, "pp grid-stride x4, 256 thr, %d blocks", blocks);
+      report(name, chain([&](f4* a, f4* b) { copy_stride<4, 0><<<blocks, 256>>>(a, b, n); }, 20));
+      std::snprintf(name, sizeof name, "pp chunk per block x4, 64 thr (one wave, the 2-D kernels' shape), %d blocks", blocks);
+      report(name, chain([&](f4* a, f4* b) { copy_chunked<4, 0><<<blocks, 64>>>(a, b, n); }, 20));
+      std::snprintf(name, sizeof name, "pp chunk per block x8, 64 thr, %d blocks", blocks);
+      report(name, chain([&](f4* a, f4* b) { copy_chunked<8, 0><<<blocks, 64>>>(a, b, n); }, 20));
+    }
+  }
   return 0;
 }
