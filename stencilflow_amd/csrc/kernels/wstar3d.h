@@ -52,7 +52,12 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #else
 #define SF_TJI (SF_TJH - 2 * SF_REACH)
 #endif
+// interior columns of a k-tile: codegen sets SF_TKI when the row is cut into tiles of EQUAL useful width
+// (512 columns in three 256-lane tiles: 172 each, instead of 248 + 248 + 16 -- the blocks of a nearly
+// empty last tile would take as long as the others while loading nothing)
+#ifndef SF_TKI
 #define SF_TKI (SF_TKH - 2 * SF_HK)
+#endif
 
 // LDS image (one per step parity): per window the first two and the last two rows of
 // every thread row, and per row of every thread row the two lowest / two highest
@@ -408,15 +413,17 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 #pragma unroll
   for (int v = 0; v < SF_VK; ++v) cx.kmask |= ((k0 + v >= 0 && k0 + v < SF_N2) ? 1u : 0u) << v;
   const bool kvec_in = (cx.kmask & 1u) != 0;  // N2 % VK == 0: whole vector in or out
+  bool kload = kvec_in;
   if (SF_KTILED) {
     const int tk = cx.tx * SF_VK;
-    if (!(tk >= SF_HK && tk < SF_TKH - SF_HK && kvec_in)) store_mask = 0;
+    if (!(tk >= SF_HK && tk < SF_HK + SF_TKI && kvec_in)) store_mask = 0;
+    kload = kload && tk < SF_TKI + 2 * SF_HK;  // lanes beyond the tile's interior and halo have nothing to read
   }
   if (!kvec_in) store_mask = 0;
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     const unsigned off = (unsigned)(((j0 + r) * SF_N2 + k0) * (int)sizeof(sf_t));
-    cx.ld_off[r] = (((cx.jmask >> r) & 1u) && kvec_in) ? off : SF_OOB;
+    cx.ld_off[r] = (((cx.jmask >> r) & 1u) && kload) ? off : SF_OOB;
     cx.st_off[r] = ((store_mask >> r) & 1u) ? off : SF_OOB;
   }
 

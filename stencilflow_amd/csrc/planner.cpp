@@ -50,8 +50,8 @@ static int star_regs_estimate(const StarCfg& c, DT dt) {
   // spills after all is rejected by select_star from its metadata.
   const int words = (dt == DT::F64) ? 2 : 1;
   const int P = c.RJ * c.VK;
-  if (c.R == 2)  // five planes per window; fitted to the code objects of round 3 (f32 T = 2: P = 16 -> 218)
-    return 5 * c.T * P * words + 42 + P;
+  if (c.R == 2)  // five planes per window; fitted to the code objects of round 3 (f32 T = 2: P = 16 -> 190, P = 20 -> 232)
+    return 5 * c.T * P * words + 22 + P / 2;
   if (c.compact)  // three live planes per window, one more in flight per loaded window; fitted to
                   // the code objects of round 2 (box, T = 2: P = 16 -> 180, P = 20 -> 212)
     return (3 * c.nwin + 1 + c.nwin - c.T) * P * words + 52 + P;
@@ -78,6 +78,8 @@ static void star_finish_cfg(StarCfg& c, const Program& P, int T) {
   c.ktiled = (tkh != P.n[2]);
   c.HK = c.ktiled ? hk : 0;
   c.NKT = c.ktiled ? (int)((P.n[2] + (tkh - 2 * c.HK) - 1) / (tkh - 2 * c.HK)) : 1;
+  // wide stars: the k-tiles share the row evenly (kernels/wstar3d.h: SF_TKI)
+  c.TKI = (c.R == 2 && c.ktiled) ? std::min<int>((int)(tkh - 2 * c.HK), round_up((int)((P.n[2] + c.NKT - 1) / c.NKT), c.VK)) : 0;
   if (c.noj) {
     c.NJT = 1;
   } else {
