@@ -13,11 +13,14 @@ literals, while the reference's CPU program is DaCe-generated C++.  So
   operand order, chain mechanics and dtype casts of the float32 path on data
   that come from the reference;
 * the oracle under its own contract (C++ typing: DESIGN.md §2) and the HIP
-  backend must agree with the vectors to within the tolerance BASELINE.json's
-  north_star states, 1e-6 relative -- measured against the largest magnitude of
-  the field (a single operator differs from NumPy's typing by at most one
-  float32 rounding of a sum; for results that cancel to ~0 "relative to the
-  result" is not meaningful);
+  backend must agree with the vectors PER POINT to within the tolerance
+  BASELINE.json's north_star states, 1e-6 relative (round 3; rounds 1-2 scaled by
+  the field's maximum): relative to the point's own value wherever that is
+  meaningful, and -- for the five float32 programs on signed random data listed in
+  CANCELLING, whose sums cancel to ~0 at some points (a float32 sum of O(1)
+  operands that comes out at 1e-3 cannot be right to 1e-6 of ITSELF under a
+  different rounding of that sum) -- relative to the largest magnitude among the
+  point and its nearest neighbours, where the last operator's operands live;
 * programs whose arithmetic is exact in float32 (``*_exact``, the fork/join and
   the float64 program) must agree bit for bit under both typings.
 """
@@ -31,6 +34,9 @@ from oracle import c_oracle, numpy_oracle as npo
 
 TOL = 1e-6  # BASELINE.json north_star: "within 1e-6 relative for float32"
 BIT_EXACT_UNDER_BOTH_TYPINGS = {"f32_jacobi7_exact", "mixed_to_f64", "f32_box_exact", "f32_fork_join"}
+# signed random float32 data: some results cancel to ~0 (per-point error relative to the result itself up to 2.7e-5,
+# relative to the operands' magnitude at most 2.8e-7)
+CANCELLING = {"f32_chain2", "f32_chain8", "f32_jacobi7", "f32_weighted_bc", "f32_hotspot2"}
 
 
 def _vectors(golden_dir):
@@ -49,9 +55,15 @@ def _expected(entry):
     return {k: np.array(v["values"], dtype=v["dtype"]).reshape(dims) for k, v in entry["result"].items()}
 
 
-def _within_tolerance(expected, got):
-    scale = float(np.abs(expected).max())
-    return float(np.abs(expected.astype(np.float64) - got.astype(np.float64)).max()) <= TOL * scale
+def _within_tolerance(expected, got, name=None):
+    """Per point: |difference| <= TOL x the point's own magnitude; for the named cancelling programs
+    TOL x the largest magnitude among the point and its nearest neighbours."""
+    from scipy.ndimage import maximum_filter
+    e, g = expected.astype(np.float64), got.astype(np.float64)
+    if name is not None and name not in CANCELLING:
+        return npo.max_rel_err(expected, got) <= TOL
+    scale = maximum_filter(np.maximum(np.abs(e), np.abs(g)), size=3, mode="nearest")
+    return bool(np.all(np.abs(e - g) <= TOL * scale))
 
 
 def test_fixture_inventory(golden_dir):
@@ -75,7 +87,7 @@ def test_oracle_reproduces_the_reference_simulator(golden_dir, name):
         if name in BIT_EXACT_UNDER_BOTH_TYPINGS:
             assert np.array_equal(own[out], exp), (name, out)
         else:
-            assert _within_tolerance(exp, own[out]), (name, out)
+            assert _within_tolerance(exp, own[out], name), (name, out)
 
 
 def _c1(golden_dir, programs_dir, tag):
@@ -117,7 +129,7 @@ def test_hip_against_the_reference_simulator(golden_dir, tmp_path, name):
         if name in BIT_EXACT_UNDER_BOTH_TYPINGS:
             assert np.array_equal(got[out], exp), (name, out)  # HIP == reference, bit for bit
         else:
-            assert _within_tolerance(exp, got[out]), (name, out)
+            assert _within_tolerance(exp, got[out], name), (name, out)
 
 
 @pytest.mark.gpu
@@ -152,7 +164,7 @@ def test_oracle_reproduces_the_reference_simulator_on_chains(golden_dir, name):
     if expected.dtype == np.float64:
         assert np.array_equal(own, expected)
     else:
-        assert _within_tolerance(expected, own)
+        assert _within_tolerance(expected, own, name)
 
 
 @pytest.mark.gpu
@@ -178,4 +190,4 @@ def test_hip_against_the_reference_simulator_on_chains(golden_dir, tmp_path, nam
     if exp.dtype == np.float64:
         assert np.array_equal(got[out], exp)
     else:
-        assert _within_tolerance(exp, got[out])
+        assert _within_tolerance(exp, got[out], name)
