@@ -4,7 +4,8 @@ plane-streaming kernel handles) on random, awkward domain sizes, each compared
 bit for bit with the oracle.  Only + - * and selects, so every implementation
 must agree exactly.  Prints one JSON line per failing program.
 
-usage: star_fuzz.py [--seeds 300] [--first 0] [--options "k1.rev=1"]"""
+usage: star_fuzz.py [--seeds 300] [--first 0] [--options "k1.rev=1"] [--generator star|wide]
+(--generator wide: chains of radius-2 stars, kernels/wstar3d.h; fusion depth 1-3)"""
 import argparse
 import json
 import os
@@ -20,7 +21,7 @@ from stencilflow_amd.backend import Plan  # noqa: E402
 from stencilflow_amd.lowering import lower  # noqa: E402
 from oracle import numpy_oracle as npo  # noqa: E402
 
-from tests.random_programs import star_program  # noqa: E402
+from tests.random_programs import star_program, wide_program  # noqa: E402
 
 
 def main():
@@ -29,15 +30,17 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--options", default="")
     ap.add_argument("--dump", type=int, default=-1, help="print the program of one seed and exit")
+    ap.add_argument("--generator", choices=["star", "wide"], default="star")
     args = ap.parse_args()
+    make = wide_program if args.generator == "wide" else star_program
     if args.dump >= 0:
-        print(json.dumps(star_program(args.dump), indent=1))
+        print(json.dumps(make(args.dump), indent=1))
         return
     base = {k: v for k, v in (kv.split("=") for kv in args.options.split(";") if kv)}
     nfail = nstar = nlaunch = 0
     with tempfile.TemporaryDirectory() as tmp:
         for seed in range(args.first, args.first + args.seeds):
-            prog = star_program(seed)
+            prog = make(seed)
             rng = np.random.default_rng(seed + 7)
             p = npo.load_program(prog)
             ins, arrays, scal = {}, [], {}
@@ -51,7 +54,7 @@ def main():
             want = npo.run_reference(prog, inputs=ins)
             path = programs.write_program(prog, os.path.join(tmp, "p.json"))
             chain = sf.KernelChainGraph(path)
-            opt = dict(base, fuse=int(rng.integers(1, 5)))
+            opt = dict(base, fuse=int(rng.integers(1, 4 if args.generator == "wide" else 5)))
             try:
                 plan = Plan(lower(chain), options=opt)
             except Exception as exc:  # noqa: BLE001
@@ -59,7 +62,7 @@ def main():
                 print(json.dumps({"seed": seed, "error": str(exc)[:300]}), flush=True)
                 continue
             desc = plan.describe()
-            nstar += desc.count("[star")
+            nstar += desc.count("[star") + desc.count("[wide star")
             if (seed - args.first + 1) % 100 == 0:  # a long run must keep writing
                 print("# %d programs, %d failures so far" % (seed - args.first + 1, nfail), flush=True)
             nlaunch += plan.num_launches
