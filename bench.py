@@ -232,6 +232,13 @@ def make_workload(name, size, stages, slab_world=1):
         return dict(prog=prog, shape=shape, np_dtype=np.float32, dtype="f32", bpu=8.0, stages=stages, name=name,
                     label="27-point box {}^3 float32 (bin/synthesize.py -stencil_shape box), {}-operator chain".format(
                         n, stages))
+    if name == "wide":
+        n = size or 512
+        shape = (n, n, n)
+        prog, _ = programs.synthesize("float32", stages, 0.0, n, n, n, 2, 2, 2)
+        return dict(prog=prog, shape=shape, np_dtype=np.float32, dtype="f32", bpu=8.0, stages=stages, name=name,
+                    label="radius-2 cross {}^3 float32 (bin/synthesize.py, extents 2 2 2), {}-operator chain".format(
+                        n, stages))
     if name == "c5":
         n = size or 512
         shape = (n, n, n)
@@ -644,11 +651,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c3", "c2", "c5", "box"], default="c3",
+    ap.add_argument("--workload", choices=["c3", "c2", "c5", "box", "wide"], default="c3",
                     help="c3 = jacobi3d 512^3 f32 (headline, default); c2 = "
                     "jacobi2d 4096^2 f32; c5 = diffusion/advection/laplacian "
-                    "512^3 f64; box = the generator's 27-point box chain 512^3 f32 "
-                    "(own records; single GPU only)")
+                    "512^3 f64; box / wide = the generator's 27-point box chain / radius-2 cross "
+                    "chain 512^3 f32 (own records; single GPU only)")
     ap.add_argument("--size", type=int, default=0)
     ap.add_argument("--stages", type=int, default=1000)
     ap.add_argument("--options", type=str, default="")

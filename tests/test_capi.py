@@ -248,3 +248,27 @@ def test_slab_halo_must_cover_the_reach_of_a_rank_with_neighbours(tmp_path):
         assert plan.num_launches == 2
     with backend.Plan(sfir, options={"fuse": 2, "slab": "0:32:0"}) as plan:
         assert plan.num_launches == 2
+
+
+def test_round3_entry_points_without_a_device(tmp_path):
+    """The entry points added in round 3, as far as they go without a GPU: the RCCL id comes from
+    librccl through dlopen (or the call says why it cannot), argument checks return statuses, a fresh
+    plan's fused kernels carry no self-check verdict, profiling can be toggled before the first use."""
+    import ctypes
+    lib = backend.load_library()
+    buf = ctypes.create_string_buffer(backend.HALO_RCCL_ID_BYTES)
+    rc = lib.sf_halo_rccl_id(buf)
+    assert rc == 0 or (rc == -2 and b"librccl" in lib.sf_last_error())
+    if rc == 0:
+        assert any(buf.raw)  # an ncclUniqueId is not all zeros
+    assert lib.sf_halo_rccl_id(None) == -1
+    assert lib.sf_halo_transport(None) is None
+    assert lib.sf_halo_configure(None, 0, 0) == -1 and b"sf_halo_configure" in lib.sf_last_error()
+    assert lib.sf_halo_use_rccl(None, buf, 0, 1) == -1
+    assert lib.sf_self_checks_run() >= 0
+    path = programs.write_program(programs.jacobi3d((24, 40, 72), 4, bc_value=0.375), str(tmp_path / "p.json"))
+    with backend.Plan(lower(sf.KernelChainGraph(path))) as plan:
+        assert set(plan.kernel_verdicts().values()) == {0}
+        plan.set_profile(True)
+        plan.set_profile(False)
+        assert all(v == 0.0 for v in plan.kernel_planes().values())

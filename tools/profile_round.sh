@@ -9,19 +9,21 @@ set -u
 tag=${1:-r01}
 export TMPDIR=/tmp
 # workloads: c3 c2 c5 = the bench workloads; box = the generator's 27-point chain (compact
-# kernel); generic = c3 forced onto the generic operator kernel (16 / 40 operators)
-for wl in ${SF_PROFILE_WORKLOADS:-c3 c2 c5 box generic}; do
+# kernel); wide = its radius-2 cross chain (wide-star kernel); generic = c3 forced onto the
+# generic operator kernel (16 / 40 operators)
+for wl in ${SF_PROFILE_WORKLOADS:-c3 c2 c5 box wide generic}; do
   out=gpurun_out/prof_${tag}_$wl
   rm -rf $out; mkdir -p $out
   case $wl in
     box) base="--workload box --stages 16"; short="--workload box --stages 16";;
+    wide) base="--workload wide --stages 16"; short="--workload wide --stages 16";;
     generic) base="--workload c3 --stages 40 --options generic_only=1"; short="--workload c3 --stages 40 --options generic_only=1";;
     *) base="--workload $wl"; short="--workload $wl --stages 100";;
   esac
-  args="bench.py $short --steps 1 --warmup 0 --no-cpu-baseline"
+  args="bench.py $short --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs"
   # the trace pass runs the bench command itself (default steps / warm-up), so its
   # average kernel duration is the one the bench line reports
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $base --no-cpu-baseline > $out/trace.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $base --no-cpu-baseline --no-other-configs > $out/trace.log 2>&1
   i=0
   for pmc in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
     i=$((i+1))
