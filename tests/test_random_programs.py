@@ -15,7 +15,7 @@ from stencilflow_amd.lowering import lower
 from tests.random_programs import random_inputs, random_program
 
 CPU_SEEDS = list(range(100, 124))
-GPU_SEEDS = list(range(100, 160))
+GPU_SEEDS = list(range(100, 148))  # (tools/*_fuzz.py run hundreds more per round: profiles/r0*_fuzz*.log)
 
 
 @pytest.fixture(autouse=True)
@@ -73,7 +73,7 @@ def test_hip_matches_oracle_on_random_programs(seed, tmp_path):
 
 
 STAR_CPU_SEEDS = list(range(0, 12))
-STAR_GPU_SEEDS = list(range(0, 48))
+STAR_GPU_SEEDS = list(range(0, 36))
 
 
 def _star_case(seed, tmp_path):
@@ -120,7 +120,7 @@ def test_hip_matches_oracle_on_random_star_chains(seed, tmp_path):
 
 
 WIDE_CPU_SEEDS = list(range(0, 8))
-WIDE_GPU_SEEDS = list(range(0, 40))
+WIDE_GPU_SEEDS = list(range(0, 28))
 
 
 def _wide_case(seed, tmp_path):
@@ -209,7 +209,7 @@ def test_random_wide_star_chains_under_slab_decomposition(seed, tmp_path):
 
 
 COMPACT_CPU_SEEDS = list(range(0, 6))
-COMPACT_GPU_SEEDS = list(range(0, 40))
+COMPACT_GPU_SEEDS = list(range(0, 30))
 
 
 def _compact_case(seed, tmp_path):
