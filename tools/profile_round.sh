@@ -11,6 +11,15 @@ export TMPDIR=/tmp
 # (the plan-time self-check launches every new fused kernel twice on a few planes: such dispatches
 # would enter the per-kernel means of duration and traffic; the code objects are the same without it)
 export SF_HIP_SELF_CHECK=0
+# The profiler preloads /opt/rocm's libamd_comgr, and hipRTC (PyTorch's copy, the one a plain
+# `python bench.py` uses) then compiles through THAT compiler instead of the one bundled with it:
+# same source, same kernel name, another code object -- for C5 even another tile shape (the 7.2
+# compiler spills at five rows per thread, round 3).  Preloading PyTorch's comgr keeps the profiled
+# objects the ones the product runs.  SF_PROFILE_SYSTEM_COMGR=1 turns this off.
+if [ "${SF_PROFILE_SYSTEM_COMGR:-0}" != "1" ]; then
+  torch_comgr=$(python3 -c "import os, torch; print(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamd_comgr.so'))" 2>/dev/null)
+  [ -f "$torch_comgr" ] && export LD_PRELOAD="$torch_comgr${LD_PRELOAD:+:$LD_PRELOAD}"
+fi
 # workloads: c3 c2 c5 = the bench workloads; box = the generator's 27-point chain (compact
 # kernel); wide = its radius-2 cross chain (wide-star kernel); generic = c3 forced onto the
 # generic operator kernel (16 / 40 operators)
