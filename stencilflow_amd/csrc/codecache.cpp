@@ -5,6 +5,7 @@
 #include <amd_comgr/amd_comgr.h>
 #include <hip/hiprtc.h>
 
+#include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -210,9 +211,16 @@ static std::string disk_cache_path(const std::string& key) {
   int major = 0, minor = 0, runtime = 0;
   hiprtcVersion(&major, &minor);
   (void)hipRuntimeGetVersion(&runtime);
+  // ... and the comgr the process really compiles through: hipRTC calls whichever libamd_comgr was
+  // loaded first (PyTorch's bundled copy, or ROCm's when a profiler preloads it) -- same versions
+  // reported, different compilers (round 3: C5's five-row tile spills under one of them)
+  Dl_info comgr_lib;
+  const char* comgr_path = (::dladdr(reinterpret_cast<void*>(&amd_comgr_get_version), &comgr_lib) && comgr_lib.dli_fname)
+                               ? comgr_lib.dli_fname
+                               : "?";
   const std::string salted = key + "\nhiprtc " + std::to_string(major) + "." + std::to_string(minor) +
-                             " runtime " + std::to_string(runtime) + " build " + HIP_VERSION_GITHASH +
-                             "\ngfx950 -O3 -std=c++17 -ffp-contract=off";
+                             " runtime " + std::to_string(runtime) + " build " + HIP_VERSION_GITHASH + " comgr " +
+                             comgr_path + "\ngfx950 -O3 -std=c++17 -ffp-contract=off";
   char name[40];
   std::snprintf(name, sizeof name, "%016llx%08x", (unsigned long long)fnv1a(salted), (unsigned)salted.size());
   return dir + "/" + name + ".co";
