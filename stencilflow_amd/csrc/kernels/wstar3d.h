@@ -28,7 +28,7 @@
 //   alternate, so there is ONE barrier per step.
 //
 // Macros from codegen: SF_T SF_VK SF_RJ SF_BX SF_BY SF_HK SF_KTILED SF_NOJ SF_N0G SF_N1
-//   SF_N2 SF_NJT SF_NKT SF_NT SF_ROW_FENCE SF_KERNEL_NAME; typedef sf_t; struct sf_scalars;
+//   SF_N2 SF_NJT SF_NKT SF_NT SF_ROW_FENCE SF_OPAQUE SF_KERNEL_NAME; typedef sf_t; struct sf_scalars;
 //   struct sf_nb; template<int S> struct sf_stage {bc(), bc_zero, apply()}.
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
@@ -316,6 +316,21 @@ template <int PH>
 __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, sf_t* __restrict__ out, const sf_scalars& sc,
                                         const sf_ctx& cx, const int p, const int p_end) {
   constexpr int ic = (PH + 3) % SF_W;
+  // Make the windows opaque at the step boundary: where the program's typing turns every neighbour
+  // into a double (a float boundary literal) the compiler otherwise keeps the
+  // conversions of whole planes alive from one unrolled step to the next -- twice the registers
+  // (star3d.h: SF_OPAQUE).  The row in flight (the newest input plane) is left alone.
+#if SF_OPAQUE
+#pragma unroll
+  for (int s = 0; s < SF_T; ++s)
+#pragma unroll
+    for (int w = 0; w < SF_W; ++w)
+#pragma unroll
+      for (int r = 0; r < SF_RJ; ++r) {
+        if (s == 0 && w == PH) continue;  // loaded during the previous step: no wait here
+        asm volatile("" : "+v"(st.w[s][w][r]));
+      }
+#endif
   // publish what other threads need of every window's centre plane (complete since two steps)
   if constexpr (SF_USE_LDS) {
 #pragma unroll

@@ -16,7 +16,7 @@ literals, while the reference's CPU program is DaCe-generated C++.  So
   backend must agree with the vectors PER POINT to within the tolerance
   BASELINE.json's north_star states, 1e-6 relative (round 3; rounds 1-2 scaled by
   the field's maximum): relative to the point's own value wherever that is
-  meaningful, and -- for the five float32 programs on signed random data listed in
+  meaningful, and -- for the float32 programs on signed random data listed in
   CANCELLING, whose sums cancel to ~0 at some points (a float32 sum of O(1)
   operands that comes out at 1e-3 cannot be right to 1e-6 of ITSELF under a
   different rounding of that sum) -- relative to the largest magnitude among the
@@ -36,7 +36,7 @@ TOL = 1e-6  # BASELINE.json north_star: "within 1e-6 relative for float32"
 BIT_EXACT_UNDER_BOTH_TYPINGS = {"f32_jacobi7_exact", "mixed_to_f64", "f32_box_exact", "f32_fork_join"}
 # signed random float32 data: some results cancel to ~0 (per-point error relative to the result itself up to 2.7e-5,
 # relative to the operands' magnitude at most 2.8e-7)
-CANCELLING = {"f32_chain2", "f32_chain8", "f32_jacobi7", "f32_weighted_bc", "f32_hotspot2"}
+CANCELLING = {"f32_chain2", "f32_chain8", "f32_jacobi7", "f32_weighted_bc", "f32_hotspot2", "f32_wide_cross2"}
 
 
 def _vectors(golden_dir):
@@ -188,6 +188,63 @@ def test_hip_against_the_reference_simulator_on_chains(golden_dir, tmp_path, nam
     assert got[out].dtype == exp.dtype
     assert np.array_equal(got[out], own[out])
     if exp.dtype == np.float64:
+        assert np.array_equal(got[out], exp)
+    else:
+        assert _within_tolerance(exp, got[out], name)
+
+
+# ---- radius-2 stars (tests/golden/simulator_wide.json, round 3): what pins kernels/wstar3d.h
+# against the reference itself -----------------------------------------------------------------
+WIDE = ["f32_wide_cross_exact", "f32_wide_cross2", "f64_wide_diffusion"]
+WIDE_BIT_EXACT = {"f32_wide_cross_exact", "f64_wide_diffusion"}
+
+
+def _wide(golden_dir, name):
+    with open(os.path.join(golden_dir, "simulator_wide.json")) as f:
+        doc = json.load(f)
+    assert "Simulator" in doc["source"]
+    return doc["programs"][name]
+
+
+@pytest.mark.parametrize("name", WIDE)
+def test_oracle_reproduces_the_reference_simulator_on_radius_2_stars(golden_dir, name):
+    """The operators the reference's generator emits for an extent of 2 (bin/synthesize.py:19-31),
+    evaluated by the reference's Simulator: bit for bit under its typing; under the contract's
+    bit for bit where float32 arithmetic is exact and in float64, per point within 1e-6 otherwise;
+    NumPy and C restatements equal."""
+    entry = _wide(golden_dir, name)
+    (out, exp), = _expected(entry).items()
+    assert np.array_equal(npo.run_reference(entry["program"], typing="nep50")[out], exp)
+    own = npo.run_reference(entry["program"])[out]
+    assert np.array_equal(c_oracle.CompiledReference(entry["program"]).run()[out], own)
+    if name in WIDE_BIT_EXACT:
+        assert np.array_equal(own, exp)
+    else:
+        assert _within_tolerance(exp, own, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", WIDE)
+@pytest.mark.parametrize("options", [None, {"fuse": 1}, {"generic_only": 1}, {"k1.bx": 64, "k1.by": 2, "k1.rj": 4}])
+def test_hip_against_the_reference_simulator_on_radius_2_stars(golden_dir, tmp_path, name, options):
+    """The HIP path on the same vectors: the fused wide-star kernel (two operators per launch for
+    the chain), one operator per launch, the generic kernel, and a pinned tile with thread rows
+    that exchange two rows through LDS -- equal to the oracle bit for bit, to the reference bit for
+    bit where arithmetic is exact / float64 and per point within 1e-6 otherwise."""
+    from tests.test_gpu_parity import _inputs_of, _run_gpu
+    entry = _wide(golden_dir, name)
+    path = str(tmp_path / (name + ".json"))
+    with open(path, "w") as f:
+        json.dump(entry["program"], f)
+    ins = _inputs_of(path)
+    got, plan_text = _run_gpu(path, ins, options=options)
+    if not (options or {}).get("generic_only"):
+        assert "[wide star" in plan_text
+    own = npo.run_reference(path, inputs=ins)
+    (out, exp), = _expected(entry).items()
+    assert got[out].dtype == exp.dtype
+    assert np.array_equal(got[out], own[out])
+    if name in WIDE_BIT_EXACT:
         assert np.array_equal(got[out], exp)
     else:
         assert _within_tolerance(exp, got[out], name)
