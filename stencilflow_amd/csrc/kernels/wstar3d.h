@@ -364,7 +364,10 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, sf_t* __restric
   sf_later_stages<2, PH>(st, lds, sc, out, cx, p);
 }
 
-extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
+// (two waves per SIMD at least: a block of one or two waves -- small grids -- would otherwise be
+// compiled for 512 registers per lane and spread into the AGPR file, which the planner reads as a
+// slow object)
+extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY, 2)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, sf_auxptrs aux, int halo,
                    int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2) {
   (void)aux;
