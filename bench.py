@@ -30,7 +30,8 @@ bin/run_distributed_program.py:98-100,283-299).  Rank 0 prints ONE JSON line
                     bandwidth.
 At N = 1 the line also carries `cpu_baseline` (the oracle's C/OpenMP port on the
 host cores) and `other_configs`: BASELINE.json's configs[1] (jacobi2d 4096^2) and
-configs[4] (the fused f64 chain), timed the same way for a few steps each.
+configs[4] (the fused f64 chain), timed the same way for a few steps each, plus two
+workloads of the reference's generator on the other fused kernel families.
 
 N > 1: the halo transport is chosen from a ladder -- the
 library's own RCCL rung (ncclSend / ncclRecv issued by libsf_hip.so), its
@@ -727,8 +728,11 @@ def main():
             # a few steps each (about 25 ms and 45 ms of GPU time per step; a step of c5 is 100
             # applications of the fused chain back to back -- a lone 0.4-ms launch between two
             # synchronisations runs 20 % slower than the same launch in a stream of launches)
+            # ... and two workloads of the reference's generator (bin/synthesize.py) that exercise the other
+            # fused kernel families: the 27-point box chain (compact3d.h) and the radius-2 cross chain
+            # (wstar3d.h), 16 operators each
             others = []
-            for name, stages, steps in (("c2", 1000, 3), ("c5", 300, 3)):
+            for name, stages, steps in (("c2", 1000, 3), ("c5", 300, 3), ("box", 16, 5), ("wide", 16, 5)):
                 owl = make_workload(name, 0, stages)
                 t = time_single(owl, {}, steps, 1, device=local_rank)
                 others.append({"workload": owl["label"], "value": t["value"], "unit": "Mcells/s", "steps": steps,
