@@ -575,27 +575,32 @@ class Decomposed:
             runner, ex = self.make_runner(self.sfir, rung, groups)
             best["runner"], best["ex"] = runner, ex
         best["groups"] = groups
-        t_exchange = t_deep if groups == 8 else t_half
-        env_early = os.environ.get("SF_BENCH_EARLY_EXCHANGE")
-        runner.early_exchange = (env_early == "1") if env_early in ("0", "1") else t_exchange > 0.85 * t_launch
-        self.notes.append("exchange alone {:.0f} us ({} planes) / {:.0f} us ({} planes), launch group {:.0f} us -> {}".format(
-            t_deep * 1e6, deep, t_half * 1e6, max(1, deep // 2), t_launch * 1e6,
-            "started a launch ahead" if runner.early_exchange else "started with the launch that needs it"))
-        # Compute units left to the exchange's copy kernels by the launch that runs beside
-        # them (RCCL rungs only): with them a copy kernel never waits for a 200-us block to
-        # retire, without them that launch is ~12 % shorter.  Both are timed.
-        default_cus = int(getattr(ex, "reserved_cus", 0))
-        env_cus = os.environ.get("SF_BENCH_RESERVED_CUS")
-        if default_cus > 0 and env_cus is None:
-            timing = {}
-            for cus in (default_cus, 0):
-                ex.reserved_cus = cus
-                timing[cus] = self.chain_seconds(runner, best["native"])
-            ex.reserved_cus = min(timing, key=timing.get)
-            self.notes.append("{} units reserved beside an exchange ({})".format(
-                ex.reserved_cus, ", ".join("{}: {:.2f} ms".format(k, v * 1e3) for k, v in timing.items())))
-        elif default_cus > 0:
-            ex.reserved_cus = int(env_cus)
+        self.notes.append("exchange alone {:.0f} us ({} planes) / {:.0f} us ({} planes), launch group {:.0f} us".format(
+            t_deep * 1e6, deep, t_half * 1e6, max(1, deep // 2), t_launch * 1e6))
+        # Two refinements of the schedule, decided by timing whole chain executions (an exchange timed
+        # alone says nothing about copies that queue behind a compute kernel holding every unit):
+        #  - the exchange started a launch ahead (two interiors of cover for a slow transfer, +4 % of
+        #    driver overhead on one GPU);
+        #  - compute units left free beside an exchange (for RCCL's copy kernels, or for blit kernels
+        #    where a DMA push is not served by the copy engines; that launch is ~12 % longer).
+        env_early, env_cus = os.environ.get("SF_BENCH_EARLY_EXCHANGE"), os.environ.get("SF_BENCH_RESERVED_CUS")
+        earlies = [env_early == "1"] if env_early in ("0", "1") else [False, True]
+        device_side = rung in ("rccl", "p2p", "torch")
+        cuses = [int(env_cus)] if env_cus is not None else ([0, 32] if device_side else [0])
+        timing = {}
+        for early in earlies:
+            for cus in cuses:
+                runner.early_exchange = early
+                if hasattr(ex, "reserved_cus"):
+                    ex.reserved_cus = cus
+                timing[(early, cus)] = self.chain_seconds(runner, best["native"])
+        early, cus = min(timing, key=timing.get)
+        runner.early_exchange = early
+        if hasattr(ex, "reserved_cus"):
+            ex.reserved_cus = cus
+        self.notes.append("exchange {}, {} units reserved beside it ({})".format(
+            "started a launch ahead" if early else "started with the launch that needs it", cus,
+            ", ".join("{}/{}: {:.2f} ms".format("ahead" if e else "with", c, v * 1e3) for (e, c), v in timing.items())))
         # the library's own schedule against SlabRunner's Python form of it (A/B)
         if rung in ("rccl", "p2p") and os.environ.get("SF_BENCH_SCHEDULE") is None:
             timing = {"native": self.chain_seconds(runner, True), "python": self.chain_seconds(runner, False)}
