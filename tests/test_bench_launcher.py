@@ -77,3 +77,36 @@ def test_plain_command_two_ranks_on_this_gpu():
                 "per_gpu_mcells_per_s", "undivided_mcells_per_s", "per_gpu_vs_undivided"):
         assert key in roof, key
     assert roof["bound"] == "hbm" and 0 < roof["frac"] <= 1 and roof["per_gpu_vs_undivided"] > 0
+
+
+def test_synthetic_grid_is_the_same_from_any_rank():
+    """The global synthetic input of a decomposed run: 64-plane blocks seeded by (SEED, block), so a
+    rank can produce its own slab AND the planes of its neighbours it needs for the untimed check
+    (bench.py: synthetic_planes; DecompositionCheck recomputes a slab from them)."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("bench_module", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    whole = bench.synthetic_planes(0, 200, (3, 8))
+    assert whole.shape == (200, 3, 8) and whole.dtype == np.float32 and 0.0 <= whole.min() and whole.max() < 1.0
+    for lo, hi in [(0, 64), (60, 70), (63, 65), (128, 200), (199, 200), (5, 5)]:
+        assert np.array_equal(bench.synthetic_planes(lo, hi, (3, 8)), whole[lo:hi])
+    assert not np.array_equal(whole[0:64], whole[64:128])  # blocks differ
+    assert np.array_equal(bench.synthetic((200, 3, 8)), whole)
+
+
+def test_roofline_block_arithmetic():
+    """frac = bytes per full launch x full launches / seconds / 8 TB/s; the algorithmic figure
+    counts 2 * sizeof(dtype) per update and may exceed 1 for fused launches."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module2", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    wl = {"bpu": 8.0}
+    r = bench.roofline_block("k", 1.1036e9, 1.1036e9, 0.1, 500.0, 500, wl, 2.0, 2 * 512.0**3)
+    assert r["basis"] == "pmc" and abs(r["avg_launch_us"] - 200.0) < 1e-9
+    assert abs(r["frac"] - 1.1036e9 / 200e-6 / 8e12) < 1e-12 and r["frac"] < 1
+    assert abs(r["algorithmic_frac"] - 2 * 512.0**3 * 8 / 200e-6 / 8e12) < 1e-12 and r["algorithmic_frac"] > 1
+    r = bench.roofline_block("k", 1.0737e9, None, 0.1, 500.0, 500, wl, 2.0, 2 * 512.0**3)
+    assert r["basis"] == "compulsory" and r["traffic"] is None
