@@ -208,6 +208,42 @@ def test_random_wide_star_chains_under_slab_decomposition(seed, tmp_path):
         r.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,cols,options", [(403, 520, {"fuse": 2}), (408, 776, {"fuse": 2}), (419, 520, {"fuse": 3}),
+                                                (428, 520, {"fuse": 1, "k1.bx": 128, "k1.by": 2, "k1.rj": 4}),
+                                                (418, 1032, {"fuse": 1, "k1.bx": 256, "k1.by": 2, "k1.rj": 3}),
+                                                (425, 520, {"fuse": 2, "k1.bx": 128, "k1.by": 4, "k1.rj": 3}),
+                                                (423, 300, {"fuse": 2}), (409, 1100, {"fuse": 2})])
+def test_wide_star_chains_on_rows_wider_than_a_tile(seed, cols, options, tmp_path):
+    """Rows that are cut into several k-tiles of equal useful width (kernels/wstar3d.h: SF_TKI) and
+    thread rows of two and four waves, whose edge elements travel through LDS with virtual waves at
+    the row ends -- the paths the small random grids never reach."""
+    from tests.random_programs import wide_program
+    prog = wide_program(seed)
+    if len(prog["dimensions"]) == 3:
+        prog["dimensions"] = [max(9, min(prog["dimensions"][0], 14)), max(10, min(prog["dimensions"][1], 26)), cols]
+    else:
+        prog["dimensions"] = [max(12, min(prog["dimensions"][0], 40)), cols]
+    rng = np.random.default_rng(seed + 17)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    want = npo.run_reference(prog, inputs=ins)
+    chain = sf.KernelChainGraph(programs.write_program(prog, str(tmp_path / "p.json")))
+    if len(prog["dimensions"]) == 2:
+        options = {k: v for k, v in options.items() if k == "fuse"}
+    with Plan(lower(chain), options=options) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]]) for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
+
+
 COMPACT_CPU_SEEDS = list(range(0, 6))
 COMPACT_GPU_SEEDS = list(range(0, 30))
 
