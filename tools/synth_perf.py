@@ -46,6 +46,9 @@ def main():
         ("wide diffusion 3-D f32 (radius 2)", ("float32", st, 0.0, n, n, n, 2, 2, 2), {"stencil_shape": "diffusion"}),
         ("wide cross 3-D f64 (radius 2)", ("float64", st, 0.0, n, n, n, 2, 2, 2), {}),
         ("wide cross 2-D f32 (radius 2)", ("float32", st, 0.0, 8 * n, 8 * n, 0, 2, 2, 0), {}),
+        # radius-2 boxes (125 / 25 points): no fused kernel, one generic launch per operator
+        ("big box 3-D f32 (radius 2, 125 points)", ("float32", min(st, 4), 0.0, n, n, n, 2, 2, 2), {"stencil_shape": "box"}),
+        ("big box 2-D f32 (radius 2, 25 points)", ("float32", min(st, 8), 0.0, 8 * n, 8 * n, 0, 2, 2, 0), {"stencil_shape": "box"}),
     ]
     rng = np.random.default_rng(5)
     with tempfile.TemporaryDirectory() as tmp:
