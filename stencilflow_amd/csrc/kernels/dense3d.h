@@ -1,0 +1,211 @@
+// dense3d.h — one operator with a DENSE neighbourhood (any subset of the offsets
+// {-2..2}^3 of one field: the 125-point box the reference's generator emits for an extent
+// of 2, bin/synthesize.py:19-31,91-104 `box`; 25 points in 2-D) per launch, with the (j,k)
+// tile of every plane staged in LDS (CDNA4 / gfx950, wave64).  Compiled at plan creation
+// by hipRTC with the macros and the `sf_dense` functor emitted by codegen (gen_dense).
+//
+// Why not the register windows of star3d.h / compact3d.h: with 25 neighbours per plane most
+// of a point's operands live in OTHER threads' registers; here every plane of the tile is in
+// LDS once and every thread reads its (RJ + 2R) x (VK + 2R) patch from there -- the "2.5-D
+// LDS plane tiling" of the literature.  Semantics per point as ExpandStencilCPU
+// (stencilflow/stencil/cpu.py:58-115): out-of-domain reads yield the boundary constant --
+// the tile is padded with it at GLOBAL coordinates when it is written to LDS; the sum is
+// evaluated in the order of the program text (the functor is the text).
+//
+// Decomposition
+//   block  = tile of TJ x TK output points of the (j,k) plane (TJ = BY * RJ rows, TK = BX * VK
+//            columns), marching along i over one chunk of planes;
+//   LDS    = ring of SIX plane slots of (TJ + 2R) x (TK + 2R) elements: step p writes plane p
+//            into slot p mod 6 (its loads were issued a step earlier), ONE barrier, then output
+//            plane q = p - R is evaluated from the five slots q-R .. q+R; the slot written at
+//            step p + 1 holds plane p - 5, which nobody reads any more;
+//   thread = RJ rows x VK columns of outputs; the step loop is unrolled by six, so a slot
+//            index is a compile-time constant and every LDS address is one per-thread base
+//            plus an immediate offset.
+//
+// Macros from codegen: SF_R SF_VK SF_RJ SF_BX SF_BY SF_NOJ SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_NT
+//   SF_NLOADS SF_KERNEL_NAME; typedef sf_t; struct sf_scalars; struct sf_auxptrs;
+//   struct sf_dense {bc(), bc_zero, template<int PH> apply_row(tb, r, sc, o)}: the VK outputs of one row,
+//   every row segment (VK + 2R elements of one (di, dj)) read from LDS as aligned 16-byte chunks.
+
+typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
+typedef sf_t sf_pair __attribute__((ext_vector_type(2)));
+#define SF_CE (16 / (int)sizeof(sf_t))  // elements of a 16-byte chunk
+typedef sf_t sf_chunk __attribute__((ext_vector_type(16 / sizeof(sf_t))));
+#define SF_SEG (SF_VK + 2 * SF_R)  // a row segment: the thread's VK columns and R more on either side
+typedef unsigned sf_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
+
+#define SF_SLOTS 6
+#define SF_OOB 0x80000000u
+#define SF_PLANE_ELEMS ((long long)SF_N1 * (long long)SF_N2)
+#define SF_PLANE_BYTES ((unsigned)(SF_PLANE_ELEMS * (long long)sizeof(sf_t)))
+#define SF_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format (gfx9 / CDNA) */
+
+#if SF_NOJ
+#define SF_TJ 1
+#define SF_RJH 0  // no row axis: no halo rows
+#else
+#define SF_TJ (SF_BY * SF_RJ)
+#define SF_RJH SF_R
+#endif
+#define SF_TK (SF_BX * SF_VK)
+#define SF_LROWS (SF_TJ + 2 * SF_RJH)
+#define SF_LS (SF_TK + 2 * SF_R)  // row stride of a slot (elements); TK is a multiple of 4, R <= 2: pairs stay 8-byte aligned
+#define SF_SLOT_ELEMS (SF_LROWS * SF_LS)
+#define SF_PAIRS_PER_ROW (SF_LS / 2)
+#define SF_PAIRS (SF_LROWS * SF_PAIRS_PER_ROW)
+#define SF_THREADS (SF_BX * SF_BY)
+
+// slot of plane q + di when the plane written this step (p = q + R) sits in slot PH
+#define SF_SLOT_OF(PH, di) (((PH) + (di) - SF_R + 2 * SF_SLOTS) % SF_SLOTS)
+
+template <typename V, int aux>
+__device__ __forceinline__ V sf_buf_load(const __amdgpu_buffer_rsrc_t rs, const unsigned off) {
+  if constexpr (sizeof(V) == 4) {
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, aux));
+  } else if constexpr (sizeof(V) == 8) {
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, aux));
+  } else {
+    static_assert(sizeof(V) == 16, "4, 8 or 16 bytes");
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, aux));
+  }
+}
+template <typename V, int aux>
+__device__ __forceinline__ void sf_buf_store(const V v, const __amdgpu_buffer_rsrc_t rs, const unsigned off) {
+  if constexpr (sizeof(V) == 8) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sf_u2, v), rs, off, 0, aux);
+  } else if constexpr (sizeof(V) == 16) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_u4, v), rs, off, 0, aux);
+  } else {
+    static_assert(sizeof(V) == 32, "8, 16 or 32 bytes");
+    struct Two { sf_u4 lo, hi; };
+    const Two two = __builtin_bit_cast(Two, v);
+    __builtin_amdgcn_raw_buffer_store_b128(two.lo, rs, off, 0, aux);
+    __builtin_amdgcn_raw_buffer_store_b128(two.hi, rs, off + 16u, 0, aux);
+  }
+}
+
+struct sf_ctx {
+  const sf_t* in;
+  int goff, halo, cb, ce;
+  // what this thread moves of every plane: SF_NLOADS pairs of elements (8 bytes for float, 16 for
+  // double) -- byte offset inside the plane (SF_OOB: outside the (j,k) domain, or no pair at
+  // all) and element index inside an LDS slot (-1: no pair)
+  unsigned ld_off[SF_NLOADS];
+  int ld_lds[SF_NLOADS];
+  unsigned st_off[SF_RJ];  // byte offset of the thread's output vector in row r, or SF_OOB
+  int tb;                  // LDS element index of the thread's patch origin (row -RJH, column -R of its outputs)
+};
+
+// the thread's pairs of input plane p, padded with the boundary constant outside the global domain
+__device__ __forceinline__ void sf_load_plane(const sf_ctx& cx, const int p, sf_pair (&dst)[SF_NLOADS], const bool enabled) {
+  const bool plane_ok = enabled && (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
+  const char* base = reinterpret_cast<const char*>(cx.in) + (long long)(p + cx.halo) * (long long)SF_PLANE_BYTES;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0,
+                                                                     plane_ok ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
+#pragma unroll
+  for (int n = 0; n < SF_NLOADS; ++n) {
+    sf_pair v = sf_buf_load<sf_pair, (SF_NT & 2) ? 2 : 0>(rs, cx.ld_off[n]);
+    if constexpr (!sf_dense::bc_zero) {
+      const bool ok = plane_ok && cx.ld_off[n] != SF_OOB;
+      v[0] = ok ? v[0] : sf_dense::bc();
+      v[1] = ok ? v[1] : sf_dense::bc();
+    }
+    dst[n] = v;
+  }
+}
+
+// One step: plane p (in `regs`) goes to slot PH, the loads of plane p + 1 are issued, output plane
+// q = p - R is evaluated and stored.
+template <int PH>
+__device__ __forceinline__ void sf_step(sf_t* lds, sf_pair (&regs)[SF_NLOADS], sf_t* __restrict__ out,
+                                        const sf_scalars& sc, const sf_ctx& cx, const int p, const int p_end) {
+#pragma unroll
+  for (int n = 0; n < SF_NLOADS; ++n)
+    if (cx.ld_lds[n] >= 0) *reinterpret_cast<sf_pair*>(&lds[PH * SF_SLOT_ELEMS + cx.ld_lds[n]]) = regs[n];
+  __syncthreads();
+  sf_load_plane(cx, p + 1, regs, p + 1 < p_end);  // lands during the evaluation below
+  const int q = p - SF_R;
+  const bool store_plane = q >= cx.cb && q < cx.ce && (q + cx.goff >= 0) && (q + cx.goff < SF_N0G);
+  char* base = reinterpret_cast<char*>(out) + (long long)(q + cx.halo) * (long long)SF_PLANE_BYTES;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(base, 0, store_plane ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
+  const sf_t* tb = lds + cx.tb;
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    sf_t row[SF_VK];
+    sf_dense::template apply_row<PH>(tb, r, sc, row);
+    sf_vec o;
+#pragma unroll
+    for (int v = 0; v < SF_VK; ++v) o[v] = row[v];
+    sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
+    __builtin_amdgcn_sched_barrier(0);  // rows in order: bounds the live row segments
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
+    SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, sf_auxptrs aux, int halo,
+                   int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2) {
+  (void)aux;
+  __shared__ sf_t lds[SF_SLOTS * SF_SLOT_ELEMS];
+
+  sf_ctx cx;
+  cx.in = in;
+  cx.goff = goff;
+  cx.halo = halo;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * SF_BX + tx;
+
+  // XCD-aware block order: consecutive logical tiles (adjacent in j) land on one XCD / L2
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int xq = nb >> 3, xr = nb & 7, xcd = b & 7;
+  const int L = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
+  const int jt = L % SF_NJT;
+  const int kt = (L / SF_NJT) % SF_NKT;
+  const int ch = L / (SF_NJT * SF_NKT);
+  if (ch < nch1) {
+    cx.cb = i_begin + ch * li;
+    cx.ce = (cx.cb + li < i_end) ? cx.cb + li : i_end;
+  } else {
+    cx.cb = i_begin2 + (ch - nch1) * li;
+    cx.ce = (cx.cb + li < i_end2) ? cx.cb + li : i_end2;
+  }
+  if (cx.cb >= cx.ce) return;
+
+  const int tj0 = SF_NOJ ? 0 : jt * SF_TJ, tk0 = kt * SF_TK;  // first output point of the tile
+  // the pairs this thread loads of every plane (row-major over the slot, pairs of columns)
+#pragma unroll
+  for (int n = 0; n < SF_NLOADS; ++n) {
+    const int pair = tid + n * SF_THREADS;
+    const int row = pair / SF_PAIRS_PER_ROW, col = (pair - row * SF_PAIRS_PER_ROW) * 2;
+    const int j = tj0 - SF_RJH + row, k = tk0 - SF_R + col;
+    const bool mine = pair < SF_PAIRS;
+    // (N2 is a multiple of 4 and R even or the tile origin a multiple of 4: a pair is inside or outside as a whole
+    //  for R = 2; for R = 1 the pair straddles the edge -- R is always 2 here, codegen enforces it)
+    const bool inside = mine && j >= 0 && j < SF_N1 && k >= 0 && k + 1 < SF_N2;
+    cx.ld_off[n] = inside ? (unsigned)((j * SF_N2 + k) * (int)sizeof(sf_t)) : SF_OOB;
+    cx.ld_lds[n] = mine ? row * SF_LS + col : -1;
+  }
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    const int j = tj0 + (SF_NOJ ? 0 : ty * SF_RJ + r), k = tk0 + tx * SF_VK;
+    const bool inside = j < SF_N1 && k + SF_VK <= SF_N2;
+    cx.st_off[r] = inside ? (unsigned)((j * SF_N2 + k) * (int)sizeof(sf_t)) : SF_OOB;
+  }
+  cx.tb = (SF_NOJ ? 0 : ty * SF_RJ) * SF_LS + tx * SF_VK;
+
+  // input planes [p_begin, p_end) are read; step p writes plane p into slot (p - p_begin) mod 6
+  const int p_begin = cx.cb - SF_R, p_end = cx.ce + SF_R;
+  sf_pair regs[SF_NLOADS];
+  sf_load_plane(cx, p_begin, regs, true);
+  // the slots of planes before p_begin are never read for a stored plane: the first stored plane is
+  // cb = p_begin + R, whose oldest operand plane is p_begin
+  for (int p = p_begin; p < p_end; p += SF_SLOTS) {
+    sf_step<0>(lds, regs, out, sc, cx, p, p_end);
+    sf_step<1>(lds, regs, out, sc, cx, p + 1, p_end);
+    sf_step<2>(lds, regs, out, sc, cx, p + 2, p_end);
+    sf_step<3>(lds, regs, out, sc, cx, p + 3, p_end);
+    sf_step<4>(lds, regs, out, sc, cx, p + 4, p_end);
+    sf_step<5>(lds, regs, out, sc, cx, p + 5, p_end);
+  }
+}

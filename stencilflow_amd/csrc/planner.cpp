@@ -16,6 +16,7 @@ namespace sf {
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 size_t star_lds_bytes(const StarCfg& c, DT dt) {
+  if (c.dense) return c.lds_bytes;  // kernels/dense3d.h (select_dense computed it)
   if (c.R == 2) {
     // kernels/wstar3d.h: two images, each with the first / last two rows of every thread row per
     // window and four edge words per row and wave (one virtual wave at either end)
@@ -60,6 +61,8 @@ static int star_regs_estimate(const StarCfg& c, DT dt) {
 }
 
 static int star_blocks_per_cu(const StarCfg& c, DT dt) {
+  if (c.dense)  // LDS and wave slots decide (about 120 registers per thread)
+    return std::max(1, std::min({(int)(160 * 1024 / std::max<size_t>(1, c.lds_bytes)), 32 / ((c.BX * c.BY + 63) / 64), 4}));
   const int threads = c.BX * c.BY;
   const int waves_per_simd = (threads + 255) / 256;  // a block's waves on one SIMD
   const int regs = star_regs_estimate(c, dt);
@@ -410,6 +413,77 @@ static StarChoice select_wide(sf_plan& pl, std::map<std::string, StarChoice>& me
   return out;
 }
 
+// A dense-neighbourhood operator (kernels/dense3d.h): a few block shapes in order of preference -- the
+// tile is staged in LDS, so what matters is the halo it re-reads and two blocks per unit (LDS, waves).
+static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& memo, int kidx, DT dt) {
+  const Program& P = pl.P;
+  const bool noj = P.n[1] == 1;
+  struct Shape {
+    int bx, by, rj;
+  };
+  static const Shape shapes3d[] = {{16, 16, 2}, {32, 8, 2}, {16, 8, 4}, {16, 16, 1}, {32, 8, 1}};
+  static const Shape shapes2d[] = {{64, 1, 1}, {128, 1, 1}};
+  StarChoice out;
+  const std::string prefix = std::string(noj ? "sf_dense2d_" : "sf_dense3d_") + short_of(dt);
+  const long long pin_bx = pl.opt.get(noj ? "k2.bx" : "k1.bx", 0), pin_by = pl.opt.get("k1.by", 0), pin_rj = pl.opt.get("k1.rj", 0);
+  std::vector<Shape> todo;
+  if (pin_bx && (noj || (pin_by && pin_rj))) todo.push_back({(int)pin_bx, noj ? 1 : (int)pin_by, noj ? 1 : (int)pin_rj});
+  else todo.assign(noj ? std::begin(shapes2d) : std::begin(shapes3d), noj ? std::end(shapes2d) : std::end(shapes3d));
+  for (const Shape& sh : todo) {
+    StarCfg c;
+    c.T = 1;
+    c.R = 2;
+    c.dense = true;
+    c.VK = dt == DT::F64 ? 2 : 4;  // 16 bytes of output per lane and row
+    c.BX = sh.bx;
+    c.BY = sh.by;
+    c.RJ = sh.rj;
+    c.noj = noj;
+    c.n0g = P.n[0];
+    c.n1 = P.n[1];
+    c.n2 = P.n[2];
+    if (sh.bx * sh.by > 1024 || sh.bx * sh.by < 64 || (sh.bx * sh.by) % 64 != 0) continue;
+    const long long tk = (long long)c.BX * c.VK, tj = noj ? 1 : (long long)c.BY * c.RJ;
+    c.ktiled = true;
+    c.HK = 0;
+    c.NKT = (int)((P.n[2] + tk - 1) / tk);
+    c.NJT = noj ? 1 : (int)((P.n[1] + tj - 1) / tj);
+    const size_t lds = 6 * (size_t)(tj + (noj ? 0 : 4)) * (size_t)(tk + 4) * size_of(dt);
+    if (lds > 160 * 1024) continue;
+    c.lds_bytes = lds;
+    const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] * (double)P.n[2] *
+                               (double)size_of(dt);
+    c.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
+    StarKernelSource g = gen_dense(P, kidx, c);
+    const std::string sig = "dense" + std::to_string(fnv1a(g.source));
+    auto it = memo.find(sig);
+    if (it != memo.end()) return it->second;
+    int ck = -1;
+    try {
+      ck = intern_kernel(pl, prefix, g.source);
+    } catch (const Error& e) {
+      if (e.status != SF_ERR_COMPILE) throw;
+      if (pl.opt.get("debug", 0) != 0)
+        std::fprintf(stderr, "[sf_hip] dense candidate %dx%dx%d rejected by the compiler: %.400s\n", sh.bx, sh.by, sh.rj, e.what());
+      continue;
+    }
+    const CompiledKernel& k = pl.kernels[ck];
+    if (pl.opt.get("debug", 0) != 0)
+      std::fprintf(stderr, "[sf_hip] dense candidate block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d lds %d\n", sh.bx,
+                   sh.by, sh.rj, k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
+    if (!kernel_unsafe(k) && !kernel_slow(k)) {
+      out.ok = true;
+      out.cfg = c;
+      out.ck = ck;
+      out.alts.push_back({c, ck});
+      out.sig = sig;
+      memo[sig] = out;
+      return out;
+    }
+  }
+  return out;
+}
+
 // Extra compiler flags of the compact kernels: without the SLP vectoriser hipcc
 // keeps the 26 adds of a box stencil scalar instead of pairing them into
 // v_pk_add_f32, whose operand pairs it has to assemble with moves (option compact.slp).
@@ -500,7 +574,7 @@ static void describe_step(std::ostringstream& desc, const sf_plan& pl, const Ste
   desc << "  launch " << ck.name << ": ";
   for (int k : st.kernels) desc << P.kernels[k].name << " ";
   if (st.star)
-    desc << (st.compact ? "[compact windows " + std::to_string(st.cfg.nwin) + " T=" : st.wide ? std::string("[wide star T=") : std::string("[star T=")) << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
+    desc << (st.compact ? "[compact windows " + std::to_string(st.cfg.nwin) + " T=" : st.dense ? std::string("[dense T=") : st.wide ? std::string("[wide star T=") : std::string("[star T=")) << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
          << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " chunk "
          << star_chunk_length(pl, st.cfg, dt, (int)pl.n_local) << " lds " << star_lds_bytes(st.cfg, dt)
          << " B]";
@@ -753,6 +827,19 @@ void build_plan(sf_plan& pl) {
       } else {
         st.kernels.push_back(k);
       }
+      // dense neighbourhoods of radius 2 (the generator's box of extent 2): one operator per launch, LDS tiles
+      if (!st.star && st.kernels.size() == 1 && !generic_only && star_ok_dims && pl.opt.get("dense", 1) != 0 &&
+          dense_eligible(P, P.kernels[k])) {
+        StarChoice choice = select_dense(pl, star_memo, k, P.kernels[k].dt);
+        if (choice.ok) {
+          st.star = true;
+          st.dense = true;
+          st.cfg = choice.cfg;
+          st.ck = choice.ck;
+          st.alts = choice.alts;
+          st.sig = choice.sig;
+        }
+      }
     }
     k += (int)st.kernels.size();
     pl.steps.push_back(st);
@@ -782,7 +869,7 @@ void build_plan(sf_plan& pl) {
   std::map<std::string, int> last_use; // field -> last step reading it
   auto step_reads = [&](const Step& st) {
     std::vector<std::string> r;
-    if (st.wide) {
+    if (st.wide || st.dense) {
       r.push_back(P.kernels[st.kernels[0]].acc[0].field);  // one field, streamed
     } else if (st.compact) {
       // argument 0: the streamed field of the first stage; then the extra fields in
@@ -875,7 +962,8 @@ void build_plan(sf_plan& pl) {
     if (st.star) {
       if (star_lds_bytes(st.cfg, dt) > 160 * 1024)
         throw Error(SF_ERR_INVALID, "star kernel: tile needs more than 160 KiB of LDS");
-      StarKernelSource g = st.wide ? gen_wide(P, st.kernels, st.cfg)
+      StarKernelSource g = st.dense  ? gen_dense(P, st.kernels[0], st.cfg)
+                           : st.wide ? gen_wide(P, st.kernels, st.cfg)
                            : st.compact ? gen_compact(P, st.kernels, st.cfg) : gen_star(P, st.kernels, st.cfg);
       st.scalars = g.scalars;
       st.scalar_offsets = g.scalar_offsets;
@@ -890,6 +978,10 @@ void build_plan(sf_plan& pl) {
           if (reads[a + 1] != g.aux[a]) throw Error(SF_ERR_STATE, "star step: auxiliary order mismatch");
       }
       st.halo_depth = st.cfg.T * st.cfg.R;
+      if (st.dense) {  // (what the operator really reaches along the stream axis)
+        st.halo_depth = 0;
+        for (auto& a : P.kernels[st.kernels[0]].acc) st.halo_depth = std::max(st.halo_depth, std::abs(a.off[0]));
+      }
       st.halo_buf = st.in_bufs[0];
     } else {
       // 4 points per thread with aligned vector loads when rows allow it; the

@@ -87,6 +87,7 @@ struct Step {
   bool star = false;     // plane-streaming launch (star3d.h or, with `compact`, compact3d.h)
   bool compact = false;
   bool wide = false;  // radius-2 star launch (kernels/wstar3d.h)
+  bool dense = false;  // dense neighbourhood of radius 2, tiles staged in LDS (kernels/dense3d.h)
   std::vector<int> kernels;    // program kernel indices fused in this launch
   int ck = -1;                 // compiled kernel
   std::vector<int> in_bufs;    // argument order

@@ -348,6 +348,78 @@ def wide_program(seed):
     return prog
 
 
+# --- random chains of DENSE-neighbourhood operators (kernels/dense3d.h): any subset of the
+# offsets {-2..2}^3 (2-D: {-2..2}^2) of the previous stage, at least one of them beyond what the
+# star / compact / wide-star kernels take (a diagonal at distance 2), scalar / literal
+# coefficients, int / float / shrink boundaries; rows of 4m elements; only + - * and selects ------
+def dense_program(seed):
+    rng = np.random.default_rng(20_000 + seed)
+    nd = 3 if rng.random() < 0.7 else 2
+    its = ["i", "j", "k"][3 - nd:]
+    if nd == 3:
+        dims = [int(rng.integers(5, 22)), int(rng.integers(3, 50)), 4 * int(rng.integers(2, 50))]
+    else:
+        dims = [int(rng.integers(5, 120)), 4 * int(rng.integers(2, 150))]
+    dtype = "float32" if rng.random() < 0.65 else "float64"
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": [],
+            "dimensions": dims, "program": {}}
+    scalars = []
+    for n in range(int(rng.integers(0, 3))):
+        name = "s%d" % n
+        prog["inputs"][name] = {"data": float(np.round(rng.uniform(-1, 1), 3)), "data_type": dtype, "input_dims": []}
+        scalars.append(name)
+    stages = int(rng.integers(1, 4))
+    prev = "a"
+    for s in range(stages):
+        name = "b%d" % s
+        density = rng.choice([0.08, 0.3, 1.0])
+        offs = []
+        for idx in np.ndindex(*([5] * nd)):
+            off = tuple(int(x) - 2 for x in idx)
+            if any(off) and rng.random() < density:
+                offs.append(off)
+        far = tuple(int(rng.choice([-2, 2])) if d < 2 else int(rng.choice([-2, -1, 1, 2])) for d in range(nd))
+        if far not in offs:
+            offs.append(far)  # a diagonal at distance 2: beyond every other fused kernel
+        if rng.random() < 0.6:
+            offs.append((0, ) * nd)
+        terms = []
+        for t in rng.permutation(len(offs)):
+            off = offs[int(t)]
+            idx = [it if o == 0 else "%s%+d" % (it, o) for it, o in zip(its, off)]
+            acc = "%s[%s]" % (prev, ",".join(idx))
+            r = rng.random()
+            if r < 0.6:
+                terms.append(acc)
+            elif r < 0.85 or not scalars:
+                terms.append("%r*%s" % (float(np.round(rng.uniform(-1, 1), 4)), acc))
+            else:
+                terms.append("%s*%s" % (rng.choice(scalars), acc))
+        expr = terms[0]
+        for t in terms[1:]:
+            expr = "%s %s %s" % (expr, rng.choice(["+", "+", "-"]), t)
+            if rng.random() < 0.1:
+                expr = "(" + expr + ")"
+        if rng.random() < 0.6:
+            expr = "%r * (%s)" % (float(np.round(rng.uniform(0.01, 0.1), 8)), expr)
+        kind = rng.random()
+        if kind < 0.1:
+            bc = {"type": "shrink"}
+        elif kind < 0.4:
+            bc = {"type": "constant", "value": int(rng.integers(-1, 3))}
+        else:
+            bc = {"type": "constant", "value": float(rng.choice(EXACT))}
+        prog["program"][name] = {"computation_string": "%s = %s" % (name, expr),
+                                 "boundary_conditions": {prev: bc}, "data_type": dtype}
+        prev = name
+    prog["outputs"].append(prev)
+    text = " ".join(k["computation_string"] for k in prog["program"].values())
+    for name in scalars:
+        if name not in text:
+            del prog["inputs"][name]
+    return prog
+
+
 # --- random chains of COMPACT operators (kernels/compact3d.h): any subset of the 27
 # offsets {-1,0,1}^3 of the previous stage, optionally a second full input field read
 # through such offsets, scalar / literal coefficients, int / float / shrink boundaries,

@@ -244,6 +244,92 @@ def test_wide_star_chains_on_rows_wider_than_a_tile(seed, cols, options, tmp_pat
             assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
 
 
+DENSE_CPU_SEEDS = list(range(0, 6))
+DENSE_GPU_SEEDS = list(range(0, 24))
+
+
+def _dense_case(seed, tmp_path):
+    from tests.random_programs import dense_program
+    prog = dense_program(seed)
+    rng = np.random.default_rng(seed + 19)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    path = programs.write_program(prog, str(tmp_path / "p.json"))
+    return prog, ins, sf.KernelChainGraph(path)
+
+
+@pytest.mark.parametrize("seed", DENSE_CPU_SEEDS)
+def test_random_dense_chains_plan(seed, tmp_path):
+    """Operators with dense radius-2 neighbourhoods (kernels/dense3d.h; the generator's box of
+    extent 2, bin/synthesize.py:19-31) are planned onto LDS-tiled dense launches (CPU: hipRTC only)
+    and the two oracles agree on them."""
+    prog, ins, chain = _dense_case(seed, tmp_path)
+    a = npo.run_reference(prog, inputs=ins)
+    b = c_oracle.CompiledReference(prog).run(inputs=ins)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (seed, k)
+    with Plan(lower(chain)) as plan:
+        # (an operator whose dense form does not come out clean -- many double-typed terms -- keeps the generic kernel)
+        assert plan.describe().count("[dense") >= 1, plan.describe()
+        assert plan.describe().count("[dense") + plan.describe().count("[point]") == len(prog["program"]), plan.describe()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", DENSE_GPU_SEEDS)
+def test_hip_matches_oracle_on_random_dense_chains(seed, tmp_path):
+    prog, ins, chain = _dense_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain)) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]]) for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:400])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(500, 506)))
+def test_random_dense_chains_under_slab_decomposition(seed, tmp_path):
+    """The same on two or three in-process slabs (a dense launch reaches up to two planes across a
+    slab boundary; the runner exchanges what every launch reads)."""
+    from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
+    from tests.random_programs import dense_program
+    prog = dense_program(seed)
+    prog["dimensions"][0] = max(prog["dimensions"][0], 24)
+    rng = np.random.default_rng(seed + 23)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    want = npo.run_reference(prog, inputs=ins)
+    sfir = lower(sf.KernelChainGraph(programs.write_program(prog, str(tmp_path / "p.json"))))
+    shape, world = tuple(prog["dimensions"]), int(rng.integers(2, 4))
+    exch = LocalExchanger(world)
+    groups = int(rng.integers(1, 3))
+    runners = [SlabRunner(sfir, shape, r, world, exchanger=exch.for_rank(r), groups_per_exchange=groups) for r in range(world)]
+    for r in runners:
+        if r.plan.scalar_names:
+            r.plan.set_scalars([ins[n] for n in r.plan.scalar_names])
+        r.upload([np.ascontiguousarray(ins[n][r.lo:r.hi]) for n in r.plan.input_names])
+    run_lockstep(runners)
+    name = runners[0].plan.output_names[0]
+    got = np.zeros(shape, dtype=want[name].dtype)
+    for r in runners:
+        parts = [np.zeros(r.local_shape, dtype=want[n].dtype) for n in r.plan.output_names]
+        r.download(parts)
+        got[r.lo:r.hi] = parts[0]
+    assert np.array_equal(got, want[name], equal_nan=True), seed
+    for r in runners:
+        r.close()
+
+
 COMPACT_CPU_SEEDS = list(range(0, 6))
 COMPACT_GPU_SEEDS = list(range(0, 30))
 
