@@ -421,7 +421,9 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
   struct Shape {
     int bx, by, rj;
   };
-  static const Shape shapes3d[] = {{16, 16, 2}, {32, 8, 2}, {16, 8, 4}, {16, 16, 1}, {32, 8, 1}};
+  // (measured on the 125-point box 512^3, profiles/r03_dense_shapes.log: 2.53 / 2.52 / 2.47 / 2.38 / 2.18e5 Mcells/s
+  //  in this order; four rows per thread 1.8e5)
+  static const Shape shapes3d[] = {{64, 8, 1}, {32, 16, 1}, {32, 8, 1}, {32, 8, 2}, {16, 16, 2}};
   static const Shape shapes2d[] = {{64, 1, 1}, {128, 1, 1}};
   StarChoice out;
   const std::string prefix = std::string(noj ? "sf_dense2d_" : "sf_dense3d_") + short_of(dt);
