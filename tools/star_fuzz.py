@@ -5,7 +5,8 @@ bit for bit with the oracle.  Only + - * and selects, so every implementation
 must agree exactly.  Prints one JSON line per failing program.
 
 usage: star_fuzz.py [--seeds 300] [--first 0] [--options "k1.rev=1"] [--generator star|wide]
-(--generator wide: chains of radius-2 stars, kernels/wstar3d.h; fusion depth 1-3)"""
+(--generator wide: chains of radius-2 stars, kernels/wstar3d.h; fusion depth 1-3;
+ --generator dense: operators with dense radius-2 neighbourhoods, kernels/dense3d.h)"""
 import argparse
 import json
 import os
@@ -21,7 +22,7 @@ from stencilflow_amd.backend import Plan  # noqa: E402
 from stencilflow_amd.lowering import lower  # noqa: E402
 from oracle import numpy_oracle as npo  # noqa: E402
 
-from tests.random_programs import star_program, wide_program  # noqa: E402
+from tests.random_programs import dense_program, star_program, wide_program  # noqa: E402
 
 
 def main():
@@ -30,9 +31,9 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--options", default="")
     ap.add_argument("--dump", type=int, default=-1, help="print the program of one seed and exit")
-    ap.add_argument("--generator", choices=["star", "wide"], default="star")
+    ap.add_argument("--generator", choices=["star", "wide", "dense"], default="star")
     args = ap.parse_args()
-    make = wide_program if args.generator == "wide" else star_program
+    make = {"wide": wide_program, "dense": dense_program}.get(args.generator, star_program)
     if args.dump >= 0:
         print(json.dumps(make(args.dump), indent=1))
         return
@@ -62,7 +63,7 @@ def main():
                 print(json.dumps({"seed": seed, "error": str(exc)[:300]}), flush=True)
                 continue
             desc = plan.describe()
-            nstar += desc.count("[star") + desc.count("[wide star")
+            nstar += desc.count("[star") + desc.count("[wide star") + desc.count("[dense")
             if (seed - args.first + 1) % 100 == 0:  # a long run must keep writing
                 print("# %d programs, %d failures so far" % (seed - args.first + 1, nfail), flush=True)
             nlaunch += plan.num_launches
