@@ -431,11 +431,18 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
   std::vector<Shape> todo;
   if (pin_bx && (noj || (pin_by && pin_rj))) todo.push_back({(int)pin_bx, noj ? 1 : (int)pin_by, noj ? 1 : (int)pin_rj});
   else todo.assign(noj ? std::begin(shapes2d) : std::begin(shapes3d), noj ? std::end(shapes2d) : std::end(shapes3d));
-  for (const Shape& sh : todo) {
+  // every shape with row segments held in registers first; then, for the first shapes, the form that reads
+  // each operand from LDS where the text uses it (operators whose typing doubles what a segment takes)
+  std::vector<std::pair<Shape, bool>> variants;
+  for (const Shape& sh : todo) variants.push_back({sh, false});
+  for (size_t i = 0; i < todo.size() && i < 2; ++i) variants.push_back({todo[i], true});
+  for (const auto& variant : variants) {
+    const Shape& sh = variant.first;
     StarCfg c;
     c.T = 1;
     c.R = 2;
     c.dense = true;
+    c.dense_scalar = variant.second;
     c.VK = dt == DT::F64 ? 2 : 4;  // 16 bytes of output per lane and row
     c.BX = sh.bx;
     c.BY = sh.by;
@@ -471,8 +478,8 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     }
     const CompiledKernel& k = pl.kernels[ck];
     if (pl.opt.get("debug", 0) != 0)
-      std::fprintf(stderr, "[sf_hip] dense candidate block %dx%d rows/thread %d: vgpr %d agpr %d spill %d scratch %d lds %d\n", sh.bx,
-                   sh.by, sh.rj, k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
+      std::fprintf(stderr, "[sf_hip] dense candidate block %dx%d rows/thread %d%s: vgpr %d agpr %d spill %d scratch %d lds %d\n", sh.bx,
+                   sh.by, sh.rj, variant.second ? " (operands read where used)" : "", k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
     if (!kernel_unsafe(k) && !kernel_slow(k)) {
       out.ok = true;
       out.cfg = c;
