@@ -35,8 +35,8 @@ workloads of the reference's generator on the other fused kernel families.
 
 N > 1: the halo transport is chosen from a ladder -- the
 library's own RCCL rung (ncclSend / ncclRecv issued by libsf_hip.so), its
-peer-to-peer DMA pushes, torch.distributed's RCCL, shared host memory, gloo --
-within a wall-clock budget; a rung counts only if, ON EVERY RANK, a decomposed run of
+peer-to-peer DMA pushes, shared host memory, gloo (torch.distributed's RCCL only when
+SF_BENCH_TRANSPORT=torch asks for it) -- within a wall-clock budget; a rung counts only if, ON EVERY RANK, a decomposed run of
 the chain's first operators equals the rank's local recomputation of its slab from
 the global synthetic input bit for bit (stencilflow_amd.distributed.DecompositionCheck);
 the same check runs again after the timed region and the process exits non-zero on a
@@ -337,7 +337,11 @@ def time_single(wl, options, steps, warmup, device=0):
 class Decomposed:
     """The slab-decomposed run of one rank: transport ladder, schedule, check, timing."""
 
-    RUNGS = ["rccl", "p2p", "torch", "shm", "gloo"]
+    # torch.distributed's RCCL ("torch") is taken only when asked for (SF_BENCH_TRANSPORT=torch): its process
+    # group ends the process from a watchdog thread on an asynchronous error, which no ladder can catch, and the
+    # library issues the same RCCL calls itself on the first rung
+    RUNGS = ["rccl", "p2p", "shm", "gloo"]
+    AFTER_TORCH = ["torch", "shm", "gloo"]
     NAMES = {"rccl": "RCCL send/recv issued by libsf_hip.so (sf_halo_use_rccl: grouped ncclSend / ncclRecv on the "
                      "transport's stream)",
              "p2p": "DMA pushes into the neighbours' ghost planes (HIP IPC, flags in shared host memory; sf_halo_*)",
@@ -531,7 +535,10 @@ class Decomposed:
             first = "torch"
         budget = float(os.environ.get("SF_BENCH_LADDER_SECONDS", "60"))
         # a pinned rung is taken without probing the others; when it fails the ladder continues below it
-        ladder = self.RUNGS[self.RUNGS.index(first):] if first in self.RUNGS else list(self.RUNGS)
+        if first == "torch":
+            ladder = list(self.AFTER_TORCH)
+        else:
+            ladder = self.RUNGS[self.RUNGS.index(first):] if first in self.RUNGS else list(self.RUNGS)
         native_env = os.environ.get("SF_BENCH_SCHEDULE")
         t_begin = time.perf_counter()
         best = None
@@ -539,7 +546,7 @@ class Decomposed:
             library_rung = rung in ("rccl", "p2p")
             if best is not None:
                 (elapsed, ) = self.agreed_max(time.perf_counter() - t_begin)
-                if first in self.RUNGS or not library_rung or elapsed > budget:
+                if first in self.RUNGS or first == "torch" or not library_rung or elapsed > budget:
                     break
             native = library_rung and native_env != "python"
             seconds, runner, ex, check, msg = self.try_rung(rung, native)

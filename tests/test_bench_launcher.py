@@ -33,7 +33,7 @@ def test_plain_command_launches_two_ranks_over_gloo():
     """World 2 on CPU: self-launch, rendezvous on the gloo control plane, ranks
     counted, rank 0's line relayed by the parent."""
     r = _run(["--gpus", "2", "--launch-check"])
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[-8000:]
     rec = _line(r.stdout)
     assert rec["launch_check"] and rec["ranks"] == 2 and rec["world_size"] == 2 and rec["n_gpus"] == 2
 
@@ -61,7 +61,7 @@ def test_plain_command_two_ranks_on_this_gpu():
     (sf_halo_*) can; the line must report 2 ranks, connected."""
     r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64", "--stages", "24"],
              env={"SF_BENCH_SINGLE_DEVICE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[-8000:]
     rec = _line(r.stdout)
     assert rec["n_gpus"] == 2 and rec["config"]["ranks"] == 2
     # processes sharing one device can map each other's buffers: the library's own

@@ -274,7 +274,7 @@ def test_transport_handshake_gloo(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("first,expect,transport", [(None, "DMA pushes", "p2p"), ("torch", "shared by the ranks", "shm"),
+@pytest.mark.parametrize("first,expect,transport", [(None, "DMA pushes", "p2p"), ("shm", "shared by the ranks", "shm"),
                                                     ("gloo", "gloo", "gloo")])
 def test_bench_three_ranks_on_one_gpu_falls_back(first, expect, transport):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one
@@ -283,9 +283,8 @@ def test_bench_three_ranks_on_one_gpu_falls_back(first, expect, transport):
     device): the default ladder must agree on that on every rank, go on to the
     library's peer-to-peer pushes (processes sharing a device can map each other's
     buffers), PROVE them -- the decomposed run of the chain's first operators against
-    each rank's local recomputation -- and print its line with `verified`; started at
-    torch.distributed's RCCL the ladder lands on shared host memory, started at its last
-    rung it uses gloo."""
+    each rank's local recomputation -- and print its line with `verified`; pinned to
+    shared host memory or to its last rung (gloo) it uses that one without probing the others."""
     import json
     import subprocess
     env = dict(os.environ, SF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -297,7 +296,7 @@ def test_bench_three_ranks_on_one_gpu_falls_back(first, expect, transport):
            os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
            "--size", "64", "--stages", "24"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[-8000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
@@ -482,7 +481,7 @@ def test_bench_self_loop_selects_rccl():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
            "--size", "64", "--stages", "24"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[-8000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
