@@ -49,7 +49,7 @@
 //   diagnostic builds: SF_STAMP (cycle stamps), SF_EXPERIMENT (timing-only
 //   variants with parts removed -- results invalid);
 //   typedef sf_t, struct sf_scalars, struct sf_auxptrs,
-//   template<int S> struct sf_stage {bc(), load_aux(), apply()}.
+//   template<int S> struct sf_stage {bc(), bc_zero, bc_copy, load_aux(), apply()}.
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 
@@ -508,12 +508,21 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
 #else
     const auto ax = sf_aux_row<S>(cx, q, r);
 #endif
+    // `copy` boundaries: which neighbours of this row's points lie outside the domain (the functor then
+    // takes the centre value in their place; what the windows hold there is never used)
+    unsigned edge_row = 0;
+    if constexpr (sf_stage<S>::bc_copy)
+      edge_row = (q + cx.goff <= 0 ? 1u : 0u) | (q + cx.goff >= SF_N0G - 1 ? 2u : 0u) |
+                 (!SF_NOJ && cx.j0 + r <= 0 ? 4u : 0u) | (!SF_NOJ && cx.j0 + r >= SF_N1 - 1 ? 8u : 0u);
     sf_vec o;
 #pragma unroll
     for (int v = 0; v < SF_VK; ++v) {
       const sf_t km = (v > 0) ? c[v > 0 ? v - 1 : 0] : km_e;
       const sf_t kp = (v < SF_VK - 1) ? c[v < SF_VK - 1 ? v + 1 : v] : kp_e;
-      o[v] = sf_stage<S>::apply(c[v], im[v], ip[v], jm[v], jp[v], km, kp, sc, ax, v);
+      unsigned edge = 0;
+      if constexpr (sf_stage<S>::bc_copy)
+        edge = edge_row | (cx.k0 + v <= 0 ? 16u : 0u) | (cx.k0 + v >= SF_N2 - 1 ? 32u : 0u);
+      o[v] = sf_stage<S>::apply(c[v], im[v], ip[v], jm[v], jp[v], km, kp, sc, ax, v, edge);
     }
     jm = c;
 #if SF_RING4

@@ -266,6 +266,30 @@ def star_program(seed):
     return prog
 
 
+def with_copy_boundaries(prog, seed, share=0.6):
+    """The program with the boundary condition of a random share of its operators' streamed
+    fields (those read off-centre) turned into `copy` -- an out-of-domain read takes the value at
+    the point itself (reference stencil/intel_fpga.py:225-227).  A generator of its own, so that
+    the programs of the other generators keep their seeds.  (The reference's CPU expansion
+    raises for `copy`, stencil/cpu.py:87, and so do the oracles: these programs are checked
+    HIP against HIP -- fused against the one-operator-per-launch generic kernel -- and against a
+    NumPy statement of the rule for the Jacobi chain, tests/test_gpu_parity.py.)"""
+    import copy as _copy
+    rng = np.random.default_rng([seed, 77])
+    out = _copy.deepcopy(prog)
+    changed = 0
+    for name, k in out["program"].items():
+        for f, bc in k["boundary_conditions"].items():
+            if (f == "a" or f.startswith("b")) and rng.random() < share:
+                k["boundary_conditions"][f] = {"type": "copy"}
+                changed += 1
+    if not changed:
+        first = next(iter(out["program"].values()))
+        f = next(iter(first["boundary_conditions"]))
+        first["boundary_conditions"][f] = {"type": "copy"}
+    return out
+
+
 # --- random chains of WIDE-STAR operators (kernels/wstar3d.h): offsets -2..2 along one axis
 # at a time (at least one at distance 2 in most stages; a stage without one is a plain star and
 # breaks the group), scalar / literal coefficients, int / float / shrink boundaries, ternaries

@@ -582,46 +582,55 @@ def test_full_size_three_operator_chain_properties():
     assert np.array_equal(fused["lap"][:c, :c, :c], ref[:c, :c, :c])
 
 
-def test_copy_boundary_condition(tmp_path):
+@pytest.mark.parametrize("shape,stages,options,launch", [
+    ((6, 10, 16), 1, None, "[star"),
+    ((6, 10, 16), 1, {"generic_only": 1}, "[point"),
+    ((21, 24, 64), 5, {"fuse": 2}, "[star T=2"),
+    ((9, 12, 520), 4, {"fuse": 3}, "[star T=3"),
+    ((70, 136), 6, None, "[star"),
+    ((70, 136), 3, {"generic_only": 1}, "[point"),
+])
+def test_copy_boundary_condition(tmp_path, shape, stages, options, launch):
     """`copy`: out-of-domain reads take the centre value (the FPGA expansions'
     semantics, reference stencil/intel_fpga.py:225-227; the reference's CPU
     path raises NameError for it, stencil/cpu.py:87 -- so this is checked
-    against a direct NumPy statement of that rule, not against the oracle)."""
-    shape = (6, 10, 16)
-    prog = programs.jacobi3d(shape, 1)
-    prog["program"]["b0"]["boundary_conditions"]["a"] = {"type": "copy"}
+    against a direct NumPy statement of that rule, not against the oracle):
+    for a star of radius 1 that is the field padded with its own edge values.
+    Fused star kernels (any depth, 3-D and 2-D) and the generic kernel."""
+    if len(shape) == 3:
+        prog = programs.jacobi3d(shape, stages)
+    else:
+        prog = programs.jacobi2d(shape, stages)
+    for k in prog["program"].values():
+        for f in k["boundary_conditions"]:
+            k["boundary_conditions"][f] = {"type": "copy"}
     rng = np.random.default_rng(SEED + 11)
     x = rng.uniform(-1, 1, shape).astype(np.float32)
     path = _write(tmp_path, prog)
-    got, desc = _run_gpu(path, {"a": x})
-    assert "point" in desc
-    xd = x.astype(np.float64)
+    got, desc = _run_gpu(path, {"a": x}, options=options)
+    assert launch in desc, desc
+    if launch != "[point":
+        assert "[point" not in desc
+    # no access of these operators carries a literal (copy keeps the field type): the sum is
+    # accumulated in float32, in the order of the program text; the coefficient is a double
+    want = x
+    for _ in range(stages):
+        p = np.pad(want, 1, mode="edge")
+        c = tuple(slice(1, -1) for _ in shape)
 
-    def nb(axis, off):
-        sh = np.roll(xd, -off, axis=axis)
-        idx = [slice(None)] * 3
-        idx[axis] = slice(-1, None) if off > 0 else slice(0, 1)
-        sh[tuple(idx)] = xd[tuple(idx)]  # out of domain -> centre value
-        return sh
+        def nb(axis, off):
+            idx = list(c)
+            idx[axis] = slice(1 + off, p.shape[axis] - 1 + off)
+            return p[tuple(idx)]
 
-    s = nb(0, -1) + nb(0, 1)
-    s = s + nb(1, -1)
-    s = s + nb(1, 1)
-    s = s + nb(2, -1)
-    s = s + nb(2, 1)
-    want = (0.16666666 * s).astype(np.float32)
-    # every access of this kernel has a BC select, so all operands are float
-    # (copy keeps the field type): the sum is accumulated in float32
-    xs = x
-    def nbf(axis, off):
-        sh = np.roll(xs, -off, axis=axis)
-        idx = [slice(None)] * 3
-        idx[axis] = slice(-1, None) if off > 0 else slice(0, 1)
-        sh[tuple(idx)] = xs[tuple(idx)]
-        return sh
-    sf32 = ((((nbf(0, -1) + nbf(0, 1)) + nbf(1, -1)) + nbf(1, 1)) + nbf(2, -1)) + nbf(2, 1)
-    want32 = (0.16666666 * sf32.astype(np.float64)).astype(np.float32)
-    assert np.array_equal(got["b0"], want32), npo.max_rel_err(want, got["b0"])
+        if len(shape) == 3:
+            s = ((((nb(0, -1) + nb(0, 1)) + nb(1, -1)) + nb(1, 1)) + nb(2, -1)) + nb(2, 1)
+            want = (0.16666666 * s.astype(np.float64)).astype(np.float32)
+        else:
+            s = ((nb(0, -1) + nb(0, 1)) + nb(1, -1)) + nb(1, 1)
+            want = (0.25 * s.astype(np.float64)).astype(np.float32)
+    name = "b{}".format(stages - 1)
+    assert np.array_equal(got[name], want), npo.max_rel_err(want, got[name])
 
 
 @pytest.mark.parametrize("args,kwargs", [
