@@ -6,7 +6,10 @@ must agree exactly.  Prints one JSON line per failing program.
 
 usage: star_fuzz.py [--seeds 300] [--first 0] [--options "k1.rev=1"] [--generator star|wide]
 (--generator wide: chains of radius-2 stars, kernels/wstar3d.h; fusion depth 1-3;
- --generator dense: operators with dense radius-2 neighbourhoods, kernels/dense3d.h)"""
+ --generator dense: operators with dense radius-2 neighbourhoods, kernels/dense3d.h;
+ --generator copy: star chains with `copy` boundaries -- the reference's CPU expansion and the
+   oracles have none (stencil/cpu.py:87), so the fused result is compared with the library's
+   generic kernel, one operator per launch)"""
 import argparse
 import json
 import os
@@ -22,7 +25,7 @@ from stencilflow_amd.backend import Plan  # noqa: E402
 from stencilflow_amd.lowering import lower  # noqa: E402
 from oracle import numpy_oracle as npo  # noqa: E402
 
-from tests.random_programs import dense_program, star_program, wide_program  # noqa: E402
+from tests.random_programs import dense_program, star_program, wide_program, with_copy_boundaries  # noqa: E402
 
 
 def main():
@@ -31,9 +34,10 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--options", default="")
     ap.add_argument("--dump", type=int, default=-1, help="print the program of one seed and exit")
-    ap.add_argument("--generator", choices=["star", "wide", "dense"], default="star")
+    ap.add_argument("--generator", choices=["star", "wide", "dense", "copy"], default="star")
     args = ap.parse_args()
-    make = {"wide": wide_program, "dense": dense_program}.get(args.generator, star_program)
+    make = {"wide": wide_program, "dense": dense_program,
+            "copy": lambda seed: with_copy_boundaries(star_program(seed), seed)}.get(args.generator, star_program)
     if args.dump >= 0:
         print(json.dumps(make(args.dump), indent=1))
         return
@@ -52,9 +56,18 @@ def main():
                         npo._NP[desc["data_type"]])
                 else:
                     ins[name] = scal[name] = desc["data"]
-            want = npo.run_reference(prog, inputs=ins)
             path = programs.write_program(prog, os.path.join(tmp, "p.json"))
             chain = sf.KernelChainGraph(path)
+            if args.generator == "copy":
+                with Plan(lower(chain), options={"generic_only": 1}) as ref:
+                    if ref.scalar_names:
+                        ref.set_scalars([scal[n] for n in ref.scalar_names])
+                    routs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]])
+                             for n in ref.output_names]
+                    ref.run([np.ascontiguousarray(ins[n]) for n in ref.input_names], routs, 1)
+                    want = dict(zip(ref.output_names, routs))
+            else:
+                want = npo.run_reference(prog, inputs=ins)
             opt = dict(base, fuse=int(rng.integers(1, 4 if args.generator == "wide" else 5)))
             try:
                 plan = Plan(lower(chain), options=opt)
