@@ -397,7 +397,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all,
     if constexpr (has_x) sf_gather<xw, stage::xneed, PH, r>(nbx, st, lds_all, cx, x);
     sf_vec o;
 #pragma unroll
-    for (int v = 0; v < SF_VK; ++v) o[v] = stage::apply(n[v], x[v], sc);
+    for (int v = 0; v < SF_VK; ++v) o[v] = stage::apply(n[v], x[v], sc, q + cx.goff, cx.j0 + r, cx.k0 + v);
     // Rows of the planes that die with this step take the planes after next.  Output
     // row r + 1 still reads row r of the prev plane (its j-1 neighbour there), so
     // the row that is dead after output row r is r - 1; the last one follows the loop.

@@ -25,7 +25,7 @@
 //
 // Macros from codegen: SF_R SF_VK SF_RJ SF_BX SF_BY SF_NOJ SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_NT
 //   SF_NLOADS SF_KERNEL_NAME; typedef sf_t; struct sf_scalars; struct sf_auxptrs;
-//   struct sf_dense {bc(), bc_zero, template<int PH> apply_row(tb, r, sc, o)}: the VK outputs of one row,
+//   struct sf_dense {bc(), bc_zero, template<int PH> apply_row(tb, r, sc, o, gi, gj, gk0)}: the VK outputs of one row,
 //   every row segment (VK + 2R elements of one (di, dj)) read from LDS as aligned 16-byte chunks.
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
@@ -89,6 +89,7 @@ __device__ __forceinline__ void sf_buf_store(const V v, const __amdgpu_buffer_rs
 struct sf_ctx {
   const sf_t* in;
   int goff, halo, cb, ce;
+  int j0, k0;  // global (j, k) of the thread's first output point (`copy` boundaries)
   // what this thread moves of every plane: SF_NLOADS pairs of elements (8 bytes for float, 16 for
   // double) -- byte offset inside the plane (SF_OOB: outside the (j,k) domain, or no pair at
   // all) and element index inside an LDS slot (-1: no pair)
@@ -135,7 +136,7 @@ __device__ __forceinline__ void sf_step(sf_t* lds, sf_pair (&regs)[SF_NLOADS], s
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     sf_t row[SF_VK];
-    sf_dense::template apply_row<PH>(tb, r, sc, row);
+    sf_dense::template apply_row<PH>(tb, r, sc, row, q + cx.goff, cx.j0 + r, cx.k0);
     sf_vec o;
 #pragma unroll
     for (int v = 0; v < SF_VK; ++v) o[v] = row[v];
@@ -193,6 +194,8 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     cx.st_off[r] = inside ? (unsigned)((j * SF_N2 + k) * (int)sizeof(sf_t)) : SF_OOB;
   }
   cx.tb = (SF_NOJ ? 0 : ty * SF_RJ) * SF_LS + tx * SF_VK;
+  cx.j0 = tj0 + (SF_NOJ ? 0 : ty * SF_RJ);
+  cx.k0 = tk0 + tx * SF_VK;
 
   // input planes [p_begin, p_end) are read; step p writes plane p into slot (p - p_begin) mod 6
   const int p_begin = cx.cb - SF_R, p_end = cx.ce + SF_R;

@@ -82,6 +82,7 @@ struct sf_ctx {
   unsigned jmask, kmask;
   bool tile_inside;  // block-uniform: every point of the tile lies in the (j,k) domain
   int goff, halo, cb, ce;
+  int j0, k0;  // global (j, k) of the thread's first point (`copy` boundaries)
   // byte offset of this lane's vector in row r of a plane, or SF_OOB where the lane must
   // not load (outside the (j,k) domain) / store (halo rows and columns)
   unsigned ld_off[SF_RJ], st_off[SF_RJ];
@@ -250,7 +251,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       nb.k[1] = (v >= 1) ? c[v >= 1 ? v - 1 : 0] : lo1;
       nb.k[2] = (v + 1 < SF_VK) ? c[v + 1 < SF_VK ? v + 1 : v] : hi0;
       nb.k[3] = (v + 2 < SF_VK) ? c[v + 2 < SF_VK ? v + 2 : v] : (v + 2 == SF_VK ? hi0 : hi1);
-      o[v] = sf_stage<S>::apply(nb, sc, v);
+      o[v] = sf_stage<S>::apply(nb, sc, v, q + cx.goff, cx.j0 + r, cx.k0 + v);
     }
     if constexpr (S == 1) {
       // row r of the input window's oldest plane (p - 4) is dead now: it receives row r of plane
@@ -413,6 +414,8 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY, 2)
 
   const int j0 = SF_NOJ ? 0 : (jt * SF_TJI - SF_REACH + cx.ty * SF_RJ);
   const int k0 = SF_KTILED ? (kt * SF_TKI - SF_HK + cx.tx * SF_VK) : cx.tx * SF_VK;
+  cx.j0 = j0;
+  cx.k0 = k0;
   {
     const int tj0 = SF_NOJ ? 0 : (jt * SF_TJI - SF_REACH);
     const int tk0 = SF_KTILED ? (kt * SF_TKI - SF_HK) : 0;

@@ -633,6 +633,69 @@ def test_copy_boundary_condition(tmp_path, shape, stages, options, launch):
     assert np.array_equal(got[name], want), npo.max_rel_err(want, got[name])
 
 
+def _copy_read(x, off):
+    """x read at p + off, points whose read leaves the domain taking x[p] (the `copy` rule)."""
+    valid = np.ones(x.shape, bool)
+    src = x
+    for axis, o in enumerate(off):
+        if o == 0:
+            continue
+        src = np.roll(src, -o, axis=axis)
+        idx = [slice(None)] * x.ndim
+        idx[axis] = slice(x.shape[axis] - o, None) if o > 0 else slice(0, -o)
+        valid[tuple(idx)] = False
+    return np.where(valid, src, x)
+
+
+_CROSS2 = [(0, 0, 0)] + [tuple(s * d if a == ax else 0 for a in range(3)) for ax in range(3) for d in (1, 2) for s in (-1, 1)]
+_BOX1 = [(i, j, k) for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1)]
+_SCATTER2 = [(0, 0, 0), (-2, 1, 0), (2, -2, 1), (1, 1, -2), (0, 2, 2), (-1, -2, -1), (2, 0, 0), (0, -1, 2), (-2, -2, -2), (1, 0, 1)]
+_BOX2_2D = [(j, k) for j in (-2, -1, 0, 1, 2) for k in (-2, -1, 0, 1, 2)]
+
+
+@pytest.mark.parametrize("offsets,shape,dtype,stages,options,launch", [
+    (_CROSS2, (11, 14, 72), "float32", 4, {"fuse": 2}, "[wide star T=2"),
+    (_CROSS2, (9, 10, 40), "float64", 2, None, "[wide star"),
+    (_BOX1, (10, 13, 68), "float32", 4, {"fuse": 2}, "[compact"),
+    (_BOX1, (7, 9, 24), "float64", 3, {"fuse": 3}, "[compact"),
+    (_SCATTER2, (12, 21, 72), "float32", 2, None, "[dense"),
+    (_BOX2_2D, (45, 136), "float32", 3, None, "[dense"),
+    (_SCATTER2, (6, 8, 16), "float64", 2, {"generic_only": 1}, "[point"),
+])
+def test_copy_boundary_in_the_other_fused_kernels(tmp_path, offsets, shape, dtype, stages, options, launch):
+    """`copy` in the wide-star, compact and dense kernels (and, last row, the generic kernel on the same
+    kind of operator): every read that leaves the domain -- along any of its offsets -- takes the value at
+    the point itself; NumPy statement of the rule, sum in the order of the text, in the field's type."""
+    its = ["i", "j", "k"][3 - len(shape):]
+    np_t = np.float32 if dtype == "float32" else np.float64
+
+    def expr(f):
+        terms = ["{}[{}]".format(f, ",".join(it if o == 0 else "{}{:+d}".format(it, o) for it, o in zip(its, off)))
+                 for off in offsets]
+        return "0.0625 * (" + " + ".join(terms) + ")"
+
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": ["b{}".format(stages - 1)],
+            "dimensions": list(shape), "program": {}}
+    prev = "a"
+    for s in range(stages):
+        name = "b{}".format(s)
+        prog["program"][name] = {"computation_string": "{} = {}".format(name, expr(prev)),
+                                 "boundary_conditions": {prev: {"type": "copy"}}, "data_type": dtype}
+        prev = name
+    x = np.random.default_rng(SEED + 12).uniform(-1, 1, shape).astype(np_t)
+    got, desc = _run_gpu(_write(tmp_path, prog), {"a": x}, options=options)
+    assert launch in desc, desc
+    if launch != "[point":
+        assert "[point" not in desc
+    want = x
+    for _ in range(stages):
+        s = _copy_read(want, offsets[0])
+        for off in offsets[1:]:
+            s = s + _copy_read(want, off)
+        want = (0.0625 * s.astype(np.float64)).astype(np_t)
+    assert np.array_equal(got[prev], want), npo.max_rel_err(want, got[prev])
+
+
 @pytest.mark.parametrize("args,kwargs", [
     (("float32", 4, 0, 12, 20, 32, 1, 1, 1), {}),
     (("float32", 3, 0, 10, 12, 16, 1, 1, 1), {"stencil_shape": "diffusion"}),

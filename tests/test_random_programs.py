@@ -122,14 +122,14 @@ def test_hip_matches_oracle_on_random_star_chains(seed, tmp_path):
 COPY_SEEDS = list(range(0, 16))
 
 
-def _copy_case(seed, tmp_path):
+def _copy_case(seed, tmp_path, generator="star_program"):
     """A random star chain with `copy` boundaries (tests/random_programs.py: with_copy_boundaries).
     The reference's CPU expansion -- and with it the oracles -- has no `copy` (stencil/cpu.py:87
     raises), so the fused star kernel is checked against the product's own generic kernel, one
     operator per launch (the form tests/test_gpu_parity.py::test_copy_boundary_condition pins
     against a NumPy statement of the rule)."""
-    from tests.random_programs import star_program, with_copy_boundaries
-    prog = with_copy_boundaries(star_program(seed), seed)
+    import tests.random_programs as rp
+    prog = rp.with_copy_boundaries(getattr(rp, generator)(seed), seed)
     rng = np.random.default_rng(seed + 7)
     ins = {}
     for name, desc in prog["inputs"].items():
@@ -166,6 +166,21 @@ def test_fused_copy_boundaries_match_the_generic_kernel(seed, tmp_path):
     assert "[star" in desc
     for n in want:
         assert np.array_equal(got[n], want[n], equal_nan=True), (seed, n, desc[:400])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generator,kernel,seed", [(g, k, s) for g, k in (("wide_program", "[wide star"),
+                                                                           ("compact_program", "[compact"),
+                                                                           ("dense_program", "[dense"))
+                                                   for s in range(4)])
+def test_copy_boundaries_in_the_other_fused_kernels_match_the_generic_kernel(generator, kernel, seed, tmp_path):
+    prog, ins, chain, opt = _copy_case(seed, tmp_path, generator)
+    opt = {"fuse": min(opt["fuse"], 3)}
+    want, desc = _run_plan(chain, prog, ins, {"generic_only": 1})
+    got, desc = _run_plan(chain, prog, ins, opt)
+    assert kernel in desc or "[star" in desc
+    for n in want:
+        assert np.array_equal(got[n], want[n], equal_nan=True), (generator, seed, n, desc[:400])
 
 
 @pytest.mark.gpu

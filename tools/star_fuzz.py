@@ -7,9 +7,10 @@ must agree exactly.  Prints one JSON line per failing program.
 usage: star_fuzz.py [--seeds 300] [--first 0] [--options "k1.rev=1"] [--generator star|wide]
 (--generator wide: chains of radius-2 stars, kernels/wstar3d.h; fusion depth 1-3;
  --generator dense: operators with dense radius-2 neighbourhoods, kernels/dense3d.h;
- --generator copy: star chains with `copy` boundaries -- the reference's CPU expansion and the
-   oracles have none (stencil/cpu.py:87), so the fused result is compared with the library's
-   generic kernel, one operator per launch)"""
+ --generator compact: the 27 offsets of radius 1, kernels/compact3d.h (tools/compact_fuzz.py is its own tool);
+ --copy (or --generator copy = star --copy): a share of the boundary conditions becomes `copy` -- the
+   reference's CPU expansion and the oracles have none (stencil/cpu.py:87), so the fused result is
+   compared with the library's generic kernel, one operator per launch)"""
 import argparse
 import json
 import os
@@ -25,7 +26,8 @@ from stencilflow_amd.backend import Plan  # noqa: E402
 from stencilflow_amd.lowering import lower  # noqa: E402
 from oracle import numpy_oracle as npo  # noqa: E402
 
-from tests.random_programs import dense_program, star_program, wide_program, with_copy_boundaries  # noqa: E402
+from tests.random_programs import (compact_program, dense_program, star_program, wide_program,  # noqa: E402
+                                   with_copy_boundaries)
 
 
 def main():
@@ -34,10 +36,14 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--options", default="")
     ap.add_argument("--dump", type=int, default=-1, help="print the program of one seed and exit")
-    ap.add_argument("--generator", choices=["star", "wide", "dense", "copy"], default="star")
+    ap.add_argument("--generator", choices=["star", "wide", "dense", "compact", "copy"], default="star")
+    ap.add_argument("--copy", action="store_true",
+                    help="turn a share of the boundary conditions into `copy`; reference: the generic kernel")
     args = ap.parse_args()
-    make = {"wide": wide_program, "dense": dense_program,
-            "copy": lambda seed: with_copy_boundaries(star_program(seed), seed)}.get(args.generator, star_program)
+    if args.generator == "copy":
+        args.generator, args.copy = "star", True
+    plain = {"wide": wide_program, "dense": dense_program, "compact": compact_program}.get(args.generator, star_program)
+    make = (lambda seed: with_copy_boundaries(plain(seed), seed)) if args.copy else plain
     if args.dump >= 0:
         print(json.dumps(make(args.dump), indent=1))
         return
@@ -58,7 +64,7 @@ def main():
                     ins[name] = scal[name] = desc["data"]
             path = programs.write_program(prog, os.path.join(tmp, "p.json"))
             chain = sf.KernelChainGraph(path)
-            if args.generator == "copy":
+            if args.copy:
                 with Plan(lower(chain), options={"generic_only": 1}) as ref:
                     if ref.scalar_names:
                         ref.set_scalars([scal[n] for n in ref.scalar_names])
@@ -76,7 +82,7 @@ def main():
                 print(json.dumps({"seed": seed, "error": str(exc)[:300]}), flush=True)
                 continue
             desc = plan.describe()
-            nstar += desc.count("[star") + desc.count("[wide star") + desc.count("[dense")
+            nstar += desc.count("[star") + desc.count("[wide star") + desc.count("[dense") + desc.count("[compact")
             if (seed - args.first + 1) % 100 == 0:  # a long run must keep writing
                 print("# %d programs, %d failures so far" % (seed - args.first + 1, nfail), flush=True)
             nlaunch += plan.num_launches
@@ -94,7 +100,7 @@ def main():
                                       "first_bad": bad[0].tolist(), "dims": prog["dimensions"],
                                       "maxrel": npo.max_rel_err(want[n], got),
                                       "sched": desc[:600]}), flush=True)
-    print("programs: %d, launches: %d (star: %d), failures: %d" % (args.seeds, nlaunch, nstar, nfail))
+    print("programs: %d, launches: %d (fused kernels: %d), failures: %d" % (args.seeds, nlaunch, nstar, nfail))
 
 
 if __name__ == "__main__":
