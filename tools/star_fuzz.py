@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--options", default="")
     ap.add_argument("--dump", type=int, default=-1, help="print the program of one seed and exit")
     ap.add_argument("--generator", choices=["star", "wide", "dense", "compact", "copy"], default="star")
+    ap.add_argument("--seconds", type=float, default=0, help="stop after this many seconds (0: run all seeds)")
     ap.add_argument("--copy", action="store_true",
                     help="turn a share of the boundary conditions into `copy`; reference: the generic kernel")
     args = ap.parse_args()
@@ -48,9 +49,14 @@ def main():
         print(json.dumps(make(args.dump), indent=1))
         return
     base = {k: v for k, v in (kv.split("=") for kv in args.options.split(";") if kv)}
-    nfail = nstar = nlaunch = 0
+    nfail = nstar = nlaunch = ndone = 0
+    import time
+    t_begin = time.perf_counter()
     with tempfile.TemporaryDirectory() as tmp:
         for seed in range(args.first, args.first + args.seeds):
+            if args.seconds and time.perf_counter() - t_begin > args.seconds:
+                break
+            ndone += 1
             prog = make(seed)
             rng = np.random.default_rng(seed + 7)
             p = npo.load_program(prog)
@@ -83,7 +89,7 @@ def main():
                 continue
             desc = plan.describe()
             nstar += desc.count("[star") + desc.count("[wide star") + desc.count("[dense") + desc.count("[compact")
-            if (seed - args.first + 1) % 100 == 0:  # a long run must keep writing
+            if (seed - args.first + 1) % 25 == 0:  # a long run must keep writing
                 print("# %d programs, %d failures so far" % (seed - args.first + 1, nfail), flush=True)
             nlaunch += plan.num_launches
             if plan.scalar_names:
@@ -100,7 +106,7 @@ def main():
                                       "first_bad": bad[0].tolist(), "dims": prog["dimensions"],
                                       "maxrel": npo.max_rel_err(want[n], got),
                                       "sched": desc[:600]}), flush=True)
-    print("programs: %d, launches: %d (fused kernels: %d), failures: %d" % (args.seeds, nlaunch, nstar, nfail))
+    print("programs: %d, launches: %d (fused kernels: %d), failures: %d" % (ndone, nlaunch, nstar, nfail))
 
 
 if __name__ == "__main__":
