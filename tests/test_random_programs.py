@@ -15,7 +15,7 @@ from stencilflow_amd.lowering import lower
 from tests.random_programs import random_inputs, random_program
 
 CPU_SEEDS = list(range(100, 124))
-GPU_SEEDS = list(range(100, 148))  # (tools/*_fuzz.py run hundreds more per round: profiles/r0*_fuzz*.log)
+GPU_SEEDS = list(range(100, 132))  # (tools/*_fuzz.py run hundreds more per round: profiles/r0*_fuzz*.log)
 
 
 @pytest.fixture(autouse=True)
@@ -73,7 +73,7 @@ def test_hip_matches_oracle_on_random_programs(seed, tmp_path):
 
 
 STAR_CPU_SEEDS = list(range(0, 12))
-STAR_GPU_SEEDS = list(range(0, 36))
+STAR_GPU_SEEDS = list(range(0, 24))
 
 
 def _star_case(seed, tmp_path):
@@ -119,7 +119,7 @@ def test_hip_matches_oracle_on_random_star_chains(seed, tmp_path):
             assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:400])
 
 
-COPY_SEEDS = list(range(0, 16))
+COPY_SEEDS = list(range(0, 8))  # (tools/star_fuzz.py --copy: profiles/r03_copy_fuzz*.log)
 
 
 def _copy_case(seed, tmp_path, generator="star_program"):
@@ -172,7 +172,7 @@ def test_fused_copy_boundaries_match_the_generic_kernel(seed, tmp_path):
 @pytest.mark.parametrize("generator,kernel,seed", [(g, k, s) for g, k in (("wide_program", "[wide star"),
                                                                            ("compact_program", "[compact"),
                                                                            ("dense_program", "[dense"))
-                                                   for s in range(4)])
+                                                   for s in range(2)])
 def test_copy_boundaries_in_the_other_fused_kernels_match_the_generic_kernel(generator, kernel, seed, tmp_path):
     prog, ins, chain, opt = _copy_case(seed, tmp_path, generator)
     opt = {"fuse": min(opt["fuse"], 3)}
@@ -184,7 +184,7 @@ def test_copy_boundaries_in_the_other_fused_kernels_match_the_generic_kernel(gen
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(600, 604)))
+@pytest.mark.parametrize("seed", list(range(600, 602)))
 def test_fused_copy_boundaries_under_slab_decomposition(seed, tmp_path):
     """`copy` is decided at GLOBAL coordinates: a slab's first plane is a boundary only on rank 0."""
     from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
@@ -224,7 +224,7 @@ def test_fused_copy_boundaries_under_slab_decomposition(seed, tmp_path):
 
 
 WIDE_CPU_SEEDS = list(range(0, 8))
-WIDE_GPU_SEEDS = list(range(0, 28))
+WIDE_GPU_SEEDS = list(range(0, 16))
 
 
 def _wide_case(seed, tmp_path):
@@ -349,7 +349,7 @@ def test_wide_star_chains_on_rows_wider_than_a_tile(seed, cols, options, tmp_pat
 
 
 DENSE_CPU_SEEDS = list(range(0, 6))
-DENSE_GPU_SEEDS = list(range(0, 10))  # tools/star_fuzz.py --generator dense: profiles/r03_dense_fuzz.log
+DENSE_GPU_SEEDS = list(range(0, 6))  # tools/star_fuzz.py --generator dense: profiles/r03_dense_fuzz.log
 
 
 def _dense_case(seed, tmp_path):
@@ -435,7 +435,7 @@ def test_random_dense_chains_under_slab_decomposition(seed, tmp_path):
 
 
 COMPACT_CPU_SEEDS = list(range(0, 6))
-COMPACT_GPU_SEEDS = list(range(0, 14))
+COMPACT_GPU_SEEDS = list(range(0, 10))
 
 
 def _compact_case(seed, tmp_path):
