@@ -25,6 +25,55 @@ def counter_means(root, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+def counter_sums(root, counter):
+    """kernel -> (sum over dispatches, number of dispatches) of one PMC pass."""
+    acc = defaultdict(lambda: [0.0, 0])
+    for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if r["Counter_Name"] == counter and r["Kernel_Name"].startswith("sf_"):
+                    acc[r["Kernel_Name"]][0] += float(r["Counter_Value"])
+                    acc[r["Kernel_Name"]][1] += 1
+    return acc
+
+
+def slab_records(tag, result):
+    """The slab kernels of bench.py --gpus N (tools/slab_traffic.py under the same PMC passes): their launches
+    cover plane ranges of many lengths, so the record is the SUM of the counters over one process divided by the
+    full-slab launches it made (planes launched / planes of the slab)."""
+    for root in sorted(glob.glob("gpurun_out/prof_%s_slab*" % tag)):
+        try:
+            with open(os.path.join(root, "planes.json")) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        kernel = rec["kernel"]
+        fetch, write = counter_sums(root, "FETCH_SIZE"), counter_sums(root, "WRITE_SIZE")
+        if kernel not in fetch or kernel not in write:
+            continue
+        expected = rec["executions"] * rec["launches_per_execution"]
+        if fetch[kernel][1] != expected or write[kernel][1] != expected:
+            print("slab%d: %d / %d dispatches counted, %d expected -- record skipped" %
+                  (rec["world"], fetch[kernel][1], write[kernel][1], expected), file=sys.stderr)
+            continue
+        full = rec["executions"] * rec["full_slab_launches_per_execution"]
+        family = "slab%d" % rec["world"]
+        for old in [k for k, v in result.items() if isinstance(v, dict) and v.get("family") == family]:
+            del result[old]
+        result[kernel] = {
+            "kernel": kernel, "family": family,
+            "hbm_bytes_per_launch": (fetch[kernel][0] * 1024.0 * 2.0 + write[kernel][0] * 1024.0) / full,
+            "fetch_size_kb_summed": fetch[kernel][0], "write_size_kb_summed": write[kernel][0],
+            "dispatches": expected, "full_slab_launches": full, "n_local": rec["n_local"], "halo": rec["halo"],
+            "correction": "gfx950: FETCH_SIZE reports half of a wide coalesced read stream -> x2 "
+                          "(MI355X_MICROARCH.md, HBM)",
+            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- "
+                       "python3 tools/slab_traffic.py --world %d (rank 0's launches of bench.py --gpus %d, no "
+                       "neighbour; per launch = per 512 planes written)" % (rec["world"], rec["world"]),
+            "round": tag,
+        }
+
+
 def main():
     tag, out_path = sys.argv[1], sys.argv[2]
     result = {}
@@ -44,10 +93,11 @@ def main():
                 continue
             family = re.sub(r"_[0-9a-f]{8}$", "", kernel)
             # one record per kernel family: a new code object replaces the old record
-            for old in [k for k in result if re.sub(r"_[0-9a-f]{8}$", "", k) == family]:
+            for old in [k for k, v in result.items()
+                        if isinstance(v, dict) and v.get("family", re.sub(r"_[0-9a-f]{8}$", "", k)) == family]:
                 del result[old]
             result[kernel] = {
-                "kernel": kernel,
+                "kernel": kernel, "family": family,
                 "hbm_bytes_per_launch": fetch[kernel] * 1024.0 * 2.0 + write[kernel] * 1024.0,
                 "fetch_size_kb_reported": fetch[kernel],
                 "write_size_kb_reported": write[kernel],
@@ -58,6 +108,7 @@ def main():
                            "--no-cpu-baseline" % wl,
                 "round": tag,
             }
+    slab_records(tag, result)
     with open(out_path, "w") as f:
         json.dump(result, f, indent=1)
     print(json.dumps(result, indent=1))

@@ -24,6 +24,7 @@ fi
 # kernel); wide = its radius-2 cross chain (wide-star kernel); generic = c3 forced onto the
 # generic operator kernel (16 / 40 operators)
 for wl in ${SF_PROFILE_WORKLOADS:-c3 c2 c5 box wide generic}; do
+  [ "$wl" = none ] && continue
   out=gpurun_out/prof_${tag}_$wl
   rm -rf $out; mkdir -p $out
   case $wl in
@@ -46,4 +47,19 @@ for wl in ${SF_PROFILE_WORKLOADS:-c3 c2 c5 box wide generic}; do
   f=$(ls -t $out/trace/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/${tag}_bench_${wl}_kernel_stats.csv
 done
+# the slab kernels of bench.py --gpus N (own code objects: the global plane count is a constant of the source):
+# rank 0's launches of one process without neighbours, tools/slab_traffic.py
+for n in ${SF_PROFILE_SLABS:-2 4 8}; do
+  out=gpurun_out/prof_${tag}_slab$n
+  rm -rf $out; mkdir -p $out
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 tools/slab_traffic.py --world $n --out $out/planes.json > $out/trace.log 2>&1
+  i=0
+  for pmc in FETCH_SIZE WRITE_SIZE; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $out/pmc_$i -- python3 tools/slab_traffic.py --world $n --out $out/planes.json > $out/pmc_$i.log 2>&1
+  done
+  python3 tools/profile_summary.py $out > /dev/null
+  cp $out/summary.txt gpurun_out/${tag}_bench_slab${n}_rocprof_summary.txt
+done
+cp profiles/hbm_traffic.json gpurun_out/hbm_traffic.json 2>/dev/null
 python3 tools/hbm_traffic.py $tag gpurun_out/hbm_traffic.json
