@@ -110,3 +110,25 @@ def test_roofline_block_arithmetic():
     assert abs(r["algorithmic_frac"] - 2 * 512.0**3 * 8 / 200e-6 / 8e12) < 1e-12 and r["algorithmic_frac"] > 1
     r = bench.roofline_block("k", 1.0737e9, None, 0.1, 500.0, 500, wl, 2.0, 2 * 512.0**3)
     assert r["basis"] == "compulsory" and r["traffic"] is None
+
+
+def test_committed_traffic_records_cover_the_bench_kernels():
+    """profiles/hbm_traffic.json (tools/profile_round.sh + tools/hbm_traffic.py): one PMC record per
+    kernel family of the bench workloads and one per slab kernel of `bench.py --gpus 2/4/8` (own code
+    objects: the global plane count is a constant of the generated source); every record within a
+    few per cent of the compulsory bytes of its launch -- a record far off would make `roofline.frac`
+    a fiction.  bench.measured_traffic() finds a record by the full kernel name only."""
+    import json
+    import bench
+    with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+        table = json.load(f)
+    families = {v.get("family", k.rsplit("_", 1)[0]): v for k, v in table.items()}
+    field = 512 ** 3 * 4
+    for fam, lo, hi in (("sf_star3d_f32_t2", 2 * field, 2.2 * field), ("slab2", 2 * field, 2.2 * field),
+                        ("slab4", 2 * field, 2.2 * field), ("slab8", 2 * field, 2.2 * field),
+                        ("sf_star3d_f64_t3", 4 * field, 4.6 * field), ("sf_star2d_f32_t4", 2 * 4096 ** 2 * 4, 2.6 * 4096 ** 2 * 4)):
+        assert fam in families, (fam, sorted(families))
+        assert lo <= families[fam]["hbm_bytes_per_launch"] <= hi, (fam, families[fam]["hbm_bytes_per_launch"])
+    for name, rec in table.items():
+        assert bench.measured_traffic(name) == rec["hbm_bytes_per_launch"]
+    assert bench.measured_traffic("sf_star3d_f32_t2_00000000") is None
