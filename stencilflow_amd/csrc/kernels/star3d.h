@@ -45,7 +45,7 @@
 //
 // Macros from codegen: SF_T SF_VK SF_RJ SF_BX SF_BY SF_HK SF_KTILED SF_NOJ
 //   SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_LDS_DB SF_ROW_FENCE SF_OPAQUE SF_REVERSE
-//   SF_PREFETCH2 SF_PFD SF_SPREAD_LOADS SF_DPP SF_NT SF_NAUX SF_KERNEL_NAME;
+//   SF_PREFETCH2 SF_PFD SF_SPREAD_LOADS SF_DPP SF_NT SF_TILE_ORDER SF_NAUX SF_KERNEL_NAME;
 //   diagnostic builds: SF_STAMP (cycle stamps), SF_EXPERIMENT (timing-only
 //   variants with parts removed -- results invalid);
 //   typedef sf_t, struct sf_scalars, struct sf_auxptrs,
@@ -810,8 +810,14 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   const int nb = gridDim.x, b = blockIdx.x;
   const int xq = nb >> 3, xr = nb & 7, xcd = b & 7;
   const int L = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
+#if SF_TILE_ORDER == 1
+  // k-tiles fastest: an XCD's share is a band of whole tile rows, every pair of k-neighbours in it
+  const int kt = L % SF_NKT;
+  const int jt = (L / SF_NKT) % SF_NJT;
+#else
   const int jt = L % SF_NJT;
   const int kt = (L / SF_NJT) % SF_NKT;
+#endif
   const int ch = L / (SF_NJT * SF_NKT);
 
   // chunks [0, nch1) cover planes [i_begin, i_end), later chunks a second range
