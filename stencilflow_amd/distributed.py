@@ -465,8 +465,7 @@ class PeerExchanger:
             elif error is not None:
                 self._fail(error)
             try:
-                self._check(self._lib.sf_halo_use_rccl(self._h, rccl_id, 0 if self.self_loop else rank,
-                                                       1 if self.self_loop else world))
+                self._use_rccl_bounded(rccl_id, 0 if self.self_loop else rank, 1 if self.self_loop else world)
             except Exception as exc:  # noqa: BLE001
                 error = exc
             if not self.self_loop:
@@ -477,6 +476,33 @@ class PeerExchanger:
             self._raise_if_any_failed(self._control.all_gather(error is None), error, "create")
         elif error is not None:
             self._fail(error)
+
+    # seconds a communicator may take to form ($SF_HALO_RCCL_INIT_SECONDS); one node, a few seconds at most
+    RCCL_INIT_SECONDS = 90.0
+
+    def _use_rccl_bounded(self, rccl_id, comm_rank, comm_size):
+        """``sf_halo_use_rccl`` (ncclCommInitRank) on a helper thread, given up after a bounded wait: a
+        bootstrap that never completes (no usable interface, a rank that died) must fail THIS rung --
+        the ranks then agree on the next one -- instead of holding the run until the launcher kills
+        it.  A call that did not return keeps the handle: it is neither reused nor destroyed."""
+        import os
+        import threading
+        seconds = float(os.environ.get("SF_HALO_RCCL_INIT_SECONDS", self.RCCL_INIT_SECONDS))
+        box = {}
+
+        def work():
+            box["status"] = self._lib.sf_halo_use_rccl(self._h, rccl_id, comm_rank, comm_size)
+            if box["status"] != 0:  # (the message is the calling thread's)
+                box["message"] = (self._lib.sf_last_error() or b"").decode()
+
+        worker = threading.Thread(target=work, name="sf-halo-rccl-init", daemon=True)
+        worker.start()
+        worker.join(seconds)
+        if worker.is_alive():
+            self._h = self._ct.c_void_p()  # abandoned to the call that still holds it
+            raise RuntimeError("halo transport (rccl): the communicator did not form within {:.0f} s".format(seconds))
+        if box.get("status", -1) != 0:
+            raise RuntimeError("halo transport (rccl): " + box.get("message", "ncclCommInitRank failed"))
 
     def _fail(self, error):
         self.close()

@@ -492,6 +492,28 @@ def test_bench_self_loop_selects_rccl():
 
 
 @pytest.mark.gpu
+def test_a_communicator_that_does_not_form_in_time_fails_its_rung_only():
+    """ncclCommInitRank runs on a helper thread under a bounded wait (PeerExchanger._use_rccl_bounded):
+    given no time at all, the RCCL rung is reported as failed -- the run does not hang on it -- and the
+    ladder goes on to a rung that works in this self-loop set-up (gloo through host buffers), is proven
+    there and prints its line."""
+    import json
+    import subprocess
+    env = dict(os.environ, SF_BENCH_SELF_LOOP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SF_HALO_RCCL_INIT_SECONDS="0.0001",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SF_BENCH_TRANSPORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
+           "--size", "64", "--stages", "24"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-8000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    deco = rec["config"]["decomposition"]
+    assert "rccl not used" in deco and "did not form within" in deco, deco
+    assert rec["config"]["transport"] == "gloo" and rec["config"]["verified"] is True
+
+
+@pytest.mark.gpu
 def test_program_inputs_no_launch_writes_are_exchanged_once(tmp_path):
     """A chain whose every operator also reads one extra field across planes (the shape of the
     reference generator's extra spatial fields, bin/synthesize.py:170-196) on two slabs: the extra
