@@ -182,15 +182,17 @@ def test_copy_boundaries_in_the_other_fused_kernels_match_the_generic_kernel(gen
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(600, 602)))
-def test_fused_copy_boundaries_under_slab_decomposition(seed, tmp_path):
+@pytest.mark.parametrize("generator,seed", [("star_program", 600), ("star_program", 601), ("wide_program", 602),
+                                            ("compact_program", 603), ("dense_program", 605)])
+def test_fused_copy_boundaries_under_slab_decomposition(generator, seed, tmp_path):
     """`copy` is decided at GLOBAL coordinates: a slab's first plane is a boundary only on rank 0."""
     from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
-    prog, ins, chain, opt = _copy_case(seed, tmp_path)
+    prog, ins, chain, opt = _copy_case(seed, tmp_path, generator)
+    opt = {"fuse": min(opt["fuse"], 3)}
     if len(prog["dimensions"]) == 3:
-        prog["dimensions"][0] = max(prog["dimensions"][0], 24)
-    else:
         prog["dimensions"][0] = max(prog["dimensions"][0], 48)
+    else:
+        prog["dimensions"][0] = max(prog["dimensions"][0], 96)
     rng = np.random.default_rng(seed + 13)
     for name, desc in prog["inputs"].items():
         if not np.isscalar(ins[name]) and ins[name].shape[0] != prog["dimensions"][0] and ins[name].ndim == len(prog["dimensions"]):
@@ -203,7 +205,7 @@ def test_fused_copy_boundaries_under_slab_decomposition(seed, tmp_path):
     groups = int(rng.integers(1, 3))
     runners = [SlabRunner(sfir, shape, r, world, options=opt, exchanger=exch.for_rank(r), groups_per_exchange=groups)
                for r in range(world)]
-    assert "[star" in runners[0].plan.describe()
+    assert "[point" not in runners[0].plan.describe() or generator == "dense_program"
     for r in runners:
         if r.plan.scalar_names:
             r.plan.set_scalars([ins[n] for n in r.plan.scalar_names])
