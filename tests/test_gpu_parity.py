@@ -852,6 +852,37 @@ def test_full_c2_configuration_bit_exact():
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("args,kwargs,stages,kernel", [
+    ((2, 2, 2), {}, 4, "[wide star T=2"),
+    ((1, 1, 1), {"stencil_shape": "box"}, 4, "[compact"),
+    ((2, 2, 2), {"stencil_shape": "box"}, 2, "[dense"),
+])
+def test_full_size_generator_workloads_bit_exact(args, kwargs, stages, kernel):
+    """The reference generator's radius-2 cross, 27-point box and 125-point box (bin/synthesize.py
+    conventions; the first two are bench.py's `wide` and `box` workloads) at the benchmark's 512^3,
+    random data: all 134 million results of a short chain against the C oracle -- the tile and
+    chunk shapes the planner picks for the full-size grid, which small random programs never see."""
+    import tempfile
+    from oracle import c_oracle
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    n = 512
+    prog, _ = programs.synthesize("float32", stages, 0.0, n, n, n, *args, **kwargs)
+    x = np.random.default_rng(SEED + 34).uniform(-1, 1, (n, n, n)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        chain = sf.KernelChainGraph(programs.write_program(prog, os.path.join(tmp, "w.json")))
+    out = prog["outputs"][0]
+    got = np.zeros((n, n, n), np.float32)
+    with Plan(lower(chain)) as plan:
+        assert kernel in plan.describe(), plan.describe()
+        assert list(plan.output_names) == [out] and list(plan.input_names) == ["a"]
+        plan.run([x], [got], 1)
+    ref = c_oracle.CompiledReference(prog)
+    ref.threads = _oracle_threads()
+    want = ref.run({"a": x})[out]
+    assert np.array_equal(got, want), npo.max_rel_err(want, got)
+
+
 def test_full_c5_configuration_bit_exact():
     """C5 itself: diffusion -> advection -> laplacian on 512^3 float64 random
     data, fused into one launch, all 134 million results against the C oracle."""
