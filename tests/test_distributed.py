@@ -468,6 +468,26 @@ def test_rccl_exchanger_sends_to_itself():
 
 
 @pytest.mark.gpu
+def test_bench_drops_a_tuned_schedule_the_check_rejects():
+    """The refinements of the schedule (halo depth, early exchange, reserved units, native / Python) are
+    speed only: when the check rejects the tuned schedule (forced here by a test hook) the run goes back to
+    the schedule the ladder proved, proves it again and prints a verified line instead of giving up."""
+    import json
+    import subprocess
+    env = dict(os.environ, SF_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SF_BENCH_TEST_REJECT_TUNED="1")
+    env.pop("SF_BENCH_TRANSPORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--size", "64", "--stages", "24"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-8000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert "TUNED SCHEDULE REJECTED" in rec["config"]["decomposition"]
+    assert rec["config"]["verified"] is True and rec["value"] > 0 and rec["config"]["transport"] == "p2p"
+
+
+@pytest.mark.gpu
 def test_bench_self_loop_selects_rccl():
     """bench.py's multi-rank path end to end on one GPU with the RCCL rung of the
     transport ladder: one process as rank 1 of 3, every halo sent to the rank
