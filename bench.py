@@ -798,8 +798,11 @@ def main():
     # process before the decomposed run (the per-GPU yardstick of the N-GPU value)
     undivided = None
     if rank == 0 and not self_loop and os.environ.get("SF_BENCH_NO_UNDIVIDED") != "1":
-        one = make_workload("c3", args.size, args.stages, 1)
-        undivided = time_single(one, options, 2, 1, device=local_rank)["value"]
+        try:
+            one = make_workload("c3", args.size, args.stages, 1)
+            undivided = time_single(one, options, 2, 1, device=local_rank)["value"]
+        except Exception as exc:  # noqa: BLE001 -- a yardstick, not the measurement
+            print("bench.py: undivided yardstick not measured: {}: {}".format(type(exc).__name__, exc), file=sys.stderr)
     dist.barrier()
 
     job = Decomposed(args, wl, sfir, options, rank, world, local_rank, self_loop)
@@ -851,14 +854,18 @@ def main():
     result["value"] = cells / elapsed / 1e6
     result["ms_per_step"] = elapsed / args.steps * 1e3
     fused = args.stages / max(1, len(runner.steps))
+    # (the profiled execution exchanges halos: every rank runs it; the timed value is already in hand, so
+    # a failure here costs the roofline block, not the line)
+    try:
+        roof = job.per_gpu_roofline(best, fused)
+    except Exception as exc:  # noqa: BLE001
+        roof = {"bound": "hbm", "error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
     if rank == 0:
-        result["roofline"] = job.per_gpu_roofline(best, fused)
+        result["roofline"] = roof
         per_gpu = result["value"] / (1 if self_loop else world)
         result["roofline"]["per_gpu_mcells_per_s"] = per_gpu
         result["roofline"]["undivided_mcells_per_s"] = undivided
         result["roofline"]["per_gpu_vs_undivided"] = (per_gpu / undivided) if undivided else None
-    else:
-        job.per_gpu_roofline(best, fused)  # (the profiled execution exchanges halos: every rank runs it)
     transport = job.NAMES[best["rung"]] + " (" + "; ".join(job.notes) + ")"
     if self_loop:
         transport += " -- SELF-LOOP TEST: rank 1 of 3, halos sent to the rank itself"
