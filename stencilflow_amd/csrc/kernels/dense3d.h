@@ -26,7 +26,8 @@
 // Macros from codegen: SF_R SF_VK SF_RJ SF_BX SF_BY SF_NOJ SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_NT
 //   SF_NLOADS SF_KERNEL_NAME; typedef sf_t; struct sf_scalars; struct sf_auxptrs;
 //   struct sf_dense {bc(), bc_zero, template<int PH> apply_row(tb, r, sc, o, gi, gj, gk0)}: the VK outputs of one row,
-//   every row segment (VK + 2R elements of one (di, dj)) read from LDS as aligned 16-byte chunks.
+//   every row segment (VK + 2R elements of one (di, dj)) read from LDS as aligned 16-byte chunks;
+//   SF_DENSE_ROWS 1 (the operator is one plain sum): apply_rows(tb, sc, out[RJ][VK]) instead, all rows in step.
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 typedef sf_t sf_pair __attribute__((ext_vector_type(2)));
@@ -133,6 +134,19 @@ __device__ __forceinline__ void sf_step(sf_t* lds, sf_pair (&regs)[SF_NLOADS], s
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(base, 0, store_plane ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
   const sf_t* tb = lds + cx.tb;
+#if SF_DENSE_ROWS
+  // the operator is one plain sum: all rows of the thread are accumulated in step (a row segment read
+  // from LDS serves every row that needs it), then stored
+  sf_t rows[SF_RJ][SF_VK];
+  sf_dense::template apply_rows<PH>(tb, sc, rows);
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    sf_vec o;
+#pragma unroll
+    for (int v = 0; v < SF_VK; ++v) o[v] = rows[r][v];
+    sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
+  }
+#else
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     sf_t row[SF_VK];
@@ -143,6 +157,7 @@ __device__ __forceinline__ void sf_step(sf_t* lds, sf_pair (&regs)[SF_NLOADS], s
     sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
     __builtin_amdgcn_sched_barrier(0);  // rows in order: bounds the live row segments
   }
+#endif
 }
 
 extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)

@@ -437,9 +437,25 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
   else todo.assign(noj ? std::begin(shapes2d) : std::begin(shapes3d), noj ? std::end(shapes2d) : std::end(shapes3d));
   // every shape with row segments held in registers first; then, for the first shapes, the form that reads
   // each operand from LDS where the text uses it (operators whose typing doubles what a segment takes)
-  std::vector<std::pair<Shape, bool>> variants;
-  for (const Shape& sh : todo) variants.push_back({sh, false});
-  for (size_t i = 0; i < todo.size() && i < 2; ++i) variants.push_back({todo[i], true});
+  struct Variant {
+    Shape first;
+    bool second;  // operands read from LDS where the text uses them
+    bool sum;     // plain-sum form: the thread's rows accumulated in step, row segments shared between them
+  };
+  std::vector<Variant> variants;
+  // An operator that is one plain sum (the generator's boxes): several rows per thread, so that a row segment
+  // read from LDS serves them all -- LDS bytes per output fall from 200 to 120 (two rows) or 80 (four).
+  // (measured on the 125-point box 512^3, profiles/r03_dense_sum_probe.log: 0.595 / 0.600 / 0.609 ms per operator
+  //  against 0.666 row by row; four rows per thread 0.605-0.616: with 124 adds per point the kernel is bound by
+  //  vector issue -- 0.42 ms at full rate -- not by LDS bytes any more)
+  static const Shape sums3d[] = {{64, 4, 2}, {64, 8, 2}, {32, 8, 2}};
+  if (pl.opt.get("dense.sum", 1) != 0 && dense_sum_form(P, P.kernels[kidx], nullptr)) {
+    if (pin_bx && (noj || (pin_by && pin_rj))) variants.push_back({todo[0], false, true});
+    else if (noj) for (const Shape& sh : shapes2d) variants.push_back({sh, false, true});
+    else for (const Shape& sh : sums3d) variants.push_back({sh, false, true});
+  }
+  for (const Shape& sh : todo) variants.push_back({sh, false, false});
+  for (size_t i = 0; i < todo.size() && i < 2; ++i) variants.push_back({todo[i], true, false});
   for (const auto& variant : variants) {
     const Shape& sh = variant.first;
     StarCfg c;
@@ -447,6 +463,7 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     c.R = 2;
     c.dense = true;
     c.dense_scalar = variant.second;
+    c.dense_sum = variant.sum;
     c.VK = dt == DT::F64 ? 2 : 4;  // 16 bytes of output per lane and row
     c.BX = sh.bx;
     c.BY = sh.by;
@@ -483,7 +500,7 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     const CompiledKernel& k = pl.kernels[ck];
     if (pl.opt.get("debug", 0) != 0)
       std::fprintf(stderr, "[sf_hip] dense candidate block %dx%d rows/thread %d%s: vgpr %d agpr %d spill %d scratch %d lds %d\n", sh.bx,
-                   sh.by, sh.rj, variant.second ? " (operands read where used)" : "", k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
+                   sh.by, sh.rj, variant.sum ? " (plain sum, rows in step)" : variant.second ? " (operands read where used)" : "", k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
     if (!kernel_unsafe(k) && !kernel_slow(k)) {
       out.ok = true;
       out.cfg = c;

@@ -852,6 +852,47 @@ def test_full_c2_configuration_bit_exact():
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("dims,dtype,bc,sum_form", [
+    ((20, 24, 72), "float32", {"type": "constant", "value": 0}, True),
+    ((11, 37, 40), "float32", {"type": "constant", "value": 0.5}, True),    # float literal: the sum runs in double
+    ((9, 14, 24), "float64", {"type": "constant", "value": 0.25}, True),
+    ((12, 18, 40), "float32", {"type": "shrink"}, True),
+    ((70, 136), "float32", {"type": "constant", "value": 0.0}, True),
+])
+def test_generator_box_of_extent_two_in_the_plain_sum_form(tmp_path, dims, dtype, bc, sum_form):
+    """The generator's box of extent 2 (125 points, 25 in 2-D) is ONE left-associated sum: the dense
+    kernel then accumulates all rows of a thread in step, term by term in the order of the text, and a row
+    segment read from LDS serves every row that needs it (codegen.hpp: dense_sum_form).  Same results,
+    bit for bit, as the oracle -- whatever type the boundary literal gives the sum."""
+    full = list(dims) + [0] * (3 - len(dims))
+    ext = [2 if d else 0 for d in full]
+    prog, _ = programs.synthesize(dtype, 2, 0.0, *full, *ext, stencil_shape="box")
+    for k in prog["program"].values():
+        for f in k["boundary_conditions"]:
+            k["boundary_conditions"][f] = dict(bc)
+    x = np.random.default_rng(SEED + 35).uniform(-1, 1, dims).astype(dtype)
+    path = _write(tmp_path, prog)
+    chain = sf.KernelChainGraph(path)
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    got = np.zeros(dims, dtype)
+    with Plan(lower(chain)) as plan:
+        assert "[dense" in plan.describe(), plan.describe()
+        assert ("#define SF_DENSE_ROWS 1" in plan.kernel_source(0)) == sum_form
+        plan.run([x], [got], 1)
+    if bc["type"] == "copy":
+        with Plan(lower(chain), options={"generic_only": 1}) as ref:
+            want = np.zeros(dims, dtype)
+            ref.run([x], [want], 1)
+    else:
+        want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
+    if bc["type"] == "shrink":
+        inner = tuple(slice(4, -4) for _ in dims)
+        assert np.array_equal(got[inner], want[inner])
+    else:
+        assert np.array_equal(got, want, equal_nan=True)
+
+
 @pytest.mark.parametrize("args,kwargs,stages,kernel", [
     ((2, 2, 2), {}, 4, "[wide star T=2"),
     ((1, 1, 1), {"stencil_shape": "box"}, 4, "[compact"),
