@@ -444,6 +444,62 @@ def dense_program(seed):
     return prog
 
 
+def dense_sum_program(seed):
+    """Operators that are ONE left-associated sum over a random subset of {-2..2}^d, the terms in
+    RANDOM order (the generator's boxes list them in lexicographic order), optionally scaled once by a
+    literal or a scalar; the centre (a float operand among doubles when the boundary literal is a
+    float) anywhere in the sum, also first: the plain-sum form of the dense kernel (codegen.hpp:
+    dense_sum_form) or, where the partial sums would change type, the text as it stands."""
+    rng = np.random.default_rng(30_000 + seed)
+    nd = 3 if rng.random() < 0.7 else 2
+    its = ["i", "j", "k"][3 - nd:]
+    if nd == 3:
+        dims = [int(rng.integers(5, 22)), int(rng.integers(3, 50)), 4 * int(rng.integers(2, 50))]
+    else:
+        dims = [int(rng.integers(5, 120)), 4 * int(rng.integers(2, 150))]
+    dtype = "float32" if rng.random() < 0.65 else "float64"
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": [],
+            "dimensions": dims, "program": {}}
+    if rng.random() < 0.4:
+        prog["inputs"]["s0"] = {"data": float(np.round(rng.uniform(-1, 1), 3)), "data_type": dtype, "input_dims": []}
+    stages = int(rng.integers(1, 4))
+    prev = "a"
+    for s in range(stages):
+        name = "b%d" % s
+        density = rng.choice([0.1, 0.4, 1.0])
+        offs = [tuple(int(x) - 2 for x in idx) for idx in np.ndindex(*([5] * nd))
+                if any(int(x) != 2 for x in idx) and rng.random() < density]
+        far = tuple(int(rng.choice([-2, 2])) if d < 2 else int(rng.choice([-2, -1, 1, 2])) for d in range(nd))
+        if far not in offs:
+            offs.append(far)
+        if rng.random() < 0.7:
+            offs.append((0, ) * nd)
+        if rng.random() < 0.5:
+            offs = [offs[int(t)] for t in rng.permutation(len(offs))]
+        terms = ["%s[%s]" % (prev, ",".join(it if o == 0 else "%s%+d" % (it, o) for it, o in zip(its, off))) for off in offs]
+        expr = " + ".join(terms)
+        c = rng.random()
+        if c < 0.5:
+            expr = "%r * (%s)" % (float(np.round(rng.uniform(0.01, 0.1), 8)), expr)
+        elif c < 0.7 and "s0" in prog["inputs"]:
+            expr = "s0 * (%s)" % expr
+        kind = rng.random()
+        if kind < 0.1:
+            bc = {"type": "shrink"}
+        elif kind < 0.4:
+            bc = {"type": "constant", "value": int(rng.integers(-1, 3))}
+        else:
+            bc = {"type": "constant", "value": float(rng.choice(EXACT))}
+        prog["program"][name] = {"computation_string": "%s = %s" % (name, expr),
+                                 "boundary_conditions": {prev: bc}, "data_type": dtype}
+        prev = name
+    prog["outputs"].append(prev)
+    text = " ".join(k["computation_string"] for k in prog["program"].values())
+    if "s0" in prog["inputs"] and "s0 *" not in text:
+        del prog["inputs"]["s0"]
+    return prog
+
+
 # --- random chains of COMPACT operators (kernels/compact3d.h): any subset of the 27
 # offsets {-1,0,1}^3 of the previous stage, optionally a second full input field read
 # through such offsets, scalar / literal coefficients, int / float / shrink boundaries,

@@ -352,9 +352,9 @@ DENSE_CPU_SEEDS = list(range(0, 6))
 DENSE_GPU_SEEDS = list(range(0, 4))  # tools/star_fuzz.py --generator dense: profiles/r03_dense_fuzz.log
 
 
-def _dense_case(seed, tmp_path):
-    from tests.random_programs import dense_program
-    prog = dense_program(seed)
+def _dense_case(seed, tmp_path, generator="dense_program"):
+    import tests.random_programs as rp
+    prog = getattr(rp, generator)(seed)
     rng = np.random.default_rng(seed + 19)
     p = npo.load_program(prog)
     ins = {}
@@ -386,6 +386,36 @@ def test_random_dense_chains_plan(seed, tmp_path):
 @pytest.mark.parametrize("seed", DENSE_GPU_SEEDS)
 def test_hip_matches_oracle_on_random_dense_chains(seed, tmp_path):
     prog, ins, chain = _dense_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain)) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]]) for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:400])
+
+
+@pytest.mark.parametrize("seed", [0, 3, 4])
+def test_plain_sums_take_the_dense_kernels_sum_form(seed, tmp_path):
+    """Operators that are one left-associated sum of accesses, the terms in any order (tests/random_programs.py:
+    dense_sum_program): the oracles agree, and the dense launches use the form that accumulates the rows of a
+    thread in step (SF_DENSE_ROWS 1 in the generated source)."""
+    prog, ins, chain = _dense_case(seed, tmp_path, "dense_sum_program")
+    a = npo.run_reference(prog, inputs=ins)
+    b = c_oracle.CompiledReference(prog).run(inputs=ins)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (seed, k)
+    with Plan(lower(chain)) as plan:
+        names = plan.kernel_names()
+        dense = [i for i, n in enumerate(names) if n.startswith("sf_dense") and n in plan.describe()]
+        assert dense and all("#define SF_DENSE_ROWS 1" in plan.kernel_source(i) for i in dense), plan.describe()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 8])
+def test_hip_matches_oracle_on_random_plain_sums(seed, tmp_path):
+    prog, ins, chain = _dense_case(seed, tmp_path, "dense_sum_program")
     want = npo.run_reference(prog, inputs=ins)
     with Plan(lower(chain)) as plan:
         if plan.scalar_names:

@@ -26,8 +26,8 @@ from stencilflow_amd.backend import Plan  # noqa: E402
 from stencilflow_amd.lowering import lower  # noqa: E402
 from oracle import numpy_oracle as npo  # noqa: E402
 
-from tests.random_programs import (compact_program, dense_program, star_program, wide_program,  # noqa: E402
-                                   with_copy_boundaries)
+from tests.random_programs import (compact_program, dense_program, dense_sum_program, star_program,  # noqa: E402
+                                   wide_program, with_copy_boundaries)
 
 
 def main():
@@ -36,14 +36,14 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--options", default="")
     ap.add_argument("--dump", type=int, default=-1, help="print the program of one seed and exit")
-    ap.add_argument("--generator", choices=["star", "wide", "dense", "compact", "copy"], default="star")
+    ap.add_argument("--generator", choices=["star", "wide", "dense", "dense_sum", "compact", "copy"], default="star")
     ap.add_argument("--seconds", type=float, default=0, help="stop after this many seconds (0: run all seeds)")
     ap.add_argument("--copy", action="store_true",
                     help="turn a share of the boundary conditions into `copy`; reference: the generic kernel")
     args = ap.parse_args()
     if args.generator == "copy":
         args.generator, args.copy = "star", True
-    plain = {"wide": wide_program, "dense": dense_program, "compact": compact_program}.get(args.generator, star_program)
+    plain = {"wide": wide_program, "dense": dense_program, "dense_sum": dense_sum_program, "compact": compact_program}.get(args.generator, star_program)
     make = (lambda seed: with_copy_boundaries(plain(seed), seed)) if args.copy else plain
     if args.dump >= 0:
         print(json.dumps(make(args.dump), indent=1))
