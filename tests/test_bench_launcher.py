@@ -132,3 +132,22 @@ def test_committed_traffic_records_cover_the_bench_kernels():
     for name, rec in table.items():
         assert bench.measured_traffic(name) == rec["hbm_bytes_per_launch"]
     assert bench.measured_traffic("sf_star3d_f32_t2_00000000") is None
+
+
+def test_traffic_records_belong_to_the_code_objects_the_bench_compiles():
+    """`roofline.basis` is "pmc" only when profiles/hbm_traffic.json holds counters of EXACTLY the code
+    object a workload runs (kernel name = family + hash of the generated source).  Any edit of a kernel
+    header or of the generator re-hashes the kernels and silently turns the basis into "compulsory"
+    (VERDICT r02, weak 7): this test fails instead, until tools/profile_round.sh has been run again and
+    its summaries committed.  (hipRTC compiles without a GPU.)"""
+    import json
+    import bench
+    from stencilflow_amd.backend import Plan
+    with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+        table = json.load(f)
+    for name, stages in (("c3", 1000), ("c2", 1000), ("c5", 300), ("box", 16), ("wide", 16)):
+        wl = bench.make_workload(name, 0, stages)
+        _, sfir = bench.lower_program(wl["prog"])
+        with Plan(sfir) as plan:
+            launched = [n for n in plan.kernel_names() if n in plan.describe()]
+        assert launched and all(n in table for n in launched), (name, launched, sorted(table))
