@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""GPU: what the dense kernel's skeleton costs (planes through registers into the LDS ring, one barrier per
+plane, results out) apart from the operator's arithmetic: a 5-term and a 27-term operator over offsets at
+distance 2, 512^3 float32, in the kernel's two forms and on the generic kernel (profiles/r03_dense_floor.log:
+0.20-0.22 ms = the HBM bound of one read and one write; the 125-point box takes 0.595 ms).
+usage (repository root): python tools/dense_floor_probe.py"""
 import sys, os, tempfile, time, json
 sys.path.insert(0, os.getcwd())
 import numpy as np
