@@ -436,7 +436,7 @@ class Decomposed:
     def run_chain(self, runner, native):
         if native:
             runner.execute_native()
-            runner.plan.synchronize()
+            runner.synchronize_native()
         else:
             runner.execute()
             runner.synchronize()
@@ -826,7 +826,7 @@ def main():
 
     def sync():
         if native:
-            runner.plan.synchronize()
+            runner.synchronize_native()
         else:
             runner.synchronize()
         if hasattr(exchanger, "check"):

@@ -268,9 +268,21 @@ int sf_halo_start(sf_halo* halo, int key, int depth, void* compute_stream);
 /* Make `compute_stream` wait until the exchange started last on `key` is done. */
 int sf_halo_finish(sf_halo* halo, int key, void* compute_stream);
 /* Fails (SF_ERR_DEVICE) if a wait of this rank -- or a neighbour's wait for this rank --
- * has timed out (peer-to-peer), or if RCCL reports an asynchronous error; call after
- * synchronising. */
+ * has timed out (peer-to-peer; call after synchronising), or if RCCL reports an
+ * asynchronous error.  RCCL rung: ncclSend / ncclRecv have no time limit, so this call
+ * is also the bound -- it waits ON THE HOST, at most `timeout_ms`, until every exchange
+ * started so far has arrived; call it BEFORE waiting for the device.  After a time-out
+ * or an error the communicator has been ended (ncclCommAbort: its kernels leave the
+ * streams, later synchronisations return) and the transport stays failed. */
 int sf_halo_check(sf_halo* halo);
+/* The caller gives the transport up (e.g. the communicator did not form on every rank):
+ * what RCCL holds is ended with ncclCommAbort, and sf_halo_destroy will not wait for it
+ * (ncclCommDestroy of a half-formed communicator may wait for the missing ranks). */
+int sf_halo_fail(sf_halo* halo);
+/* For a handle another thread is still inside (an ncclCommInitRank that never returned):
+ * it can be neither used nor destroyed; this releases the one thing that outlives the
+ * process -- the name of its flag page in /dev/shm -- without touching the rest. */
+int sf_halo_abandon(sf_halo* halo);
 /* The RCCL rung.  One rank (any) obtains an id -- SF_HALO_RCCL_ID_BYTES bytes, an
  * ncclUniqueId -- and hands it to every rank of the run; every rank then calls
  * sf_halo_use_rccl BEFORE its first sf_halo_export (collective: ncclCommInitRank over

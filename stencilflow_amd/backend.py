@@ -97,6 +97,8 @@ API = [
     ("sf_halo_start", _I, [_P, _I, _I, _P]),
     ("sf_halo_finish", _I, [_P, _I, _P]),
     ("sf_halo_check", _I, [_P]),
+    ("sf_halo_fail", _I, [_P]),
+    ("sf_halo_abandon", _I, [_P]),
     ("sf_halo_rccl_id", _I, [_P]),
     ("sf_halo_use_rccl", _I, [_P, _P, _I, _I]),
     ("sf_halo_transport", _S, [_P]),

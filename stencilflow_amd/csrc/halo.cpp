@@ -9,7 +9,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <memory>
 #include <set>
 
@@ -127,6 +129,7 @@ struct Rccl {
   result_t (*GetUniqueId)(unique_id*) = nullptr;
   result_t (*CommInitRank)(comm_t*, int, unique_id, int) = nullptr;
   result_t (*CommDestroy)(comm_t) = nullptr;
+  result_t (*CommAbort)(comm_t) = nullptr;  // optional: ends a communicator whose operations cannot complete
   result_t (*GroupStart)() = nullptr;
   result_t (*GroupEnd)() = nullptr;
   result_t (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
@@ -178,6 +181,7 @@ static Rccl& rccl() {
   lib.Recv = reinterpret_cast<decltype(lib.Recv)>(sym("ncclRecv"));
   lib.GetErrorString = reinterpret_cast<decltype(lib.GetErrorString)>(sym("ncclGetErrorString"));
   lib.CommGetAsyncError = reinterpret_cast<decltype(lib.CommGetAsyncError)>(::dlsym(h, "ncclCommGetAsyncError"));
+  lib.CommAbort = reinterpret_cast<decltype(lib.CommAbort)>(::dlsym(h, "ncclCommAbort"));
   lib.Send = reinterpret_cast<decltype(lib.Send)>(sym("ncclSend"));  // (last: marks the table complete)
   return lib;
 }
@@ -231,12 +235,33 @@ struct sf_halo {
   // RCCL rung
   sf::Rccl::comm_t comm = nullptr;
   int comm_rank = 0, comm_size = 0;  // comm_size == 1 with world > 1: every halo comes back to the sender (tests)
+  // an exchange that did not complete in time, an asynchronous RCCL error, or a communicator that did not form on
+  // every rank (sf_halo_fail): the communicator is ended with ncclCommAbort, never waited for
+  bool failed = false, aborted = false;
   // schedule refinements of sf_plan_execute_decomposed
   int reserved_cus = 0, early_exchange = 0;
   bool has_neighbour(int d) const { return d == 0 ? rank > 0 : rank < world - 1; }
 };
 
 namespace sf {
+
+// End a communicator whose operations may never complete: its kernels leave the streams, so the events behind
+// them fire and streams, plans and buffers can be released.  (Without ncclCommAbort in the library the
+// communicator is left alone: better a leak than a wait without end.)
+static void halo_abort_comm(sf_halo& h) {
+  h.failed = true;
+  if (!h.comm || h.aborted) return;
+  // (SF_RCCL_NO_ABORT=1, tests: the stall is staged on this rank's own stream and resolves by itself;
+  // the communicator is then left alone -- neither aborted nor destroyed)
+  const char* no_abort = std::getenv("SF_RCCL_NO_ABORT");
+  if (no_abort && no_abort[0] == '1') return;
+  h.aborted = true;
+  try {
+    Rccl& nc = rccl();
+    if (nc.CommAbort) (void)nc.CommAbort(h.comm);
+  } catch (...) {
+  }
+}
 
 static const size_t kFlagPageBytes = 4096;
 
@@ -331,12 +356,22 @@ int sf_halo_destroy(sf_halo* h) {
   SF_API_BEGIN
   if (!h) return SF_OK;
   (void)hipSetDevice(h->device);
-  if (h->send) (void)hipStreamSynchronize(h->send);
-  if (h->recv) (void)hipStreamSynchronize(h->recv);
-  if (h->comm) {
-    try {
-      (void)sf::rccl().CommDestroy(h->comm);
-    } catch (...) {
+  if (h->comm && h->failed) {
+    // a communicator with an exchange that cannot complete: ended, not waited for
+    sf::halo_abort_comm(*h);
+    const bool can_abort = h->aborted && sf::rccl().CommAbort != nullptr;
+    if (can_abort) {
+      if (h->send) (void)hipStreamSynchronize(h->send);
+      if (h->recv) (void)hipStreamSynchronize(h->recv);
+    }
+  } else {
+    if (h->send) (void)hipStreamSynchronize(h->send);
+    if (h->recv) (void)hipStreamSynchronize(h->recv);
+    if (h->comm) {
+      try {
+        (void)sf::rccl().CommDestroy(h->comm);
+      } catch (...) {
+      }
     }
   }
   for (auto& kv : h->bufs) {
@@ -352,6 +387,26 @@ int sf_halo_destroy(sf_halo* h) {
   if (h->send) (void)hipStreamDestroy(h->send);
   if (h->recv) (void)hipStreamDestroy(h->recv);
   delete h;
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_halo_fail(sf_halo* h) {
+  SF_API_BEGIN
+  if (!h) throw Error(SF_ERR_INVALID, "sf_halo_fail: null transport");
+  // (the caller knows the communicator did not form on every rank, or gave the transport up: whatever RCCL
+  // still holds is ended with ncclCommAbort at once and sf_halo_destroy will not wait for it)
+  sf::halo_abort_comm(*h);
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_halo_abandon(sf_halo* h) {
+  SF_API_BEGIN
+  if (!h) throw Error(SF_ERR_INVALID, "sf_halo_abandon: null transport");
+  // A handle another thread is still inside (ncclCommInitRank that never returned) can be neither used nor
+  // destroyed; what can be released without touching it is the NAME of its flag page in /dev/shm.
+  if (h->own.owner && !h->own.name.empty()) ::shm_unlink(h->own.name.c_str());
   return SF_OK;
   SF_API_END
 }
@@ -534,10 +589,38 @@ int sf_halo_check(sf_halo* h) {
   SF_API_BEGIN
   if (!h) throw Error(SF_ERR_INVALID, "sf_halo_check: null transport");
   if (h->comm) {
+    if (h->failed) throw Error(SF_ERR_DEVICE, "sf_halo: the RCCL transport has failed earlier (communicator ended)");
     sf::Rccl& nc = sf::rccl();
-    sf::Rccl::result_t async = 0;
-    if (nc.CommGetAsyncError) SF_RCCL_CHECK(nc.CommGetAsyncError(h->comm, &async));
-    if (async != 0) throw Error(SF_ERR_DEVICE, std::string("sf_halo: RCCL reports ") + nc.GetErrorString(async));
+    // Bounded on the host: ncclSend / ncclRecv have no time limit of their own, so a neighbour that
+    // died or missed an exchange would hold every later synchronisation.  Every exchange started so far must have
+    // arrived within the transport's time limit; if not -- or if RCCL reports an asynchronous error -- the
+    // communicator is ended (ncclCommAbort: its kernels leave the streams) and the transport stays failed.
+    SF_HIP_CHECK(hipSetDevice(h->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (auto& kv : h->bufs) {
+      sf::HaloBuffer& b = kv.second;
+      if (b.count == 0 || !b.received) continue;
+      for (;;) {
+        sf::Rccl::result_t async = 0;
+        if (nc.CommGetAsyncError && nc.CommGetAsyncError(h->comm, &async) == 0 && async != 0) {
+          sf::halo_abort_comm(*h);
+          throw Error(SF_ERR_DEVICE, std::string("sf_halo: RCCL reports ") + nc.GetErrorString(async));
+        }
+        const hipError_t q = hipEventQuery(b.received);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) {
+          sf::halo_abort_comm(*h);
+          throw Error(SF_ERR_DEVICE, std::string("sf_halo: ") + hipGetErrorString(q));
+        }
+        const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > (long long)h->timeout_ms) {
+          sf::halo_abort_comm(*h);
+          throw Error(SF_ERR_DEVICE, "sf_halo: rank " + std::to_string(h->rank) + ": an RCCL halo exchange did not complete within " +
+                                         std::to_string(h->timeout_ms) + " ms (communicator ended)");
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+      }
+    }
     return SF_OK;
   }
   const unsigned status = __atomic_load_n(static_cast<unsigned*>(h->own.host) + 1023, __ATOMIC_ACQUIRE);
@@ -610,7 +693,9 @@ extern "C" int sf_plan_execute_decomposed(sf_plan* plan, sf_halo* halo, int repe
     for (size_t s = 0; s < pl.steps.size(); ++s) {
       const Step& st = pl.steps[s];
       const int d = reach_of(s);
-      if (alone || d == 0) {
+      // (a zero-reach launch of a chain must still recompute the ghost planes that are good, or the next launch
+      // reads planes nobody wrote: the chain case comes first, as in SlabRunner.step_begin -- ADVICE r03)
+      if (alone || (d == 0 && !chain)) {
         launch_ranges(pl, st, 0, n, 0, 0, pl.stream);
         continue;
       }

@@ -64,6 +64,9 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_PLANE_BYTES ((unsigned)(SF_PLANE_ELEMS * (long long)sizeof(sf_t)))
 #define SF_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format (gfx9 / CDNA) */
 
+#ifndef SF_SKIP_ROWS
+#define SF_SKIP_ROWS 0
+#endif
 #define SF_SLOTS 4
 #define SF_NWIN (SF_T + SF_NX)
 #define SF_TJH (SF_BY * SF_RJ)
@@ -169,6 +172,9 @@ struct sf_ctx {
   bool kvec_in, tile_inside;
   int goff, halo, cb, ce, j0, k0;
   unsigned ld_off[SF_RJ], st_off[SF_RJ];
+#if SF_SKIP_ROWS
+  unsigned need_rows[SF_T];  // wave-uniform: bit r set = stage s + 1 evaluates row r of this thread row
+#endif
 };
 
 __host__ __device__ constexpr int sf_rows_at(int ty, int which) { return (ty * 2 + which) * SF_TKH; }
@@ -309,18 +315,24 @@ __device__ __forceinline__ void sf_prepare_row(sf_nbr& nb, const sf_state& st, c
   });
 }
 
+// The source rows output row R needs that are not prepared yet: -1, 0 and 1 before the first output
+// row, R + 1 afterwards (also run for an output row that is skipped: the rows after it build on it).
+template <int WIN, unsigned NEED, int PH, int R>
+__device__ __forceinline__ void sf_gather_prepare(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx) {
+  if constexpr (R == 0) {
+    sf_prepare_row<WIN, NEED, PH, -1>(nb, st, lds_all, cx);
+    sf_prepare_row<WIN, NEED, PH, 0>(nb, st, lds_all, cx);
+  }
+  sf_prepare_row<WIN, NEED, PH, R + 1>(nb, st, lds_all, cx);
+}
+
 // Neighbourhood of output row R: n[v][(d*3+e)*3+f] for the SF_VK points of the row,
 // read from window WIN through mask NEED at phase PH.
 template <int WIN, unsigned NEED, int PH, int R>
 __device__ __forceinline__ void sf_gather(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx,
                                           sf_t (&n)[SF_VK][27]) {
   constexpr int slot[3] = {PH % SF_SLOTS, (PH + 1) % SF_SLOTS, (PH + 2) % SF_SLOTS};
-  // source rows not prepared yet: -1, 0 and 1 before the first output row, R + 1 afterwards
-  if constexpr (R == 0) {
-    sf_prepare_row<WIN, NEED, PH, -1>(nb, st, lds_all, cx);
-    sf_prepare_row<WIN, NEED, PH, 0>(nb, st, lds_all, cx);
-  }
-  sf_prepare_row<WIN, NEED, PH, R + 1>(nb, st, lds_all, cx);
+  sf_gather_prepare<WIN, NEED, PH, R>(nb, st, lds_all, cx);
   sf_static_for<0, 3>([&](auto D) {
     constexpr int d = decltype(D)::value;
     sf_static_for<0, 3>([&](auto E) {
@@ -385,6 +397,17 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all,
   sf_nbr nbn, nbx;
   sf_static_for<0, SF_RJ>([&](auto RR) {
     constexpr int r = decltype(RR)::value;
+#if SF_SKIP_ROWS
+    // a halo row of the tile no later stage reads (star3d.h: SF_SKIP_ROWS; wave-uniform test): the windows
+    // move on, the neighbour rows are prepared for the rows that follow, nothing is evaluated
+    if (!((cx.need_rows[S - 1] >> r) & 1u)) {
+      sf_gather_prepare<src, stage::need, PH, r>(nbn, st, lds_all, cx);
+      if constexpr (has_x) sf_gather_prepare<xw, stage::xneed, PH, r>(nbx, st, lds_all, cx);
+      if constexpr (r > 0) sf_refill<S, PH, r - 1>(st, cx, p, p_end);
+      if constexpr (r == SF_RJ - 1) sf_refill<S, PH, r>(st, cx, p, p_end);
+      return;
+    }
+#endif
     sf_t n[SF_VK][27], x[SF_VK][27];
 #pragma unroll
     for (int v = 0; v < SF_VK; ++v)
@@ -594,6 +617,18 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     cx.st_off[r] = ((store_mask >> r) & 1u) ? off : SF_OOB;
   }
 
+#if SF_SKIP_ROWS
+#pragma unroll
+  for (int s = 0; s < SF_T; ++s) {
+    unsigned need = 0;
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r) {
+      const int tr = (int)threadIdx.y * SF_RJ + r;
+      need |= ((SF_NOJ || (tr >= s + 1 && tr < SF_TJH - (s + 1))) ? 1u : 0u) << r;
+    }
+    cx.need_rows[s] = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
+  }
+#endif
   sf_state st;
 #pragma unroll
   for (int w = 0; w < SF_NWIN; ++w)

@@ -71,6 +71,15 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 #ifndef SF_BUFFER_IO
 #define SF_BUFFER_IO 0
 #endif
+// SF_SKIP_ROWS: a stage does not evaluate the rows of the tile's halo that no later stage reads.  Stage S of T
+// is read back through S' > S stages of reach one row each, so of the SF_TJH rows of a tile only rows
+// [S, SF_TJH - S) of its output are ever used (the storing stage: exactly the rows it stores).  The test is on
+// the thread row, which is the same for all lanes of a wave: a scalar branch around the row's arithmetic.  Only the
+// first and last thread rows of a block skip anything -- with 2 waves per thread row and 4 thread rows each SIMD holds
+// one such wave, so every SIMD issues (RJ - S) instead of RJ rows per stage for one of its two waves.
+#ifndef SF_SKIP_ROWS
+#define SF_SKIP_ROWS 0
+#endif
 // (diagnostic values: 2 = buffer loads only, 3 = buffer stores only)
 #define SF_BIO_LOADS (SF_BUFFER_IO == 1 || SF_BUFFER_IO == 2)
 #define SF_BIO_STORES (SF_BUFFER_IO == 1 || SF_BUFFER_IO == 3)
@@ -177,6 +186,9 @@ struct sf_ctx {
   bool kvec_in;
   bool tile_inside;  // block-uniform: every point of the tile lies in the (j,k) domain
   int goff, halo, cb, ce, j0, k0;
+#if SF_SKIP_ROWS
+  unsigned need_rows[SF_T];  // wave-uniform: bit r set = stage s + 1 evaluates row r of this thread row
+#endif
 #if SF_BUFFER_IO
   // byte offset of this lane's vector in row r of a plane, or SF_OOB where the
   // lane must not load (outside the (j,k) domain) / store (halo rows and columns)
@@ -388,6 +400,27 @@ __device__ __forceinline__ sf_aux_passed sf_aux_take(const sf_ctx& cx, const int
 }
 #endif
 
+// Stage 1 is done with row r of the input window's "prev" slot: the row takes its next plane.
+template <int PH>
+__device__ __forceinline__ void sf_refill_row(sf_state& st, const sf_ctx& cx, const int p, const int r,
+                                              const bool load_next) {
+  constexpr int iprev = PH % SF_SLOTS;
+  (void)iprev;
+#if SF_RING4
+  // it receives row r of the plane after next (the next plane is already in flight in the fourth
+  // slot), which has two steps to land -- and nothing is copied
+  SF_LOAD_ROW_IF(load_next, st.w[0][iprev][r], p + 2, r);
+#elif SF_PREFETCH2
+  // it takes row r of plane p+1 from the staging registers (loaded during the previous step),
+  // which then receive row r of plane p+2
+  st.w[0][iprev][r] = st.pf[PH % SF_PFD][r];
+  SF_LOAD_ROW_IF(load_next, st.pf[PH % SF_PFD][r], p + 1 + SF_PFD, r);
+#elif SF_SPREAD_LOADS
+  // it receives row r of input plane p+1 -- loads are spread over stage 1 instead of issued in a burst
+  SF_LOAD_ROW_IF(load_next, st.w[0][iprev][r], p + 1, r);
+#endif
+}
+
 // One stage of the fused group at one step: reads the source window of stage
 // S-1 at phase PH and writes plane q = p - S of stage S (into its own window, or
 // to HBM for the last stage).
@@ -457,6 +490,15 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     const sf_vec c = st.w[src][icur][r];
+#if SF_SKIP_ROWS
+    // a halo row no later stage reads (wave-uniform test: a scalar branch); the row above still is this
+    // row's j-neighbour, and the input window still moves on
+    if (!((cx.need_rows[S - 1] >> r) & 1u)) {
+      jm = c;
+      if constexpr (S == 1) sf_refill_row<PH>(st, cx, p, r, load_next);
+      continue;
+    }
+#endif
     const sf_vec im = st.w[src][iprev][r];
     const sf_vec ip = st.w[src][inext][r];
     const sf_vec jp = (r < SF_RJ - 1) ? st.w[src][icur][r < SF_RJ - 1 ? r + 1 : r] : jpl;
@@ -525,28 +567,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       o[v] = sf_stage<S>::apply(c[v], im[v], ip[v], jm[v], jp[v], km, kp, sc, ax, v, edge);
     }
     jm = c;
-#if SF_RING4
-    if constexpr (S == 1) {
-      // row r of the input window's "prev" slot is dead now: it receives row r of
-      // the plane after next (the next plane is already in flight in the fourth
-      // slot), which has two steps to land -- and nothing is copied
-      SF_LOAD_ROW_IF(load_next, st.w[0][iprev][r], p + 2, r);
-    }
-#elif SF_PREFETCH2
-    if constexpr (S == 1) {
-      // row r of the input window's "prev" slot is dead now: it takes row r of
-      // plane p+1 from the staging registers (loaded during the previous step),
-      // which then receive row r of plane p+2
-      st.w[0][iprev][r] = st.pf[PH % SF_PFD][r];
-      SF_LOAD_ROW_IF(load_next, st.pf[PH % SF_PFD][r], p + 1 + SF_PFD, r);
-    }
-#elif SF_SPREAD_LOADS
-    if constexpr (S == 1) {
-      // row r of the input window's "prev" slot is dead now: it receives row r of
-      // input plane p+1 -- loads are spread over stage 1 instead of issued in a burst
-      SF_LOAD_ROW_IF(load_next, st.w[0][iprev][r], p + 1, r);
-    }
-#endif
+    if constexpr (S == 1) sf_refill_row<PH>(st, cx, p, r, load_next);
     if constexpr (S == SF_T) {
       // last stage of the group: write interior, in-domain points
       // SF_EXPERIMENT 1: timing-only build without the output stores (invalid results)
@@ -858,6 +879,18 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     if (!(tk >= SF_HK && tk < SF_TKH - SF_HK && cx.kvec_in)) cx.store_mask = 0;
   }
 
+#if SF_SKIP_ROWS
+#pragma unroll
+  for (int s = 0; s < SF_T; ++s) {
+    unsigned need = 0;
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r) {
+      const int tr = (int)threadIdx.y * SF_RJ + r;
+      need |= ((SF_NOJ || (tr >= s + 1 && tr < SF_TJH - (s + 1))) ? 1u : 0u) << r;
+    }
+    cx.need_rows[s] = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
+  }
+#endif
 #if SF_BUFFER_IO
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {

@@ -207,6 +207,8 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   const long long dpp_opt = pl.opt.get("k1.dpp", -1);
   base.dpp = dpp_opt >= 0 ? (int)dpp_opt : 4;
   base.uniform = (int)pl.opt.get("k1.uni", 0);
+  // halo rows of the tile no later stage reads are not evaluated (star3d.h: SF_SKIP_ROWS)
+  base.skip_rows = (int)pl.opt.get("k1.skip", 0);
   // logical tile order inside an XCD's share of the grid: 1 = k-tiles fastest, so that the share is a band of whole
   // tile rows and all its k-neighbours (which re-read each other's halo columns) meet in one L2.  C5 (16 x 5 tiles):
   // FETCH 1.2445 -> 1.1922 GB per launch, 0.7 % faster (profiles/r03_c5_tile_order.log); no k-tiles: same order
@@ -1007,11 +1009,9 @@ void build_plan(sf_plan& pl) {
         for (size_t a = 0; a < g.aux.size(); ++a)
           if (reads[a + 1] != g.aux[a]) throw Error(SF_ERR_STATE, "star step: auxiliary order mismatch");
       }
+      // (dense3d.h streams planes cb - R .. ce + R whatever the operator reaches along the stream axis, and its
+      // plane test knows the global domain only: the slab buffer must hold R ghost planes for it -- ADVICE r03)
       st.halo_depth = st.cfg.T * st.cfg.R;
-      if (st.dense) {  // (what the operator really reaches along the stream axis)
-        st.halo_depth = 0;
-        for (auto& a : P.kernels[st.kernels[0]].acc) st.halo_depth = std::max(st.halo_depth, std::abs(a.off[0]));
-      }
       st.halo_buf = st.in_bufs[0];
     } else {
       // 4 points per thread with aligned vector loads when rows allow it; the

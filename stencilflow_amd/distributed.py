@@ -469,7 +469,12 @@ class PeerExchanger:
             except Exception as exc:  # noqa: BLE001
                 error = exc
             if not self.self_loop:
-                self._raise_if_any_failed(self._control.all_gather(error is None), error, "ncclCommInitRank")
+                oks = self._control.all_gather(error is None)
+                if not all(oks) and self._h:
+                    # a communicator that did not form on every rank is ended (ncclCommAbort), not destroyed:
+                    # ncclCommDestroy of a half-formed communicator may wait for the missing ranks
+                    self._lib.sf_halo_fail(self._h)
+                self._raise_if_any_failed(oks, error, "ncclCommInitRank")
             elif error is not None:
                 self._fail(error)
         elif world > 1:
@@ -499,7 +504,9 @@ class PeerExchanger:
         worker.start()
         worker.join(seconds)
         if worker.is_alive():
-            self._h = self._ct.c_void_p()  # abandoned to the call that still holds it
+            # abandoned to the call that still holds it; the name of its flag page in /dev/shm is released
+            self._lib.sf_halo_abandon(self._h)
+            self._h = self._ct.c_void_p()
             raise RuntimeError("halo transport (rccl): the communicator did not form within {:.0f} s".format(seconds))
         if box.get("status", -1) != 0:
             raise RuntimeError("halo transport (rccl): " + box.get("message", "ncclCommInitRank failed"))
@@ -578,6 +585,7 @@ class PeerExchanger:
         try:
             view[halo:halo + n_local] = self.rank + 1
             self.finish(self.start(tensor, halo_regions(n_local, halo, halo, plane_bytes), key=key))
+            self.wait_bounded()
             torch.cuda.current_stream(self.device).synchronize()
             self.check()
             lo, hi = int(view[0, 0]), int(view[-1, -1])
@@ -619,6 +627,13 @@ class PeerExchanger:
 
     def check(self):
         self._check(self._lib.sf_halo_check(self._h))
+
+    def wait_bounded(self):
+        """RCCL rung: every exchange started so far has arrived, or the transport's time limit has passed and
+        the communicator is ended (``sf_halo_check`` polls the exchanges' events on the host; ncclSend / ncclRecv
+        themselves never give up).  The peer-to-peer rung bounds its waits on the device: nothing to do."""
+        if self.transport == "rccl" and self._h and self.world > 1:
+            self.check()
 
     def close(self):
         if self._h:
@@ -1036,7 +1051,21 @@ class SlabRunner:
             self.step_end(s, self.step_begin(s))
 
     def synchronize(self):
+        self.wait_for_halos()
         self.stream.synchronize()
+
+    def wait_for_halos(self):
+        """Before any wait for the device: a transport whose exchanges have no time limit of their own (the RCCL
+        rung) is waited for on the host within ITS limit, so a neighbour that died fails this rank's run instead
+        of holding it (``PeerExchanger.wait_bounded``)."""
+        wait = getattr(self.exchanger, "wait_bounded", None)
+        if wait is not None:
+            wait()
+
+    def synchronize_native(self):
+        """Wait for ``execute_native`` (the plan's own stream), bounded as ``synchronize`` is."""
+        self.wait_for_halos()
+        self.plan.synchronize()
 
     def close(self):
         self.plan.close()

@@ -134,6 +134,7 @@ static int run_rank(int rank, int world, int down_fd, int up_fd, const char* sfi
     CHECK(sf_plan_execute_step(plan, s, 1, NULL));              /* planes next to the lower boundary */
     CHECK(sf_plan_execute_step(plan, s, 2, NULL));              /* ... and the upper one */
   }
+  if (rccl) CHECK(sf_halo_check(link)); /* RCCL: the bounded wait for the exchanges comes before any wait for the device */
   CHECK(sf_plan_synchronize(plan));
   CHECK(sf_halo_check(link));
   size_t out_bytes = sf_plan_output_bytes(plan, 0);

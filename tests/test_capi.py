@@ -272,3 +272,10 @@ def test_round3_entry_points_without_a_device(tmp_path):
         plan.set_profile(True)
         plan.set_profile(False)
         assert all(v == 0.0 for v in plan.kernel_planes().values())
+
+
+def test_round4_entry_points_without_a_device():
+    """sf_halo_fail / sf_halo_abandon (a bounded RCCL rung): argument checks return statuses."""
+    lib = backend.load_library()
+    assert lib.sf_halo_fail(None) == -1 and b"sf_halo_fail" in lib.sf_last_error()
+    assert lib.sf_halo_abandon(None) == -1 and b"sf_halo_abandon" in lib.sf_last_error()

@@ -204,6 +204,60 @@ def test_native_deep_halo_schedule_matches_the_oracle(world, groups):
     _spawn(_gpu_worker, world, (48, 20, 64), 19, True, groups, "p2p", False, True)
 
 
+def _zero_reach_worker(rank, world, port, shape, native):
+    """A chain whose third operator reads its input at the point itself only (reach 0 along the slab axis), one
+    operator per launch: the launch after it reads ghost planes the zero-reach launch must have recomputed."""
+    import torch  # noqa: F401
+    sys.path.insert(0, ROOT)
+    import stencilflow_amd as sf
+    from oracle import numpy_oracle as npo
+    from stencilflow_amd import programs
+    from stencilflow_amd.distributed import PeerExchanger, SlabRunner
+    from stencilflow_amd.lowering import lower
+    import tempfile
+    _init(rank, world, port)
+    exchanger = PeerExchanger(rank, world, "z{}".format(port), device=0)
+    stages = 7
+    prog = programs.jacobi3d(shape, stages, bc_value=0.25)
+    for k in (2, 5):  # b2 and b5 become pointwise operators
+        prog["program"]["b%d" % k]["computation_string"] = "b{0} = 2.0 * b{1}[i,j,k] + 0.125".format(k, k - 1)
+        prog["program"]["b%d" % k]["boundary_conditions"] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = programs.write_program(prog, os.path.join(tmp, "p.json"))
+        sfir = lower(sf.KernelChainGraph(path))
+    x = np.random.default_rng(13).uniform(-1, 1, shape).astype(np.float32)
+    # (the generic kernel: a fused star launch reaches one plane whatever its operators read)
+    runner = SlabRunner(sfir, shape, rank, world, device=0, exchanger=exchanger, options={"generic_only": 1},
+                        groups_per_exchange=4)
+    assert [d for _, d in runner.steps] == [1, 1, 0, 1, 1, 0, 1], runner.steps
+    runner.upload([x[runner.lo:runner.hi]])
+    if native:
+        runner.execute_native()
+        runner.plan.synchronize()
+    else:
+        runner.execute()
+        runner.synchronize()
+    exchanger.check()
+    out = np.zeros(runner.local_shape, np.float32)
+    runner.download([out])
+    want = npo.run_reference(prog, {"a": x})["b%d" % (stages - 1)]
+    assert np.array_equal(out, want[runner.lo:runner.hi])
+    import torch.distributed as dist
+    dist.barrier()
+    runner.close()
+    exchanger.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("native", [False, True])
+def test_zero_reach_launch_inside_a_chain_keeps_the_ghost_planes(native):
+    """sf_plan_execute_decomposed used to launch a zero-reach step over the owned planes only and
+    leave the count of good ghost planes unchanged; SlabRunner's Python form recomputes them.  Both forms,
+    three processes on this GPU, against the oracle bit for bit."""
+    _spawn(_zero_reach_worker, 3, (48, 20, 64), native)
+
+
 def _c4_worker(rank, world, port, shape, stages, transport, out_dir):
     """One rank of C4's grid: its slab of seeded random data through `stages`
     operators, result written to out_dir/slab<rank>.dat."""
@@ -427,6 +481,51 @@ def test_library_rccl_rung_sends_to_itself():
     Python form over the same rung, and torch.distributed's RCCL in the same self-loop
     must all give the same planes bit for bit."""
     _spawn(_library_rccl_self_worker, 1)
+
+
+def _rccl_bound_worker(rank, world, port):
+    """An RCCL exchange that cannot start within the transport's time limit (its stream is held by a flag
+    wait this test stages): the bounded wait must raise instead of waiting on."""
+    import ctypes
+    import time
+    import torch
+    sys.path.insert(0, ROOT)
+    os.environ["SF_RCCL_NO_ABORT"] = "1"  # the stall is this rank's own and resolves: nothing to abort
+    from stencilflow_amd.distributed import PeerExchanger
+    dist = _init(rank, world, port)
+    torch.cuda.set_device(0)
+    ex = PeerExchanger(1, 3, "rb{}".format(port), device=0, timeout_ms=1500, transport="rccl", self_loop=True)
+    lib = ex._lib
+    n_local, halo, plane = 12, 4, 1 << 16
+    raw = torch.zeros((n_local + 2 * halo) * plane, dtype=torch.uint8, device="cuda")
+    blob = ctypes.create_string_buffer(ex._blob_bytes)
+    assert lib.sf_halo_export(ex._h, 0, ctypes.c_void_p(raw.data_ptr()), plane, n_local, halo, blob) == 0
+    assert lib.sf_halo_connect(ex._h, 0, None, None) == 0
+    flag = torch.zeros(2, dtype=torch.int32, device="cuda")  # flag word (never set) and the wait's status word
+    stream = torch.cuda.Stream()
+    raw_stream = ctypes.c_void_p(stream.cuda_stream)
+    fp, sp = ctypes.c_void_p(flag.data_ptr()), ctypes.c_void_p(flag.data_ptr() + 4)
+    assert lib.sf_flag_wait(raw_stream, fp, 1, 5000, sp) == 0  # holds the stream for 5 s
+    assert lib.sf_halo_start(ex._h, 0, 4, raw_stream) == 0      # ... and with it the exchange
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="did not complete within 1500 ms"):
+        ex.wait_bounded()
+    waited = time.perf_counter() - t0
+    assert 1.4 <= waited < 4.0, waited
+    with pytest.raises(RuntimeError, match="has failed earlier"):
+        ex.check()
+    stream.synchronize()  # the staged wait gives up after its 5 s; the exchange then runs to itself
+    assert int(flag[1].item()) == 1
+    ex.close()  # a failed transport is not waited for
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_rung_bounds_a_stalled_exchange():
+    """ncclSend / ncclRecv have no time limit; sf_halo_check (PeerExchanger.wait_bounded) waits on
+    the host within the transport's limit, fails the transport and never waits for it again."""
+    _spawn(_rccl_bound_worker, 1)
 
 
 def _rccl_self_worker(rank, world, port):
