@@ -117,7 +117,10 @@ def cpu_baseline(shape, block=8, budget_s=12.0):
     """The oracle's C/OpenMP restatement timed on the host cores, on a bounded
     sample: the same operator on the same grid, applied `block` operators at a
     time (output fed back as input) until about `budget_s` seconds have passed.
-    The thread count is calibrated first (1x and 2x the usable CPUs, 2 s each)."""
+    Threads = the CPUs this process may really use (affinity mask capped by the cgroup
+    quota) -- no probing of other counts (2 s probes landed on 32 threads
+    for a 16-CPU quota and the figure wandered 5.3 - 9.5e3 between rounds); a quarter of
+    the budget goes to the same sample on ONE thread (`one_thread`)."""
     from oracle import c_oracle
     from stencilflow_amd import programs
     ref = c_oracle.CompiledReference(programs.jacobi3d(shape, block))
@@ -136,19 +139,18 @@ def cpu_baseline(shape, block=8, budget_s=12.0):
                 return applied, dt
 
     cpus = usable_cpus()
-    candidates = sorted({max(1, cpus), min(os.cpu_count() or cpus, 2 * cpus)})
-    best = max(candidates, key=lambda t: (lambda a, d: a / d)(*rate(t, 2.0)))
-    applied, dt = rate(best, budget_s)
-    cells = float(np.prod(shape)) * applied
+    cells_per_op = float(np.prod(shape))
+    one_applied, one_dt = rate(1, 0.25 * budget_s)
+    applied, dt = rate(cpus, 0.75 * budget_s)
     return {
-        "value": cells / dt / 1e6,
+        "value": cells_per_op * applied / dt / 1e6,
         "unit": "Mcells/s",
-        "cores": best,
+        "cores": cpus,
         "kind": "port",
+        "one_thread": cells_per_op * one_applied / one_dt / 1e6,
         "sample": "{} operators of the chain on the full {}x{}x{} grid, {:.1f} s, "
-                  "gcc -O3 -fopenmp, {} threads ({} usable CPUs of {})".format(
-                      applied, shape[0], shape[1], shape[2], dt, best, cpus,
-                      os.cpu_count()),
+                  "gcc -O3 -fopenmp, {} threads (= usable CPUs; {} logical CPUs on the box); one thread: {} operators, "
+                  "{:.1f} s".format(applied, shape[0], shape[1], shape[2], dt, cpus, os.cpu_count(), one_applied, one_dt),
     }
 
 
@@ -240,6 +242,21 @@ def make_workload(name, size, stages, slab_world=1):
         return dict(prog=prog, shape=shape, np_dtype=np.float32, dtype="f32", bpu=8.0, stages=stages, name=name,
                     label="radius-2 cross {}^3 float32 (bin/synthesize.py, extents 2 2 2), {}-operator chain".format(
                         n, stages))
+    if name == "dense":
+        n = size or 512
+        shape = (n, n, n)
+        prog, _ = programs.synthesize("float32", stages, 0.0, n, n, n, 2, 2, 2, stencil_shape="box")
+        return dict(prog=prog, shape=shape, np_dtype=np.float32, dtype="f32", bpu=8.0, stages=stages, name=name,
+                    label="125-point box {}^3 float32 (bin/synthesize.py -stencil_shape box, extents 2 2 2), "
+                          "{}-operator chain".format(n, stages))
+    if name == "fork":
+        n = size or 512
+        shape = (n, n, n)
+        prog, _ = programs.synthesize("float32", stages, 0.0, n, n, n, 1, 1, 1, fork_frequency=0.25)
+        ops = len(prog["program"])
+        return dict(prog=prog, shape=shape, np_dtype=np.float32, dtype="f32", bpu=8.0, stages=ops, name=name,
+                    label="fork / join chain {}^3 float32 (bin/synthesize.py -fork_frequency 0.25: {} stages, "
+                          "{} operators)".format(n, stages, ops))
     if name == "c5":
         n = size or 512
         shape = (n, n, n)
@@ -284,6 +301,46 @@ def roofline_block(name, moved_per_full_launch, traffic, seconds, launches_equiv
     }
 
 
+def launch_spread(plan, name):
+    """min / median / max launch time (us) of kernel `name` over ONE extra, untimed chain execution with HIP
+    events around every launch (the timed region carries none), or {} when that cannot be had."""
+    try:
+        plan.set_profile(True)
+        plan.execute(1)
+        plan.synchronize()
+        times = plan.kernel_launch_times().get(name)
+        plan.set_profile(False)
+        if not times:
+            return {}
+        return {"min_us": times[0] * 1e3, "median_us": times[1] * 1e3, "max_us": times[2] * 1e3,
+                "spread_basis": "HIP events around every launch of one extra, untimed chain execution"}
+    except Exception:  # noqa: BLE001 -- a diagnostic, never at the price of the line
+        return {}
+
+
+def program_traffic(plan, shape, bpu):
+    """Whole-program view of a plan with several kernels (fork / join programs): per chain execution the bytes
+    every launch must move at least (each field it reads once + the field it writes once) and, where
+    profiles/hbm_traffic.json holds the PMC record of every kernel involved, the bytes they did move."""
+    field = float(np.prod(shape)) * bpu / 2.0
+    names = plan.kernel_names()
+    need = measured = 0.0
+    complete = True
+    per_kernel = {}
+    for s in range(plan.num_steps):
+        reads = len(set(plan.step_inputs(s)))
+        need += (reads + 1) * field
+        per_kernel.setdefault(plan.step_kernel(s), []).append((reads + 1) * field)
+    for k, needs in per_kernel.items():
+        t = measured_traffic(names[k])
+        if t is None:
+            complete = False
+        else:
+            measured += t * len(needs)
+    return {"compulsory_bytes_per_execution": need, "pmc_bytes_per_execution": measured if complete else None,
+            "pmc_over_compulsory": (measured / need) if complete and need else None, "launches": plan.num_steps}
+
+
 def time_single(wl, options, steps, warmup, device=0):
     """One workload on one GPU: `steps` timed chain executions (barrier-free at N = 1,
     synchronised on both sides), HIP events around every execution on the plan's stream.
@@ -296,39 +353,56 @@ def time_single(wl, options, steps, warmup, device=0):
         scalar_values = [chain.inputs[k]["data"] for k in plan.scalar_names]
         if scalar_values:
             plan.set_scalars(scalar_values)
-        data = synthetic(wl["shape"], wl["np_dtype"])
-        plan.upload([data])
+        data = [synthetic(wl["shape"], wl["np_dtype"]) for _ in plan.input_names]
+        plan.upload(data)
         # one untimed execution before the counted warm-up steps: the first pass loads the
         # code objects and sizes the launch queues -- none of which belongs to a step even
         # when the caller asks for --warmup 0.  The grid is uploaded again afterwards so the
         # timed steps start from the same synthetic data.
         plan.execute(1)
         plan.synchronize()
-        plan.upload([data])
+        plan.upload(data)
         for _ in range(warmup):
             plan.execute(1)
         plan.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        kernel_ms = 0.0
+        step_ms = []
         for _ in range(steps):
             plan.execute(1)
             plan.synchronize()  # HIP events bracket the launches of this step on the plan's stream
-            kernel_ms += plan.elapsed_ms()
+            step_ms.append(plan.elapsed_ms())
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        kernel_ms = float(sum(step_ms))
         stats = plan.kernel_stats()
         launches = plan.num_launches * steps
-        name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"])
+        name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"] * max(1, stats[k]["launches"]))
         fused = wl["stages"] / plan.num_launches  # operators evaluated per launch
         cells = float(np.prod(wl["shape"])) * wl["stages"] * steps
         compulsory = float(np.prod(wl["shape"])) * wl["bpu"]  # the field once in, once out
         traffic = measured_traffic(name)
-        roof = roofline_block(name, traffic if traffic is not None else compulsory, traffic, kernel_ms * 1e-3,
-                              launches, launches, wl, fused, cells / launches)
-        roof["compulsory_bytes_per_launch"] = compulsory
-        return {"value": cells / elapsed / 1e6, "ms_per_step": elapsed / steps * 1e3, "roofline": roof,
-                "schedule": plan.describe().splitlines()[1].strip()}
+        kernels = len(set(plan.kernel_names()))
+        if kernels == 1:
+            roof = roofline_block(name, traffic if traffic is not None else compulsory, traffic, kernel_ms * 1e-3,
+                                  launches, launches, wl, fused, cells / launches)
+            roof["compulsory_bytes_per_launch"] = compulsory
+        else:
+            # several kernels (fork / join programs): the roofline of the whole execution -- every launch's bytes
+            # over the summed HIP-event time of the executions
+            prog = program_traffic(plan, wl["shape"], wl["bpu"])
+            moved = prog["pmc_bytes_per_execution"] or prog["compulsory_bytes_per_execution"]
+            roof = roofline_block(name, moved, prog["pmc_bytes_per_execution"], kernel_ms * 1e-3, steps, launches, wl,
+                                  fused, cells / steps)
+            roof["compulsory_bytes_per_launch"] = None
+            roof["scope"] = "whole chain execution ({} launches of {} kernels); `kernel` is the one with most work".format(
+                plan.num_launches, kernels)
+            roof["program"] = prog
+        roof.update(launch_spread(plan, name))
+        med = float(np.median(step_ms))
+        return {"value": cells / elapsed / 1e6, "ms_per_step": elapsed / steps * 1e3,
+                "median_ms_per_step": med, "value_at_median": cells / steps / (med * 1e-3) / 1e6 if med > 0 else None,
+                "roofline": roof, "schedule": plan.describe().splitlines()[1].strip(), "compiler": plan.compiler()}
     finally:
         plan.close()
 
@@ -689,7 +763,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c3", "c2", "c5", "box", "wide"], default="c3",
+    ap.add_argument("--workload", choices=["c3", "c2", "c5", "box", "wide", "dense", "fork"], default="c3",
                     help="c3 = jacobi3d 512^3 f32 (headline, default); c2 = "
                     "jacobi2d 4096^2 f32; c5 = diffusion/advection/laplacian "
                     "512^3 f64; box / wide = the generator's 27-point box chain / radius-2 cross "
@@ -759,7 +833,8 @@ def main():
         result["value"], result["ms_per_step"] = timed["value"], timed["ms_per_step"]
         result["roofline"] = timed["roofline"]
         result["config"].update(decomposition="single", ranks=1, transport="none (single GPU)",
-                                schedule=timed["schedule"])
+                                schedule=timed["schedule"], compiler=timed["compiler"])
+        result["median_ms_per_step"], result["value_at_median"] = timed["median_ms_per_step"], timed["value_at_median"]
         if args.workload == "c3" and not args.size and not args.options and not args.no_other_configs:
             # BASELINE.json configs[1] and configs[4] in the driver's own line:
             # a few steps each (about 25 ms and 45 ms of GPU time per step; a step of c5 is 100
@@ -769,7 +844,10 @@ def main():
             # fused kernel families: the 27-point box chain (compact3d.h) and the radius-2 cross chain
             # (wstar3d.h), 16 operators each
             others = []
-            for name, stages, steps in (("c2", 1000, 3), ("c5", 300, 3), ("box", 16, 5), ("wide", 16, 5)):
+            # (>= 10 timed steps each and the median beside the mean: SURVEY.md 8d; the whole set costs about
+            # 1.5 s of GPU time)
+            for name, stages, steps in (("c2", 1000, 10), ("c5", 300, 10), ("box", 16, 12), ("wide", 16, 12),
+                                        ("dense", 4, 12), ("fork", 16, 12)):
                 try:
                     owl = make_workload(name, 0, stages)
                     t = time_single(owl, {}, steps, 1, device=local_rank)
@@ -777,7 +855,8 @@ def main():
                     others.append({"workload": name, "error": "{}: {}".format(type(exc).__name__, str(exc)[:200])})
                     continue
                 others.append({"workload": owl["label"], "value": t["value"], "unit": "Mcells/s", "steps": steps,
-                               "ms_per_step": t["ms_per_step"], "dtype": owl["dtype"], "roofline": t["roofline"],
+                               "ms_per_step": t["ms_per_step"], "median_ms_per_step": t["median_ms_per_step"],
+                               "value_at_median": t["value_at_median"], "dtype": owl["dtype"], "roofline": t["roofline"],
                                "schedule": t["schedule"]})
             result["other_configs"] = others
         if not args.no_cpu_baseline and args.workload == "c3":

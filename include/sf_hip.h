@@ -133,6 +133,26 @@ int sf_plan_kernel_stats(sf_plan* plan, int index, int* launches,
  * option "profile=1"): bench.py times one extra, untimed chain execution this way so that
  * the timed region carries no events.  Synchronises the plan's stream first. */
 int sf_plan_set_profile(sf_plan* plan, int on);
+/* The device compiler of this process: hipRTC and runtime versions and the libamd_comgr file
+ * the process compiles through (with its version).  hipRTC binds comgr by soname, so the copy
+ * loaded first does the work; $SF_HIP_COMGR=<file> pins it: plan creation fails
+ * (SF_ERR_STATE) in a process whose comgr is another file.  The same text ends
+ * sf_plan_describe and is part of the code cache's key.  (The reference compiles each
+ * program with one toolchain, stencilflow/run_program.py:118-128.) */
+const char* sf_compiler_id(void);
+/* Index of the compiled kernel (sf_plan_kernel_name ...) that launch `step` runs. */
+int sf_plan_step_kernel(const sf_plan* plan, int step);
+/* The code object of kernel `index` as the plan will load it (an ELF for gfx950: what hipRTC
+ * compiled, or the cached copy) and the extra compiler flags it was built with; the
+ * pointers stay valid for the life of the plan.  tools/isa_stats.py disassembles it. */
+int sf_plan_kernel_object(const sf_plan* plan, int index, const void** data, size_t* bytes,
+                          const char** flags);
+/* With profiling on: shortest, median and longest HIP-event duration (ms) of the profiled
+ * launches of kernel `index` since the counters were last reset (the first 16384 are kept).
+ * SF_ERR_STATE when none was profiled.  bench.py reports them as roofline.min_us /
+ * median_us / max_us (a median, not only a mean). */
+int sf_plan_kernel_launch_times(sf_plan* plan, int index, double* min_ms,
+                                double* median_ms, double* max_ms);
 /* With profiling on: planes of the outermost dimension written by the launches of kernel
  * `index` in the executions since the counters were last reset (sf_plan_execute,
  * sf_plan_set_profile) -- a decomposed run launches over plane ranges of different

@@ -68,6 +68,8 @@ API = [
     ("sf_plan_kernel_source", _S, [_P, _I]),
     ("sf_plan_kernel_stats", _I, [_P, _I, _IP, _DP, _DP, _DP]),
     ("sf_plan_set_profile", _I, [_P, _I]),
+    ("sf_plan_kernel_launch_times", _I, [_P, _I, _DP, _DP, _DP]),
+    ("sf_plan_kernel_object", _I, [_P, _I, _PP, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_char_p)]),
     ("sf_plan_kernel_planes", _I, [_P, _I, _DP]),
     ("sf_plan_kernel_resources", _I, [_P, _I, _IP, _IP, _IP, _IP, _IP]),
     ("sf_plan_debug_counters", _I, [_P, ctypes.POINTER(ctypes.c_ulonglong), _I]),
@@ -76,6 +78,8 @@ API = [
     ("sf_plan_step_halo", _I, [_P, _I, _IP, _IP]),
     ("sf_plan_step_inputs", _I, [_P, _I, _IP, _I]),
     ("sf_plan_step_output", _I, [_P, _I]),
+    ("sf_plan_step_kernel", _I, [_P, _I]),
+    ("sf_compiler_id", _S, []),
     ("sf_plan_execute_step", _I, [_P, _I, _I, _P]),
     ("sf_plan_execute_step_ranges", _I, [_P, _I, _I, _I, _I, _I, _P]),
     ("sf_plan_set_reserved_cus", _I, [_P, _I]),
@@ -123,6 +127,15 @@ def load_library():
     # this process (device streams, torch.distributed), its copy must be the one
     # that is loaded first, otherwise two runtimes coexist and the second sees
     # no GPU.  libsf_hip.so binds by soname and so shares whichever is resident.
+    # $SF_HIP_COMGR pins the device compiler: hipRTC binds libamd_comgr by soname, so the copy that is
+    # loaded FIRST compiles every kernel of the process (PyTorch brings its own).  Loading the named file
+    # here, globally and before torch, makes it that copy; the library refuses to plan if it is not.
+    pinned = os.environ.get("SF_HIP_COMGR")
+    if pinned:
+        try:
+            ctypes.CDLL(pinned, mode=ctypes.RTLD_GLOBAL)
+        except OSError as exc:
+            raise RuntimeError("SF_HIP_COMGR={}: {}".format(pinned, exc))
     if os.environ.get("SF_HIP_NO_TORCH") != "1":
         try:
             import torch  # noqa: F401
@@ -261,6 +274,22 @@ class Plan:
             out[name] = v.value
         return out
 
+    def kernel_object(self, index):
+        """(code object bytes, extra compiler flags) of kernel ``index``, as the plan loads it."""
+        data, size, flags = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_char_p()
+        _check(self._lib.sf_plan_kernel_object(self._h, index, ctypes.byref(data), ctypes.byref(size), ctypes.byref(flags)))
+        return ctypes.string_at(data.value, size.value), (flags.value or b"").decode()
+
+    def kernel_launch_times(self):
+        """name -> (min, median, max) HIP-event duration in ms of the profiled launches of that
+        kernel (kernels without a profiled launch are left out)."""
+        out = {}
+        for i, name in enumerate(self.kernel_names()):
+            v = [ctypes.c_double() for _ in range(3)]
+            if self._lib.sf_plan_kernel_launch_times(self._h, i, *[ctypes.byref(x) for x in v]) == 0:
+                out[name] = tuple(x.value for x in v)
+        return out
+
     def kernel_resources(self):
         """name -> dict(vgprs, agprs, spills, scratch, lds) from the code object."""
         out = {}
@@ -362,6 +391,14 @@ class Plan:
 
     def step_output(self, step):
         return _check(self._lib.sf_plan_step_output(self._h, step))
+
+    def step_kernel(self, step):
+        """Index (into ``kernel_names()``) of the compiled kernel launch ``step`` runs."""
+        return _check(self._lib.sf_plan_step_kernel(self._h, step))
+
+    def compiler(self):
+        """The device compiler of this process (hipRTC + the libamd_comgr it binds, with versions)."""
+        return (self._lib.sf_compiler_id() or b"?").decode()
 
     def execute_step(self, step, part=0, stream=None):
         _check(

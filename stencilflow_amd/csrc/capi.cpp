@@ -2,6 +2,8 @@
 // checks, status codes, nothing throws across the boundary.
 #include "sf_internal.hpp"
 
+#include <algorithm>
+
 #include <cstdlib>
 #include <memory>
 
@@ -192,6 +194,44 @@ int sf_plan_kernel_stats(sf_plan* p, int i, int* launches, double* total_ms, dou
   if (alg_bytes) *alg_bytes = k.alg_bytes_per_launch;
   return SF_OK;
 }
+const char* sf_compiler_id(void) {
+  static thread_local std::string id;
+  try {
+    id = sf::compiler_id();
+  } catch (...) {
+    id = "?";
+  }
+  return id.c_str();
+}
+int sf_plan_step_kernel(const sf_plan* p, int step) {
+  if (!p || step < 0 || step >= (int)p->steps.size()) return SF_ERR_INVALID;
+  return p->steps[step].ck;
+}
+int sf_plan_kernel_object(const sf_plan* p, int i, const void** data, size_t* bytes, const char** flags) {
+  if (!p || i < 0 || i >= (int)p->kernels.size()) return SF_ERR_INVALID;
+  const CompiledKernel& k = p->kernels[i];
+  if (data) *data = k.code.data();
+  if (bytes) *bytes = k.code.size();
+  if (flags) *flags = k.flags.c_str();
+  return SF_OK;
+}
+int sf_plan_kernel_launch_times(sf_plan* plan, int i, double* min_ms, double* median_ms, double* max_ms) {
+  SF_API_BEGIN
+  if (!plan || i < 0 || i >= (int)plan->kernels.size()) throw Error(SF_ERR_INVALID, "sf_plan_kernel_launch_times: bad argument");
+  if (plan->device_ready && plan->profile) {
+    SF_HIP_CHECK(hipSetDevice(plan->device));
+    SF_HIP_CHECK(hipStreamSynchronize(plan->stream));
+    collect_profile(*plan);
+  }
+  std::vector<float> v = plan->kernels[i].launch_ms;
+  if (v.empty()) throw Error(SF_ERR_STATE, "sf_plan_kernel_launch_times: no profiled launch of this kernel (sf_plan_set_profile)");
+  std::sort(v.begin(), v.end());
+  if (min_ms) *min_ms = v.front();
+  if (max_ms) *max_ms = v.back();
+  if (median_ms) *median_ms = v.size() % 2 ? v[v.size() / 2] : 0.5 * (v[v.size() / 2 - 1] + v[v.size() / 2]);
+  return SF_OK;
+  SF_API_END
+}
 int sf_plan_set_profile(sf_plan* plan, int on) {
   SF_API_BEGIN
   if (!plan) throw Error(SF_ERR_INVALID, "null plan");
@@ -204,6 +244,7 @@ int sf_plan_set_profile(sf_plan* plan, int on) {
     k.launches = 0;
     k.total_ms = 0;
     k.planes_launched = 0;
+    k.launch_ms.clear();
   }
   plan->profile = on != 0;
   return SF_OK;

@@ -3,6 +3,8 @@
 #include "sf_internal.hpp"
 
 #include <amd_comgr/amd_comgr.h>
+#include <climits>
+#include <cstdlib>
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
@@ -188,6 +190,45 @@ static std::map<std::string, std::vector<char>> g_code_cache;  // name + source 
 
 // <dir>/<hash>.co, or "" when the disk cache is off.  Directory: $SF_HIP_CACHE_DIR
 // ("off" disables), default $XDG_CACHE_HOME or ~/.cache + /stencilflow_amd.
+// The device compiler of this process: hipRTC major.minor, the HIP runtime's full version number (patch level
+// included), the build id of the ROCm headers this library was compiled against -- and the libamd_comgr the
+// process really compiles through: hipRTC binds libamd_comgr by soname, so whichever copy was loaded first does
+// the work (PyTorch's bundled copy after `import torch`, ROCm's in a process without torch or when a profiler
+// preloads it): same versions reported, different compilers (round 3: C5's five-row tile spills under one of
+// them).  $SF_HIP_COMGR pins it: stencilflow_amd.backend loads that file first, and a process whose comgr is
+// another file is refused at plan creation (check_pinned_compiler) instead of compiling other code silently.
+std::string compiler_id() {
+  int major = 0, minor = 0, runtime = 0;
+  hiprtcVersion(&major, &minor);
+  (void)hipRuntimeGetVersion(&runtime);
+  size_t cmaj = 0, cmin = 0;
+  amd_comgr_get_version(&cmaj, &cmin);
+  Dl_info comgr_lib;
+  const char* comgr_path = (::dladdr(reinterpret_cast<void*>(&amd_comgr_get_version), &comgr_lib) && comgr_lib.dli_fname)
+                               ? comgr_lib.dli_fname
+                               : "?";
+  return "hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " runtime " + std::to_string(runtime) +
+         " build " + HIP_VERSION_GITHASH + " comgr " + comgr_path + " (" + std::to_string(cmaj) + "." +
+         std::to_string(cmin) + ")";
+}
+
+void check_pinned_compiler() {
+  const char* want = std::getenv("SF_HIP_COMGR");
+  if (!want || !*want) return;
+  Dl_info comgr_lib;
+  const char* have = (::dladdr(reinterpret_cast<void*>(&amd_comgr_get_version), &comgr_lib) && comgr_lib.dli_fname)
+                         ? comgr_lib.dli_fname
+                         : "";
+  char a[PATH_MAX], b[PATH_MAX];
+  const char* ra = ::realpath(want, a);
+  const char* rb = ::realpath(have, b);
+  if (!ra) throw Error(SF_ERR_INVALID, std::string("SF_HIP_COMGR names '") + want + "', which does not exist");
+  if (!rb || std::strcmp(ra, rb) != 0)
+    throw Error(SF_ERR_STATE, std::string("SF_HIP_COMGR pins the device compiler to ") + ra + " but this process compiles through " +
+                                  (rb ? rb : have) + ": that library must be loaded before libhiprtc (stencilflow_amd.backend does so; "
+                                  "a C program: LD_PRELOAD it or link it first)");
+}
+
 static std::string disk_cache_path(const std::string& key) {
   const char* env = std::getenv("SF_HIP_CACHE_DIR");
   std::string dir;
@@ -205,22 +246,9 @@ static std::string disk_cache_path(const std::string& key) {
   const size_t slash = dir.rfind('/');
   if (slash != std::string::npos && slash > 0) ::mkdir(dir.substr(0, slash).c_str(), 0755);
   if (::mkdir(dir.c_str(), 0755) != 0 && errno != EEXIST) return "";
-  // the compiler that would produce this object: hipRTC major.minor, the HIP
-  // runtime's full version number (patch level included) and the build id of the
-  // ROCm headers this library was compiled against
-  int major = 0, minor = 0, runtime = 0;
-  hiprtcVersion(&major, &minor);
-  (void)hipRuntimeGetVersion(&runtime);
-  // ... and the comgr the process really compiles through: hipRTC calls whichever libamd_comgr was
-  // loaded first (PyTorch's bundled copy, or ROCm's when a profiler preloads it) -- same versions
-  // reported, different compilers (round 3: C5's five-row tile spills under one of them)
-  Dl_info comgr_lib;
-  const char* comgr_path = (::dladdr(reinterpret_cast<void*>(&amd_comgr_get_version), &comgr_lib) && comgr_lib.dli_fname)
-                               ? comgr_lib.dli_fname
-                               : "?";
-  const std::string salted = key + "\nhiprtc " + std::to_string(major) + "." + std::to_string(minor) +
-                             " runtime " + std::to_string(runtime) + " build " + HIP_VERSION_GITHASH + " comgr " +
-                             comgr_path + "\ngfx950 -O3 -std=c++17 -ffp-contract=off";
+  // the compiler that would produce this object (compiler_id(): hipRTC, runtime, build of the ROCm headers, and
+  // the libamd_comgr the process really compiles through)
+  const std::string salted = key + "\n" + compiler_id() + "\ngfx950 -O3 -std=c++17 -ffp-contract=off";
   char name[40];
   std::snprintf(name, sizeof name, "%016llx%08x", (unsigned long long)fnv1a(salted), (unsigned)salted.size());
   return dir + "/" + name + ".co";

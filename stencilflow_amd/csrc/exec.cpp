@@ -200,6 +200,7 @@ void collect_profile(sf_plan& pl) {
     pl.kernels[pl.prof_kernel[i]].launches += 1;
     pl.kernels[pl.prof_kernel[i]].total_ms += ms;
     pl.kernels[pl.prof_kernel[i]].planes_launched += pl.prof_planes[i];
+    if (pl.kernels[pl.prof_kernel[i]].launch_ms.size() < 16384) pl.kernels[pl.prof_kernel[i]].launch_ms.push_back(ms);
     (void)hipEventDestroy(pl.prof_events[i].first);
     (void)hipEventDestroy(pl.prof_events[i].second);
   }

@@ -185,7 +185,8 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   // (defaults: the ring for 2-D and f32 3-D -- C2 +10 %, C3 +1.7 %, hotspot chains
   // +1 % with k1.bio; staging registers for f64, whose ring needs a smaller tile)
   base.prefetch2 = base.reverse ? 0 : (int)pl.opt.get("k1.pf2", (base.noj || dt == DT::F32) ? 2 : 1);
-  if (base.prefetch2 < 0 || base.prefetch2 > 2) throw Error(SF_ERR_INVALID, "k1.pf2 must be 0, 1 or 2");
+  // (3: a five-slot ring, two planes in flight beside the window -- 20 registers more at five rows per thread)
+  if (base.prefetch2 < 0 || base.prefetch2 > 3) throw Error(SF_ERR_INVALID, "k1.pf2 must be 0, 1, 2 or 3");
   base.uniform_loads = (int)pl.opt.get("k1.ul", 0);
   // planes through buffer instructions (out-of-range offsets instead of branches
   // around loads and stores); a plane must stay well below the 2 GiB offset range
@@ -196,7 +197,7 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   base.buffer_io = plane_bytes <= 1024.0 * 1024 * 1024 ? (int)pl.opt.get("k1.bio", 1) : 0;
   base.pfd = (int)pl.opt.get("k1.pfd", 1);
   if (base.pfd != 1 && base.pfd != 3) throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
-  if ((base.prefetch2 != 1 && base.reverse != 2) || base.prefetch2 == 2) base.pfd = 1;
+  if ((base.prefetch2 != 1 && base.reverse != 2) || base.prefetch2 >= 2) base.pfd = 1;
   base.experiment = (int)pl.opt.get("experiment", 0);
   // lane exchange: 0 = __shfl, 1 = DPP, 2 = DPP with bound_ctrl (no copy before the
   // move), 3 = as 2 and the wave's edge lane gets its value (boundary constant or
@@ -209,6 +210,7 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   base.uniform = (int)pl.opt.get("k1.uni", 0);
   // halo rows of the tile no later stage reads are not evaluated (star3d.h: SF_SKIP_ROWS)
   base.skip_rows = (int)pl.opt.get("k1.skip", 0);
+  base.wmap = (int)pl.opt.get("k1.wmap", 0);
   // logical tile order inside an XCD's share of the grid: 1 = k-tiles fastest, so that the share is a band of whole
   // tile rows and all its k-neighbours (which re-read each other's halo columns) meet in one L2.  C5 (16 x 5 tiles):
   // FETCH 1.2445 -> 1.1922 GB per launch, 0.7 % faster (profiles/r03_c5_tile_order.log); no k-tiles: same order
@@ -635,6 +637,7 @@ std::string describe_plan(const sf_plan& pl) {
     if (desc.tellp() > 16384) break;  // long chains: describe the first launches only
     describe_step(desc, pl, st);
   }
+  desc << "  compiler: " << compiler_id() << "\n";
   return desc.str();
 }
 
@@ -645,8 +648,8 @@ static void validate_options(const sf_plan& pl) {
     const char* key;
     long long lo, hi;
   };
-  static const Range ranges[] = {{"k1.pf2", 0, 2}, {"k1.rev", 0, 2},  {"k1.dpp", 0, 4},   {"k1.bio", 0, 3},
-                                 {"k1.ul", 0, 1},  {"k1.db", 0, 1},   {"k1.nt", 0, 3},    {"k1.auxpre", 0, 2},
+  static const Range ranges[] = {{"k1.pf2", 0, 3}, {"k1.rev", 0, 2},  {"k1.dpp", 0, 4},   {"k1.bio", 0, 3},
+                                 {"k1.ul", 0, 1},  {"k1.db", 0, 1},   {"k1.nt", 0, 7},    {"k1.auxpre", 0, 2},
                                  {"graph", 0, 1},  {"autotune", 0, 8}, {"k1.order", 0, 1}};
   for (const Range& r : ranges) {
     if (!pl.opt.kv.count(r.key)) continue;
@@ -662,7 +665,57 @@ static void validate_options(const sf_plan& pl) {
     throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
 }
 
+// Depth-first topological order of the operators: an operator is followed by a consumer that has become ready,
+// so the operators of one branch of a fork (bin/synthesize.py:228-253 emits b3a0 b3b0 b3a1 b3b1 -- the order of
+// networkx' topological sort, reference sdfg_generator.py:638) sit next to each other and fuse like any chain.
+// Any topological order gives the same results (every operator is a pure function of complete fields); a chain
+// keeps its order.  Option reorder=0 keeps the order of the program record.
+static void reorder_depth_first(Program& P) {
+  const int K = (int)P.kernels.size();
+  std::map<std::string, int> producer;
+  for (int k = 0; k < K; ++k) producer[P.kernels[k].name] = k;
+  std::vector<std::vector<int>> consumers(K);
+  std::vector<int> waiting(K, 0);
+  for (int k = 0; k < K; ++k) {
+    std::set<int> deps;
+    for (auto& a : P.kernels[k].acc) {
+      auto it = producer.find(a.field);
+      if (it != producer.end() && it->second != k) deps.insert(it->second);
+    }
+    waiting[k] = (int)deps.size();
+    for (int d : deps) consumers[d].push_back(k);
+  }
+  std::vector<int> order;
+  std::vector<char> done(K, 0);
+  std::vector<int> stack;
+  for (int seed = 0; seed < K; ++seed) {
+    if (done[seed] || waiting[seed] != 0) continue;
+    stack.push_back(seed);
+    while (!stack.empty()) {
+      const int k = stack.back();
+      stack.pop_back();
+      if (done[k] || waiting[k] != 0) continue;
+      done[k] = 1;
+      order.push_back(k);
+      // consumers in program order: the first one is taken next (pushed last)
+      for (auto it = consumers[k].rbegin(); it != consumers[k].rend(); ++it) {
+        if (--waiting[*it] == 0) stack.push_back(*it);
+      }
+    }
+  }
+  if ((int)order.size() != K) return;  // (a cycle: left to the checks that report it)
+  bool same = true;
+  for (int i = 0; i < K; ++i) same = same && order[i] == i;
+  if (same) return;
+  std::vector<Kernel> sorted;
+  sorted.reserve(K);
+  for (int k : order) sorted.push_back(P.kernels[k]);
+  P.kernels.swap(sorted);
+}
+
 void build_plan(sf_plan& pl) {
+  check_pinned_compiler();
+  if (pl.opt.get("reorder", 1) != 0) reorder_depth_first(pl.P);
   const Program& P = pl.P;
   const int K = (int)P.kernels.size();
   pl.profile = pl.opt.get("profile", 0) != 0;

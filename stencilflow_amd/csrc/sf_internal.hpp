@@ -60,6 +60,7 @@ struct CompiledKernel {
   int launches = 0;
   double total_ms = 0;
   double planes_launched = 0;  // planes written by the profiled launches
+  std::vector<float> launch_ms;  // durations of the profiled launches (the first 16384), for min / median / max
   double updates_per_launch = 0, alg_bytes_per_launch = 0;
   // from the code object's amdhsa metadata (msgpack note)
   int vgprs = -1, agprs = -1, sgprs = -1, spills = -1, scratch = -1, lds = -1, sgpr_spills = -1;
@@ -158,6 +159,10 @@ void code_cache_stats(long* disk_hits, long* compiled, long* rebuilt, bool drop_
 CompiledKernel compile_cached(const std::string& prefix, const std::string& source, const std::string& flags);
 // store the self-check's verdict with the code object (process and disk level)
 void record_verdict(CompiledKernel& k, int verdict);
+
+// the device compiler of this process (hipRTC + the comgr it binds); $SF_HIP_COMGR pins the latter
+std::string compiler_id();
+void check_pinned_compiler();
 
 // ---- planner.cpp: launch groups, tile search, buffers
 void build_plan(sf_plan& pl);

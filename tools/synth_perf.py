@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--stages", type=int, default=16)
     ap.add_argument("--only", default="", help="run the cases whose label contains this text")
     ap.add_argument("--opts", default="", help="plan options, e.g. k1.bio=1;k1.pf2=2")
+    ap.add_argument("--fork", action="store_true",
+                    help="only the fork / join programs (-fork_frequency 0.25), each with reorder=0 and reorder=1")
     args = ap.parse_args()
     n, st = args.size, args.stages
     cases = [
@@ -50,11 +52,25 @@ def main():
         ("big box 3-D f32 (radius 2, 125 points)", ("float32", min(st, 4), 0.0, n, n, n, 2, 2, 2), {"stencil_shape": "box"}),
         ("big box 2-D f32 (radius 2, 25 points)", ("float32", min(st, 8), 0.0, 8 * n, 8 * n, 0, 2, 2, 0), {"stencil_shape": "box"}),
     ]
+    # fork / join sections (reference bin/synthesize.py:228-253): two branches of two operators every fourth operator
+    forks = [
+        ("fork 3-D f32", ("float32", st, 0.0, n, n, n, 1, 1, 1), {"fork_frequency": 0.25}),
+        ("fork 2-D f32", ("float32", st, 0.0, 8 * n, 8 * n, 0, 1, 1, 0), {"fork_frequency": 0.25}),
+        ("fork 3-D f64", ("float64", st, 0.0, n, n, n, 1, 1, 1), {"fork_frequency": 0.25}),
+    ]
+    if args.fork:
+        cases = [(label + " " + o, pos, dict(kw, _opts=o)) for label, pos, kw in forks for o in ("reorder=0", "reorder=1")]
+    else:
+        cases += forks
     rng = np.random.default_rng(5)
     with tempfile.TemporaryDirectory() as tmp:
         for label, pos, kw in cases:
             if args.only and args.only not in label:
                 continue
+            kw = dict(kw)
+            case_opts = kw.pop("_opts", "")
+            if case_opts:
+                args.opts = case_opts
             prog, _ = programs.synthesize(*pos, **kw)
             path = programs.write_program(prog, os.path.join(tmp, "p.json"))
             chain = sf.KernelChainGraph(path)
