@@ -189,6 +189,10 @@ int sf_plan_step_halo(const sf_plan* plan, int step, int* buffer_id,
 int sf_plan_step_inputs(const sf_plan* plan, int step, int* buffer_ids,
                         int capacity);
 int sf_plan_step_output(const sf_plan* plan, int step);
+/* All buffers step `step` writes (same convention as sf_plan_step_inputs).  One for every launch but a DAG group
+ * (round 4: a fork's branches, a join, an intermediate with several readers fused into one launch), which
+ * materialises every field something outside the group reads; sf_plan_step_output is the first of them. */
+int sf_plan_step_outputs(const sf_plan* plan, int step, int* buffer_ids, int capacity);
 /* Execute one step on `stream` (a hipStream_t, or NULL for the plan's own).
  * part: 0 = whole slab, 1 = planes adjacent to the lower slab boundary,
  *       2 = planes adjacent to the upper boundary, 3 = interior only. */

@@ -78,6 +78,7 @@ API = [
     ("sf_plan_step_halo", _I, [_P, _I, _IP, _IP]),
     ("sf_plan_step_inputs", _I, [_P, _I, _IP, _I]),
     ("sf_plan_step_output", _I, [_P, _I]),
+    ("sf_plan_step_outputs", _I, [_P, _I, _IP, _I]),
     ("sf_plan_step_kernel", _I, [_P, _I]),
     ("sf_compiler_id", _S, []),
     ("sf_plan_execute_step", _I, [_P, _I, _I, _P]),
@@ -391,6 +392,12 @@ class Plan:
 
     def step_output(self, step):
         return _check(self._lib.sf_plan_step_output(self._h, step))
+
+    def step_outputs(self, step):
+        """Buffers launch ``step`` writes (several for a DAG group)."""
+        ids = (ctypes.c_int * 8)()
+        n = _check(self._lib.sf_plan_step_outputs(self._h, step, ids, 8))
+        return [ids[i] for i in range(n)]
 
     def step_kernel(self, step):
         """Index (into ``kernel_names()``) of the compiled kernel launch ``step`` runs."""

@@ -294,6 +294,12 @@ int sf_plan_step_inputs(const sf_plan* p, int step, int* buffer_ids, int capacit
   for (int i = 0; buffer_ids && i < (int)in.size() && i < capacity; ++i) buffer_ids[i] = in[i];
   return (int)in.size();
 }
+int sf_plan_step_outputs(const sf_plan* p, int step, int* buffer_ids, int capacity) {
+  if (!p || step < 0 || step >= (int)p->steps.size()) return SF_ERR_INVALID;
+  const std::vector<int>& out = p->steps[step].out_bufs;
+  for (int i = 0; buffer_ids && i < (int)out.size() && i < capacity; ++i) buffer_ids[i] = out[i];
+  return (int)out.size();
+}
 int sf_plan_step_output(const sf_plan* p, int step) {
   if (!p || step < 0 || step >= (int)p->steps.size()) return SF_ERR_INVALID;
   return p->steps[step].out_buf;

@@ -3,6 +3,8 @@
 // (Role in the reference: program(**dace_args), stencilflow/run_program.py:164-178.)
 #include "sf_internal.hpp"
 
+#include <map>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -148,6 +150,13 @@ void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, int i_be
     for (size_t a = 1; a < st.in_bufs.size() && a <= (size_t)kMaxStarAux; ++a)
       aux_ptrs[a - 1] = pl.buffers[st.in_bufs[a]].d;
     args = {&ptrs[0], &ptrs[1], scalar_store, aux_ptrs, &halo, &goff, &i_begin, &i_end, &li_i, &nch1, &i_begin2, &i_end2};
+    // a DAG group that materialises several fields: the further output pointers (kernels/star3d.h: sf_more_outs)
+    void* more_outs[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (st.out_bufs.size() > 1) {
+      if (st.out_bufs.size() > 5) throw Error(SF_ERR_STATE, "star launch: too many outputs");
+      for (size_t o = 1; o < st.out_bufs.size(); ++o) more_outs[o - 1] = pl.buffers[st.out_bufs[o]].d;
+      args.push_back(more_outs);
+    }
     if (c.stamp) args.push_back(&pl.debug_buffer);
     SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(tiles * (nch1 + nch2)), 1, 1, c.BX, c.BY, 1, 0,
                                        stream, args.data(), nullptr));
@@ -452,7 +461,9 @@ bool calls_device_math(const Kernel& K) {
 
 long self_checks_run() { return g_self_checks.load(); }
 
-// Compare the fused launch `st` with its operators run one by one, over planes [b, e).
+// Compare the fused launch `st` with its operators run one by one, over planes [b, e).  The operators of the group
+// are a DAG in stage order (a chain: each reads the one before): an operator reads the group's input buffers or the
+// scratch results of earlier operators, and every field the launch materialises is compared.
 static unsigned long long self_check_range(sf_plan& pl, const Step& st, std::vector<CompiledKernel*>& refs,
                                            const std::vector<GenericKernelSource>& gens, int b, int e) {
   const Program& P = pl.P;
@@ -463,15 +474,24 @@ static unsigned long long self_check_range(sf_plan& pl, const Step& st, std::vec
   const size_t plane_bytes = primary.plane_bytes;
   // planes a launch may touch: inside the global domain and inside the buffers
   const int q_lo = std::max(-halo, -goff), q_hi = std::min(n + halo, (int)(P.n[0] - goff));
-  // how far each operator reaches along the stream axis, and how far the operators after it do
-  // together: operator s of the group must produce planes [b - after[s + 1], e + after[s + 1])
-  std::vector<int> after(T + 1, 0);
+  // producer (position in the group) of every field made inside the group
+  std::map<std::string, int> made;
+  for (int s = 0; s < T; ++s) made[P.kernels[st.kernels[s]].name] = s;
+  // need[s]: how many planes beyond [b, e) operator s must produce for the operators that read it
+  std::vector<int> reach(T, 0), need(T, 0);
+  for (int s = 0; s < T; ++s)
+    for (auto& a : P.kernels[st.kernels[s]].acc) reach[s] = std::max(reach[s], std::abs(a.off[0]));
+  int input_need = 0;
   for (int s = T - 1; s >= 0; --s) {
-    int reach = 0;
-    for (auto& a : P.kernels[st.kernels[s]].acc) reach = std::max(reach, std::abs(a.off[0]));
-    after[s] = after[s + 1] + reach;  // (after[s] counts operator s itself: what its INPUT must cover)
+    bool reads_memory = false;
+    for (auto& a : P.kernels[st.kernels[s]].acc) {
+      auto it = made.find(a.field);
+      if (it != made.end() && it->second < s) need[it->second] = std::max(need[it->second], need[s] + reach[s]);
+      else reads_memory = true;
+    }
+    if (reads_memory) input_need = std::max(input_need, need[s] + reach[s]);
   }
-  const int lo_s = std::max(q_lo, b - after[0]), hi_s = std::min(q_hi, e + after[0]);
+  const int lo_s = std::max(q_lo, b - input_need), hi_s = std::min(q_hi, e + input_need);
   std::vector<void*> scratch(T, nullptr);
   unsigned* d_count = nullptr;
   unsigned long long bad = 0;
@@ -485,15 +505,16 @@ static unsigned long long self_check_range(sf_plan& pl, const Step& st, std::vec
     for (int s = 0; s < T; ++s) {
       const Kernel& K = P.kernels[st.kernels[s]];
       const GenericKernelSource& g = gens[s];
-      const int rb = std::max(q_lo, b - after[s + 1]), re = std::min(q_hi, e + after[s + 1]);
+      const int rb = std::max(q_lo, b - need[s]), re = std::min(q_hi, e + need[s]);
       // (a scratch buffer holds planes [lo_s, hi_s): the kernels index planes from the start of a slab
       // buffer, so they are handed the address plane -halo would have)
       auto virtual_base = [&](void* p) { return (void*)((char*)p - (long long)(lo_s + halo) * (long long)plane_bytes); };
       std::vector<void*> ptrs;
       for (auto& name : g.reads) {
         void* p = nullptr;
-        if (s > 0 && name == P.kernels[st.kernels[s - 1]].name) {
-          p = virtual_base(scratch[s - 1]);
+        auto it = made.find(name);
+        if (it != made.end() && it->second < s) {
+          p = virtual_base(scratch[it->second]);
         } else {
           for (size_t r = 0; r < st.read_names.size(); ++r)
             if (st.read_names[r] == name) p = pl.buffers[st.in_bufs[r]].d;
@@ -530,15 +551,19 @@ static unsigned long long self_check_range(sf_plan& pl, const Step& st, std::vec
         SF_HIP_CHECK(hipModuleLaunchKernel(refs[s]->fn, (unsigned)((plane + 255) / 256), (unsigned)(re - rb), 1, 256, 1, 1, 0,
                                            pl.stream, args.data(), nullptr));
     }
-    const Buffer& out = pl.buffers[st.out_buf];
     const unsigned long long words = (unsigned long long)(e - b) * plane_bytes / size_of(dt);
     bool math = false;
     for (int k : st.kernels) math = math || calls_device_math(P.kernels[k]);
-    hipLaunchKernelGGL(sf_check_diff, dim3(1024), dim3(256), 0, pl.stream,
-                       (const void*)((char*)out.d + (size_t)(b + halo) * plane_bytes),
-                       (const void*)((char*)scratch[T - 1] + (size_t)(b - lo_s) * plane_bytes), words, dt_code(dt),
-                       math ? 1e-6 : 0.0, d_count);
-    SF_HIP_CHECK(hipGetLastError());
+    // every materialised field against the scratch result of the operator that makes it
+    for (size_t o = 0; o < st.out_bufs.size(); ++o) {
+      const Buffer& out = pl.buffers[st.out_bufs[o]];
+      const int maker = o < st.out_names.size() && made.count(st.out_names[o]) ? made[st.out_names[o]] : T - 1;
+      hipLaunchKernelGGL(sf_check_diff, dim3(1024), dim3(256), 0, pl.stream,
+                         (const void*)((char*)out.d + (size_t)(b + halo) * plane_bytes),
+                         (const void*)((char*)scratch[maker] + (size_t)(b - lo_s) * plane_bytes), words, dt_code(dt),
+                         math ? 1e-6 : 0.0, d_count);
+      SF_HIP_CHECK(hipGetLastError());
+    }
     unsigned h_count = 0;
     SF_HIP_CHECK(hipMemcpyAsync(&h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, pl.stream));
     SF_HIP_CHECK(hipStreamSynchronize(pl.stream));
@@ -612,7 +637,7 @@ void self_check(sf_plan& pl) {
         SF_HIP_CHECK(hipGetLastError());
         dirty.insert(st.in_bufs[r]);
       }
-      dirty.insert(st.out_buf);
+      for (int ob : st.out_bufs) dirty.insert(ob);
       // planes next to both ends of the slab (all of it when it is thin)
       const int span = 6 + 2 * st.halo_depth;
       unsigned long long bad = 0;

@@ -653,7 +653,7 @@ extern "C" int sf_plan_execute_decomposed(sf_plan* plan, sf_halo* halo, int repe
   bool chain = true;
   for (size_t s = 0; s < pl.steps.size(); ++s) {
     const Step& st = pl.steps[s];
-    if (st.in_bufs.size() != 1 || (s > 0 && st.in_bufs[0] != pl.steps[s - 1].out_buf)) chain = false;
+    if (st.in_bufs.size() != 1 || st.out_bufs.size() != 1 || (s > 0 && st.in_bufs[0] != pl.steps[s - 1].out_buf)) chain = false;
   }
   auto reach_of = [&](size_t s) { return pl.steps[s].halo_buf >= 0 ? pl.steps[s].halo_depth : 0; };
   auto exchange_all = [&](const std::vector<int>& bufs, int depth) {
@@ -686,7 +686,8 @@ extern "C" int sf_plan_execute_decomposed(sf_plan* plan, sf_halo* halo, int repe
   // filled once per call, to the full halo depth, at the first launch that reads them
   std::set<int> fixed, fresh;
   for (int i = 0; i < P.num_inputs; ++i) fixed.insert(pl.input_buf[i]);
-  for (const Step& st : pl.steps) fixed.erase(st.out_buf);
+  for (const Step& st : pl.steps)
+    for (int ob : st.out_bufs) fixed.erase(ob);
   for (int rep = 0; rep < repetitions; ++rep) {
     int valid = 0;        // ghost planes of the chain's current field that are still good
     long long early = -1;  // step whose exchange was started a launch ahead

@@ -67,9 +67,6 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #ifndef SF_SKIP_ROWS
 #define SF_SKIP_ROWS 0
 #endif
-#ifndef SF_WMAP
-#define SF_WMAP 0
-#endif
 #define SF_SLOTS 4
 #define SF_NWIN (SF_T + SF_NX)
 #define SF_TJH (SF_BY * SF_RJ)
@@ -562,16 +559,7 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   sf_ctx cx;
   cx.in = in;
   cx.xp = xp;
-#if SF_WMAP
-  // (star3d.h: SF_WMAP) hardware waves 2m and 2m + 1 play the m-th wave of the outer and of the inner thread rows
-  static_assert(SF_BY == 4, "SF_WMAP: four thread rows (two outer, two inner)");
-  const int hw_wave = __builtin_amdgcn_readfirstlane((((int)threadIdx.y * SF_BX + (int)threadIdx.x) >> 6));
-  const int wm = hw_wave >> 1;
-  const int sf_tid_y = (hw_wave & 1) == 0 ? (wm < SF_WPR ? 0 : SF_BY - 1) : 1 + wm / SF_WPR;
-  const int sf_tid_x = (wm % SF_WPR) * 64 + ((int)threadIdx.x & 63);
-#else
   const int sf_tid_x = (int)threadIdx.x, sf_tid_y = (int)threadIdx.y;
-#endif
   cx.tx = sf_tid_x;
   cx.ty = sf_tid_y;
   cx.wave = cx.tx >> 6;

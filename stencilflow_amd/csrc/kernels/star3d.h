@@ -51,7 +51,29 @@
 //   typedef sf_t, struct sf_scalars, struct sf_auxptrs,
 //   template<int S> struct sf_stage {bc(), bc_zero, bc_copy, load_aux(), apply()}.
 
+// A fused group is a DAG of SF_NS stages over SF_NW register windows with SF_NOUT materialised fields
+// (codegen: sf_stage<S>::src / src2 / dst / out / depth / refill, sf_win<W>::bc); SF_T is its depth, i.e. the halo
+// of a tile and the warm-up planes of a chunk.  A chain: SF_NS = SF_NW = SF_T, SF_NOUT = 1.
+#ifndef SF_NS
+#define SF_NS SF_T
+#endif
+#ifndef SF_NW
+#define SF_NW SF_T
+#endif
+#ifndef SF_NOUT
+#define SF_NOUT 1
+#endif
+#ifndef SF_DAG
+#define SF_DAG 0
+#endif
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
+// the fields a launch materialises (argument `out` is p[0]; further outputs of a DAG group follow in `more`)
+struct sf_outptrs {
+  sf_t* p[SF_NOUT > 0 ? SF_NOUT : 1];
+};
+struct sf_more_outs {
+  void* p[SF_NOUT > 1 ? SF_NOUT - 1 : 1];
+};
 
 #ifndef SF_REVERSE
 #define SF_REVERSE 0
@@ -128,7 +150,7 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #if SF_NOJ
 #define SF_ROWS_ELEMS 0
 #else
-#define SF_ROWS_ELEMS (SF_T * SF_BY * 2 * SF_TKH)
+#define SF_ROWS_ELEMS (SF_NW * SF_BY * 2 * SF_TKH)
 #endif
 #define SF_USE_LDS (!(SF_NOJ && SF_WPR == 1))
 // (SF_DPP 4: one virtual wave below and one above every row hold the boundary
@@ -136,7 +158,7 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 // they exist)
 #define SF_VWAVES (SF_DPP == 4 && SF_WPR > 1)
 #define SF_EDGE_WAVES (SF_VWAVES ? SF_WPR + 2 : SF_WPR)
-#define SF_EDGE_ELEMS (SF_T * SF_BY * SF_RJ * SF_EDGE_WAVES * 2)
+#define SF_EDGE_ELEMS (SF_NW * SF_BY * SF_RJ * SF_EDGE_WAVES * 2)
 #define SF_IMAGE_ELEMS (SF_ROWS_ELEMS + SF_EDGE_ELEMS)
 
 // w[s][slot][row]: planes of stage-s data (s = 0 is the input field).  At
@@ -159,10 +181,10 @@ struct sf_auxslots<0> {};
 
 struct sf_state
 #if SF_AUX_AHEAD == 2
-    : sf_auxslots<SF_T>
+    : sf_auxslots<SF_NS>
 #endif
 {
-  sf_vec w[SF_T][SF_SLOTS][SF_RJ];
+  sf_vec w[SF_NW][SF_SLOTS][SF_RJ];
 #if SF_REVERSE == 2 || SF_PREFETCH2 == 1
   // input planes in flight: a ring of SF_PFD (1 or 3) planes, so a load has
   // SF_PFD full steps to land (slot = phase % SF_PFD)
@@ -190,7 +212,7 @@ struct sf_ctx {
   bool tile_inside;  // block-uniform: every point of the tile lies in the (j,k) domain
   int goff, halo, cb, ce, j0, k0;
 #if SF_SKIP_ROWS
-  unsigned need_rows[SF_T];  // wave-uniform: bit r set = stage s + 1 evaluates row r of this thread row
+  unsigned need_rows[SF_NS];  // wave-uniform: bit r set = stage s + 1 evaluates row r of this thread row
 #endif
 #if SF_BUFFER_IO
   // byte offset of this lane's vector in row r of a plane, or SF_OOB where the
@@ -332,10 +354,10 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, con
 #else
   sf_vec v = sf_buf_load<sf_vec, (SF_NT & 2) ? 2 : 0>(rs, cx.ld_off[r]);
 #endif
-  if constexpr (!sf_stage<1>::bc_zero) {
+  if constexpr (!sf_win<0>::bc_zero) {
     const bool ok = plane_ok && cx.ld_off[r] != SF_OOB;
 #pragma unroll
-    for (int e = 0; e < SF_VK; ++e) v[e] = ok ? v[e] : sf_stage<1>::bc();
+    for (int e = 0; e < SF_VK; ++e) v[e] = ok ? v[e] : sf_win<0>::bc();
   }
   return v;
 #else
@@ -354,10 +376,10 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, con
       return *src;
 #endif
     }
-    return (sf_vec)sf_stage<1>::bc();
+    return (sf_vec)sf_win<0>::bc();
   }
 #endif
-  sf_vec v = (sf_vec)sf_stage<1>::bc();
+  sf_vec v = (sf_vec)sf_win<0>::bc();
   if (sf_row_ok(cx, p, r)) {
 #if SF_NT & 2
     v = __builtin_nontemporal_load(src);
@@ -386,7 +408,7 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, con
 template <int S>
 __device__ __forceinline__ typename sf_stage<S>::aux_row sf_aux_row(const sf_ctx& cx, const int q, const int r) {
   const bool plane_ok = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G) && (q + cx.halo >= 0) &&
-                        q >= cx.cb - (SF_T - S) && q < cx.ce + (SF_T - S);
+                        q >= cx.cb - (SF_T - sf_stage<S>::depth) && q < cx.ce + (SF_T - sf_stage<S>::depth);
   const bool row_ok = ((cx.jmask >> r) & 1u) != 0;
 #if SF_BIO_LOADS
   // never under a branch: a plane this stage does not evaluate has zero records
@@ -415,6 +437,12 @@ __device__ __forceinline__ sf_aux_passed sf_aux_take(const sf_ctx& cx, const int
 }
 #endif
 
+__device__ __forceinline__ void sf_load_plane(const sf_t* __restrict__ in, const sf_ctx& cx,
+                                              const int p, sf_vec (&dst)[SF_RJ], const bool enabled = true) {
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) SF_LOAD_ROW_IF(enabled, dst[r], p, r);
+}
+
 // Stage 1 is done with row r of the input window's "prev" slot: the row takes its next plane.
 template <int PH>
 __device__ __forceinline__ void sf_refill_row(sf_state& st, const sf_ctx& cx, const int p, const int r,
@@ -436,42 +464,121 @@ __device__ __forceinline__ void sf_refill_row(sf_state& st, const sf_ctx& cx, co
 #endif
 }
 
-// One stage of the fused group at one step: reads the source window of stage
-// S-1 at phase PH and writes plane q = p - S of stage S (into its own window, or
-// to HBM for the last stage).
-template <int S, int PH>
-__device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, const sf_scalars& sc,
-                                              sf_t* __restrict__ out, const sf_ctx& cx, const int p,
-                                              const bool load_next = false) {
-  constexpr int src = S - 1;
-  constexpr int iprev = PH % SF_SLOTS, icur = (PH + 1) % SF_SLOTS, inext = (PH + 2) % SF_SLOTS;
-  const int tx = cx.tx, ty = cx.ty;
-  // first / last row of the neighbouring thread rows (LDS)
-  sf_vec jm0 = st.w[src][icur][0], jpl = st.w[src][icur][SF_RJ - 1];
-  if constexpr (!SF_NOJ && SF_EXPERIMENT != 4) {
-    // No test of the thread row: the first / last thread row of the tile reads an image that
-    // exists (its own) -- rows 0 and SF_RJ-1 there are halo rows, whatever they take as their
-    // outer neighbour never reaches a stored value.  A divergent `if` here was the construct on
-    // which the toolchain fault of DESIGN.md 5.1 showed.
-    jm0 = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(src, ty > 0 ? ty - 1 : 0, 1) + tx * SF_VK]);
-    jpl = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(src, ty < SF_BY - 1 ? ty + 1 : ty, 0) + tx * SF_VK]);
-  }
-  // plane this stage produces (local owned coords).  SF_REVERSE: every stage
-  // reads only planes finished in earlier steps, so stage S lags 2S-1 steps.
-  const int q = SF_REVERSE ? p - (2 * S - 1) : p - S;
-  const bool plane_in = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G);
-  const bool store_plane = (S == SF_T) && q >= cx.cb && q < cx.ce && plane_in;
-  sf_t pad = (sf_t)0;
-  if constexpr (S < SF_T) pad = sf_stage<(S < SF_T ? S + 1 : S)>::bc();
-  sf_vec jm = jm0;
+// What a stage reads of ONE source window at one step: the rows of the neighbouring thread rows (LDS), the
+// edge columns of the neighbouring waves (LDS), and -- row by row -- the point's six neighbours.
+template <int W, int PH>
+struct sf_rowsrc {
+  static constexpr int iprev = PH % SF_SLOTS, icur = (PH + 1) % SF_SLOTS, inext = (PH + 2) % SF_SLOTS;
+  sf_vec jm, jpl;  // the row above the one being evaluated; the first row of the thread row below
 #if SF_DPP == 4 && SF_WPR > 1
   sf_t e_lo[SF_RJ], e_hi[SF_RJ];
-#pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) {
-    e_lo[r] = lds[sf_edge_at(src, ty, r, cx.wave - 1, 1)];
-    e_hi[r] = lds[sf_edge_at(src, ty, r, cx.wave + 1, 0)];
-  }
 #endif
+  sf_vec c, im, ip, jp;  // of the current row
+  sf_t km_e, kp_e;       // k-1 of the vector's first element, k+1 of its last
+
+  __device__ __forceinline__ void begin(const sf_state& st, const sf_t* lds, const sf_ctx& cx) {
+    const int tx = cx.tx, ty = cx.ty;
+    // first / last row of the neighbouring thread rows (LDS)
+    jm = st.w[W][icur][0];
+    jpl = st.w[W][icur][SF_RJ - 1];
+    if constexpr (!SF_NOJ && SF_EXPERIMENT != 4) {
+      // No test of the thread row: the first / last thread row of the tile reads an image that
+      // exists (its own) -- rows 0 and SF_RJ-1 there are halo rows, whatever they take as their
+      // outer neighbour never reaches a stored value.  A divergent `if` here was the construct on
+      // which the toolchain fault of DESIGN.md 5.1 showed.
+      jm = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(W, ty > 0 ? ty - 1 : 0, 1) + tx * SF_VK]);
+      jpl = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(W, ty < SF_BY - 1 ? ty + 1 : ty, 0) + tx * SF_VK]);
+    }
+#if SF_DPP == 4 && SF_WPR > 1
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r) {
+      e_lo[r] = lds[sf_edge_at(W, ty, r, cx.wave - 1, 1)];
+      e_hi[r] = lds[sf_edge_at(W, ty, r, cx.wave + 1, 0)];
+    }
+#endif
+  }
+
+  // row r becomes the current row (the row above it is `jm`, left there by `next`)
+  __device__ __forceinline__ void row(const sf_state& st, const sf_t* lds, const sf_ctx& cx, const int r) {
+    (void)lds;
+    (void)cx;
+    c = st.w[W][icur][r];
+    im = st.w[W][iprev][r];
+    ip = st.w[W][inext][r];
+    jp = (r < SF_RJ - 1) ? st.w[W][icur][r < SF_RJ - 1 ? r + 1 : r] : jpl;
+    // innermost-dimension halo: adjacent lanes hold the adjacent vectors
+    // SF_EXPERIMENT 3: timing-only build without the lane exchange (invalid results)
+#if SF_DPP == 4 && SF_WPR > 1
+    // Lanes 0 / 63 take the neighbouring wave's edge column -- or, from the
+    // virtual waves beside the row, the boundary constant -- as the DPP move's
+    // starting destination: no test, no select (the words were read before the
+    // first row, see e_lo / e_hi).
+    km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], e_lo[r]);
+    kp_e = sf_neighbour_lane_or<false>(c[0], e_hi[r]);
+#elif SF_DPP >= 3
+    // Lanes 0 / 63 have no source lane.  Their value is the neighbouring wave's
+    // edge column (LDS, every lane reads the same word) or the boundary constant the
+    // window's readers declare; it is handed to the DPP move as the starting destination, so no
+    // select follows -- and a boundary constant of +0 is what bound_ctrl writes.
+    const int ty = cx.ty;
+    if (SF_WPR > 1 && cx.wave > 0)
+      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], lds[sf_edge_at(W, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]);
+    else if (sf_win<W>::bc_zero)
+      km_e = sf_neighbour_lane<true>(c[SF_VK - 1]);
+    else
+      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], sf_win<W>::bc());
+    if (SF_WPR > 1 && cx.wave < SF_WPR - 1)
+      kp_e = sf_neighbour_lane_or<false>(c[0], lds[sf_edge_at(W, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]);
+    else if (sf_win<W>::bc_zero)
+      kp_e = sf_neighbour_lane<false>(c[0]);
+    else
+      kp_e = sf_neighbour_lane_or<false>(c[0], sf_win<W>::bc());
+#else
+    const int ty = cx.ty;
+    km_e = (SF_EXPERIMENT == 3) ? c[SF_VK - 1] : sf_neighbour_lane<true>(c[SF_VK - 1]);
+    kp_e = (SF_EXPERIMENT == 3) ? c[0] : sf_neighbour_lane<false>(c[0]);
+    if (SF_EXPERIMENT != 3 && cx.lane == 0)
+      km_e = (SF_WPR > 1 && cx.wave > 0)
+                 ? lds[sf_edge_at(W, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]
+                 : sf_win<W>::bc();
+    if (SF_EXPERIMENT != 3 && cx.lane == 63)
+      kp_e = (SF_WPR > 1 && cx.wave < SF_WPR - 1)
+                 ? lds[sf_edge_at(W, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]
+                 : sf_win<W>::bc();
+#endif
+  }
+  __device__ __forceinline__ sf_t km(const int v) const { return (v > 0) ? c[v > 0 ? v - 1 : 0] : km_e; }
+  __device__ __forceinline__ sf_t kp(const int v) const { return (v < SF_VK - 1) ? c[v < SF_VK - 1 ? v + 1 : v] : kp_e; }
+  // a row that is not evaluated still is the next row's j-neighbour
+  __device__ __forceinline__ void skip(const sf_state& st, const int r) { jm = st.w[W][icur][r]; }
+  __device__ __forceinline__ void next() { jm = c; }
+};
+
+// One stage of the fused group at one step.  A group is a DAG of SF_NS stages over SF_NW register windows
+// (window 0: the input field; window sf_stage<S>::dst: what stage S hands to later stages of the group):
+// stage S reads window sf_stage<S>::src (and, a join, sf_stage<S>::src2) at phase PH and produces plane
+// q = p - depth of its field -- into its window, to HBM (output sf_stage<S>::out), or both (an intermediate
+// the group hands on AND materialises).  A chain is the special case src = S - 1, dst = S, depth = S.
+template <int S, int PH>
+__device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, const sf_scalars& sc,
+                                              const sf_outptrs& outs, const sf_ctx& cx, const int p,
+                                              const bool load_next = false) {
+  using stage = sf_stage<S>;
+  constexpr int src = stage::src, src2 = stage::src2, dst = stage::dst, depth = stage::depth;
+  constexpr bool joins = src2 >= 0;
+  constexpr int iprev = PH % SF_SLOTS, icur = (PH + 1) % SF_SLOTS, inext = (PH + 2) % SF_SLOTS;
+  (void)icur;
+  sf_rowsrc<src, PH> A;
+  A.begin(st, lds, cx);
+  sf_rowsrc<(joins ? src2 : src), PH> B;
+  if constexpr (joins) B.begin(st, lds, cx);
+  // plane this stage produces (local owned coords).  SF_REVERSE: every stage
+  // reads only planes finished in earlier steps, so a stage of depth d lags 2d-1 steps.
+  const int q = SF_REVERSE ? p - (2 * depth - 1) : p - depth;
+  const bool plane_in = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G);
+  const bool store_plane = (stage::out >= 0) && q >= cx.cb && q < cx.ce && plane_in;
+  sf_t pad = (sf_t)0;
+  if constexpr (dst >= 0) pad = sf_win<(dst >= 0 ? dst : 0)>::bc();
 #if SF_AUX_AHEAD
   // all auxiliary rows of this stage are requested before its first row is
   // evaluated (they come straight from HBM: issued late they stall every row)
@@ -504,58 +611,18 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
 #endif
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
-    const sf_vec c = st.w[src][icur][r];
 #if SF_SKIP_ROWS
     // a halo row no later stage reads (wave-uniform test: a scalar branch); the row above still is this
     // row's j-neighbour, and the input window still moves on
     if (!((cx.need_rows[S - 1] >> r) & 1u)) {
-      jm = c;
-      if constexpr (S == 1) sf_refill_row<PH>(st, cx, p, r, load_next);
+      A.skip(st, r);
+      if constexpr (joins) B.skip(st, r);
+      if constexpr (stage::refill) sf_refill_row<PH>(st, cx, p, r, load_next);
       continue;
     }
 #endif
-    const sf_vec im = st.w[src][iprev][r];
-    const sf_vec ip = st.w[src][inext][r];
-    const sf_vec jp = (r < SF_RJ - 1) ? st.w[src][icur][r < SF_RJ - 1 ? r + 1 : r] : jpl;
-    // innermost-dimension halo: adjacent lanes hold the adjacent vectors
-    // SF_EXPERIMENT 3: timing-only build without the lane exchange (invalid results)
-#if SF_DPP == 4 && SF_WPR > 1
-    // Lanes 0 / 63 take the neighbouring wave's edge column -- or, from the
-    // virtual waves beside the row, the boundary constant -- as the DPP move's
-    // starting destination: no test, no select (the words were read before the
-    // first row, see e_lo / e_hi).
-    const sf_t km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], e_lo[r]);
-    const sf_t kp_e = sf_neighbour_lane_or<false>(c[0], e_hi[r]);
-#elif SF_DPP >= 3
-    // Lanes 0 / 63 have no source lane.  Their value is the neighbouring wave's
-    // edge column (LDS, every lane reads the same word) or this stage's boundary
-    // constant; it is handed to the DPP move as the starting destination, so no
-    // select follows -- and a boundary constant of +0 is what bound_ctrl writes.
-    sf_t km_e, kp_e;
-    if (SF_WPR > 1 && cx.wave > 0)
-      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], lds[sf_edge_at(src, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]);
-    else if (sf_stage<S>::bc_zero)
-      km_e = sf_neighbour_lane<true>(c[SF_VK - 1]);
-    else
-      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], sf_stage<S>::bc());
-    if (SF_WPR > 1 && cx.wave < SF_WPR - 1)
-      kp_e = sf_neighbour_lane_or<false>(c[0], lds[sf_edge_at(src, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]);
-    else if (sf_stage<S>::bc_zero)
-      kp_e = sf_neighbour_lane<false>(c[0]);
-    else
-      kp_e = sf_neighbour_lane_or<false>(c[0], sf_stage<S>::bc());
-#else
-    sf_t km_e = (SF_EXPERIMENT == 3) ? c[SF_VK - 1] : sf_neighbour_lane<true>(c[SF_VK - 1]);
-    sf_t kp_e = (SF_EXPERIMENT == 3) ? c[0] : sf_neighbour_lane<false>(c[0]);
-    if (SF_EXPERIMENT != 3 && cx.lane == 0)
-      km_e = (SF_WPR > 1 && cx.wave > 0)
-                 ? lds[sf_edge_at(src, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]
-                 : sf_stage<S>::bc();
-    if (SF_EXPERIMENT != 3 && cx.lane == 63)
-      kp_e = (SF_WPR > 1 && cx.wave < SF_WPR - 1)
-                 ? lds[sf_edge_at(src, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]
-                 : sf_stage<S>::bc();
-#endif
+    A.row(st, lds, cx, r);
+    if constexpr (joins) B.row(st, lds, cx, r);
     // centre-only auxiliary fields of this stage, row r of plane q
 #if SF_AUX_AHEAD
     const auto ax = axs[r];
@@ -574,18 +641,22 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
     sf_vec o;
 #pragma unroll
     for (int v = 0; v < SF_VK; ++v) {
-      const sf_t km = (v > 0) ? c[v > 0 ? v - 1 : 0] : km_e;
-      const sf_t kp = (v < SF_VK - 1) ? c[v < SF_VK - 1 ? v + 1 : v] : kp_e;
       unsigned edge = 0;
       if constexpr (sf_stage<S>::bc_copy)
         edge = edge_row | (cx.k0 + v <= 0 ? 16u : 0u) | (cx.k0 + v >= SF_N2 - 1 ? 32u : 0u);
-      o[v] = sf_stage<S>::apply(c[v], im[v], ip[v], jm[v], jp[v], km, kp, sc, ax, v, edge);
+      if constexpr (joins)
+        o[v] = stage::apply2(A.c[v], A.im[v], A.ip[v], A.jm[v], A.jp[v], A.km(v), A.kp(v), B.c[v], B.im[v], B.ip[v],
+                             B.jm[v], B.jp[v], B.km(v), B.kp(v), sc, ax, v, edge);
+      else
+        o[v] = stage::apply(A.c[v], A.im[v], A.ip[v], A.jm[v], A.jp[v], A.km(v), A.kp(v), sc, ax, v, edge);
     }
-    jm = c;
-    if constexpr (S == 1) sf_refill_row<PH>(st, cx, p, r, load_next);
-    if constexpr (S == SF_T) {
-      // last stage of the group: write interior, in-domain points
+    A.next();
+    if constexpr (joins) B.next();
+    if constexpr (stage::refill) sf_refill_row<PH>(st, cx, p, r, load_next);
+    if constexpr (stage::out >= 0) {
+      // a materialised field: write interior, in-domain points
       // SF_EXPERIMENT 1: timing-only build without the output stores (invalid results)
+      sf_t* __restrict__ out = outs.p[stage::out >= 0 ? stage::out : 0];
       if (SF_EXPERIMENT == 1) asm volatile("" ::"v"(o));
 #if SF_BIO_STORES
       {
@@ -608,17 +679,18 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
         *reinterpret_cast<sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)) = o;
 #endif
       }
-    } else {
-      // pad: outside the global domain the next stage must read ITS constant
+    }
+    if constexpr (dst >= 0) {
+      // pad: outside the global domain the readers of this window must read THEIR constant
       // (skipped by a block-uniform branch for tiles and planes strictly inside)
       if (!(cx.tile_inside && plane_in)) {
         const bool row_in = plane_in && ((cx.jmask >> r) & 1u);
 #pragma unroll
         for (int v = 0; v < SF_VK; ++v) o[v] = (row_in && ((cx.kmask >> v) & 1u)) ? o[v] : pad;
       }
-      // becomes plane "next" of stage S.  SF_REVERSE: stage S+1 ran earlier in
+      // becomes plane "next" of the window.  SF_REVERSE: its reader ran earlier in
       // this step and is done with the slot that held its plane "prev".
-      st.w[S < SF_T ? S : 0][SF_REVERSE ? iprev : inext][r] = o;
+      st.w[dst >= 0 ? dst : 0][SF_REVERSE ? iprev : inext][r] = o;
     }
 #if SF_ROW_FENCE
     __builtin_amdgcn_sched_barrier(0);  // rows in order: bounds the live f64 temporaries
@@ -626,66 +698,6 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
   }
 }
 
-template <int S, int PH>
-__device__ __forceinline__ void sf_later_stages(sf_state& st, const sf_t* lds, const sf_scalars& sc,
-                                                sf_t* __restrict__ out, const sf_ctx& cx,
-                                                const int p) {
-  if constexpr (S <= SF_T) {
-    sf_stage_step<S, PH>(st, lds, sc, out, cx, p);
-    sf_later_stages<S + 1, PH>(st, lds, sc, out, cx, p);
-  }
-}
-
-// stages S, S-1, ..., 2 (SF_REVERSE order: the storing stage first)
-template <int S, int PH>
-__device__ __forceinline__ void sf_later_stages_desc(sf_state& st, const sf_t* lds,
-                                                     const sf_scalars& sc, sf_t* __restrict__ out,
-                                                     const sf_ctx& cx, const int p) {
-  if constexpr (S >= 2) {
-    sf_stage_step<S, PH>(st, lds, sc, out, cx, p);
-    sf_later_stages_desc<S - 1, PH>(st, lds, sc, out, cx, p);
-  }
-}
-
-#if SF_DPP == 4 && SF_WPR > 1
-template <int S>
-__device__ __forceinline__ void sf_edge_prefill(sf_t* lds_all, const sf_ctx& cx) {
-  if constexpr (S <= SF_T) {
-    if (cx.lane == 0 && (cx.wave == 0 || cx.wave == SF_WPR - 1)) {
-#pragma unroll
-      for (int image = 0; image < (SF_LDS_DB ? 2 : 1); ++image)
-#pragma unroll
-        for (int r = 0; r < SF_RJ; ++r) {
-          sf_t* lds = lds_all + image * SF_IMAGE_ELEMS;
-          if (cx.wave == 0) lds[sf_edge_at(S - 1, cx.ty, r, -1, 1)] = sf_stage<S>::bc();
-          if (cx.wave == SF_WPR - 1) lds[sf_edge_at(S - 1, cx.ty, r, SF_WPR, 0)] = sf_stage<S>::bc();
-        }
-    }
-    sf_edge_prefill<S + 1>(lds_all, cx);
-  }
-}
-#endif
-
-#if SF_AUX_AHEAD == 2
-// Fill every stage's auxiliary slot with the rows its first step uses.
-template <int S>
-__device__ __forceinline__ void sf_aux_preload(sf_state& st, const sf_ctx& cx, const int p_first) {
-  if constexpr (S <= SF_T) {
-    const int q = SF_REVERSE ? p_first - (2 * S - 1) : p_first - S;
-#pragma unroll
-    for (int r = 0; r < SF_RJ; ++r) static_cast<sf_auxslots<S>&>(st).a[r] = sf_aux_row<S>(cx, q, r);
-    sf_aux_preload<S + 1>(st, cx, p_first);
-  }
-}
-#endif
-
-__device__ __forceinline__ void sf_load_plane(const sf_t* __restrict__ in, const sf_ctx& cx,
-                                              const int p, sf_vec (&dst)[SF_RJ], const bool enabled = true) {
-#pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) SF_LOAD_ROW_IF(enabled, dst[r], p, r);
-}
-
-// One step (input plane p) at phase PH.
 #if SF_STAMP
 // Diagnostic build only (option stamp=1): where a step spends its cycles.
 // acc[0] publish + barrier, [1] stage 1 (incl. wait for the input plane),
@@ -707,9 +719,77 @@ __device__ __forceinline__ void sf_load_plane(const sf_t* __restrict__ in, const
 #define SF_STAMP_PASS
 #endif
 
+// stages S, S + 1, ..., SF_NS in order (every stage after the ones it reads); the stage that is the last reader of
+// the input window also moves that window on (codegen: sf_stage<S>::refill -- stage 1 of a chain)
+template <int S, int PH>
+__device__ __forceinline__ void sf_stages_from(sf_state& st, const sf_t* lds, const sf_t* __restrict__ in,
+                                               const sf_scalars& sc, const sf_outptrs& outs, const sf_ctx& cx,
+                                               const int p, const int p_end, const bool load_next SF_STAMP_ARGS) {
+  if constexpr (S <= SF_NS) {
+    sf_stage_step<S, PH>(st, lds, sc, outs, cx, p, sf_stage<S>::refill && load_next);
+    if constexpr (sf_stage<S>::refill) {
+      SF_STAMP_AT(1);
+      if constexpr (!SF_RING4 && !SF_PREFETCH2 && !SF_SPREAD_LOADS) {
+        // (no ring, no staging registers, loads not spread over the rows: the freed slot takes the next plane now)
+        sf_load_plane(in, cx, p + 1, st.w[0][PH % 3], p + 1 < p_end);
+      }
+      SF_STAMP_AT(2);
+    }
+    (void)in;
+    (void)p_end;
+    sf_stages_from<S + 1, PH>(st, lds, in, sc, outs, cx, p, p_end, load_next SF_STAMP_PASS);
+  }
+}
+
+// stages S, S-1, ..., 2 (SF_REVERSE order, chains only: the storing stage first)
+template <int S, int PH>
+__device__ __forceinline__ void sf_later_stages_desc(sf_state& st, const sf_t* lds,
+                                                     const sf_scalars& sc, const sf_outptrs& outs,
+                                                     const sf_ctx& cx, const int p) {
+  if constexpr (S >= 2) {
+    sf_stage_step<S, PH>(st, lds, sc, outs, cx, p);
+    sf_later_stages_desc<S - 1, PH>(st, lds, sc, outs, cx, p);
+  }
+}
+
+#if SF_DPP == 4 && SF_WPR > 1
+template <int W>
+__device__ __forceinline__ void sf_edge_prefill(sf_t* lds_all, const sf_ctx& cx) {
+  if constexpr (W < SF_NW) {
+    if (cx.lane == 0 && (cx.wave == 0 || cx.wave == SF_WPR - 1)) {
+#pragma unroll
+      for (int image = 0; image < (SF_LDS_DB ? 2 : 1); ++image)
+#pragma unroll
+        for (int r = 0; r < SF_RJ; ++r) {
+          sf_t* lds = lds_all + image * SF_IMAGE_ELEMS;
+          if (cx.wave == 0) lds[sf_edge_at(W, cx.ty, r, -1, 1)] = sf_win<W>::bc();
+          if (cx.wave == SF_WPR - 1) lds[sf_edge_at(W, cx.ty, r, SF_WPR, 0)] = sf_win<W>::bc();
+        }
+    }
+    sf_edge_prefill<W + 1>(lds_all, cx);
+  }
+}
+#endif
+
+#if SF_AUX_AHEAD == 2
+// Fill every stage's auxiliary slot with the rows its first step uses.
+template <int S>
+__device__ __forceinline__ void sf_aux_preload(sf_state& st, const sf_ctx& cx, const int p_first) {
+  if constexpr (S <= SF_NS) {
+    const int q = SF_REVERSE ? p_first - (2 * sf_stage<S>::depth - 1) : p_first - sf_stage<S>::depth;
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r) static_cast<sf_auxslots<S>&>(st).a[r] = sf_aux_row<S>(cx, q, r);
+    sf_aux_preload<S + 1>(st, cx, p_first);
+  }
+}
+#endif
+
+
+// One step (input plane p) at phase PH.
+
 template <int PH>
 __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __restrict__ in,
-                                        sf_t* __restrict__ out, const sf_scalars& sc,
+                                        const sf_outptrs& outs, const sf_scalars& sc,
                                         const sf_ctx& cx, const int p, const int p_end SF_STAMP_ARGS) {
   constexpr int icur = (PH + 1) % SF_SLOTS;
 #if SF_REVERSE == 2
@@ -724,7 +804,7 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
   // next (fewer v_cvt, but ~80 more VGPRs and spills).
 #if SF_OPAQUE
 #pragma unroll
-  for (int s = 0; s < SF_T; ++s)
+  for (int s = 0; s < SF_NW; ++s)
 #pragma unroll
     for (int w = 0; w < SF_SLOTS; ++w)
 #pragma unroll
@@ -738,9 +818,9 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
         else asm volatile("" : "+v"(st.w[s][w][r]));
       }
 #endif
-  // publish the rows / columns other threads need of every stage's current plane
+  // publish the rows / columns other threads need of every window's current plane
 #pragma unroll
-  for (int s = 0; s < SF_T; ++s) {
+  for (int s = 0; s < SF_NW; ++s) {
     if constexpr (!SF_NOJ && SF_EXPERIMENT != 4) {
       *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(s, cx.ty, 0) + cx.tx * SF_VK]) = st.w[s][icur][0];
       *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(s, cx.ty, 1) + cx.tx * SF_VK]) =
@@ -766,16 +846,16 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
   // input loads at its very end, so the one `s_waitcnt vmcnt(0)` per step (the
   // compiler cannot count loads and stores apart) waits for loads a whole step
   // old and for stores most of a step old -- not for stores just issued.
-  sf_later_stages_desc<SF_T, PH>(st, lds, sc, out, cx, p);
+  sf_later_stages_desc<SF_T, PH>(st, lds, sc, outs, cx, p);
   SF_STAMP_AT(3);
 #if SF_REVERSE == 2
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) SF_LOAD_ROW_IF(p + SF_PFD < p_end, st.pf[PH % SF_PFD][r], p + SF_PFD, r);
   SF_STAMP_AT(2);
-  sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
+  sf_stage_step<1, PH>(st, lds, sc, outs, cx, p);
   SF_STAMP_AT(1);
 #else
-  sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
+  sf_stage_step<1, PH>(st, lds, sc, outs, cx, p);
   SF_STAMP_AT(1);
   sf_load_plane(in, cx, p + 1, st.w[0][PH % 3], p + 1 < p_end);
   SF_STAMP_AT(2);
@@ -783,37 +863,58 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
   if (SF_USE_LDS && !SF_LDS_DB) __syncthreads();
   return;
 #endif
-  // stage 1 consumes input plane p (slot "next" of the input window) and frees
-  // slot "prev", which receives input plane p+1
+  // the stages in order.  The last reader of the input window (stage 1 of a chain) consumes input plane p (slot
+  // "next") and frees slot "prev", which receives the next plane the ring / staging / plain scheme asks for
 #if SF_RING4
-  sf_stage_step<1, PH>(st, lds, sc, out, cx, p, p + 1 + SF_INFLIGHT < p_end);
-  SF_STAMP_AT(1);
+  const bool load_next = p + 1 + SF_INFLIGHT < p_end;
 #elif SF_PREFETCH2
-  sf_stage_step<1, PH>(st, lds, sc, out, cx, p, p + 1 + SF_PFD < p_end);
-  SF_STAMP_AT(1);
-#elif SF_SPREAD_LOADS
-  sf_stage_step<1, PH>(st, lds, sc, out, cx, p, p + 1 < p_end);
-  SF_STAMP_AT(1);
+  const bool load_next = p + 1 + SF_PFD < p_end;
 #else
-  sf_stage_step<1, PH>(st, lds, sc, out, cx, p);
-  SF_STAMP_AT(1);
-  sf_load_plane(in, cx, p + 1, st.w[0][PH % 3], p + 1 < p_end);
+  const bool load_next = p + 1 < p_end;
 #endif
-  SF_STAMP_AT(2);
-  sf_later_stages<2, PH>(st, lds, sc, out, cx, p);
+  sf_stages_from<1, PH>(st, lds, in, sc, outs, cx, p, p_end, load_next SF_STAMP_PASS);
   if (SF_USE_LDS && !SF_LDS_DB) __syncthreads();
   SF_STAMP_AT(3);
 }
+
+#if SF_SKIP_ROWS
+// rows of the tile stage S evaluates: what later stages can still read of its output, [depth, SF_TJH - depth)
+template <int S>
+__device__ __forceinline__ void sf_need_rows(sf_ctx& cx, const int tid_y) {
+  if constexpr (S <= SF_NS) {
+    constexpr int d = sf_stage<S>::depth;
+    unsigned need = 0;
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r) {
+      const int tr = tid_y * SF_RJ + r;
+      need |= ((SF_NOJ || (tr >= d && tr < SF_TJH - d)) ? 1u : 0u) << r;
+    }
+    cx.need_rows[S - 1] = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
+    sf_need_rows<S + 1>(cx, tid_y);
+  }
+}
+#endif
 
 extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc,
                    sf_auxptrs aux, int halo,
                    int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2
+#if SF_NOUT > 1
+                   ,
+                   sf_more_outs more
+#endif
 #if SF_STAMP
                    ,
                    unsigned long long* dbg
 #endif
     ) {
+  static_assert(!(SF_DAG && SF_REVERSE), "DAG groups run the stages in order");
+  sf_outptrs outs;
+  outs.p[0] = out;
+#if SF_NOUT > 1
+#pragma unroll
+  for (int i = 1; i < SF_NOUT; ++i) outs.p[i] = static_cast<sf_t*>(more.p[i - 1]);
+#endif
   // SF_LDS_DB: two exchange images used alternately -> one barrier per step
   __shared__ sf_t lds_all[(SF_LDS_DB ? 2 : 1) * SF_IMAGE_ELEMS];
 #if SF_AUX_PASS
@@ -833,24 +934,11 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 #if SF_AUX_PASS
   cx.aux_lds = lds_aux;
 #endif
-#if SF_WMAP
-  // Which (thread row, wave of the row) a hardware wave plays.  With SF_SKIP_ROWS the first and last thread rows
-  // have less to evaluate; the waves that share a SIMD should have one of them each.  Hardware waves 2m and 2m + 1
-  // are taken to share a SIMD (measured, not documented: with the plain order skipping rows gained nothing), so
-  // wave 2m plays the m-th wave of the outer thread rows and wave 2m + 1 the m-th wave of the inner ones.
-  static_assert(SF_BY == 4, "SF_WMAP: four thread rows (two outer, two inner)");
-  const int hw_wave = __builtin_amdgcn_readfirstlane((((int)threadIdx.y * SF_BX + (int)threadIdx.x) >> 6));
-  const int wm = hw_wave >> 1;  // m-th outer / inner wave, 0 <= m < 2 * SF_WPR
-  const int lty = (hw_wave & 1) == 0 ? (wm < SF_WPR ? 0 : SF_BY - 1) : 1 + wm / SF_WPR;
-  const int lwave = wm % SF_WPR;
-  const int sf_tid_x = lwave * 64 + ((int)threadIdx.x & 63), sf_tid_y = lty;
-#else
   const int sf_tid_x = (int)threadIdx.x, sf_tid_y = (int)threadIdx.y;
-#endif
   cx.tx = sf_tid_x;
   // thread row and wave-within-row are the same for all lanes of a wave (SF_BX is
   // a multiple of 64): telling the compiler so makes every test on them a scalar branch
-#if SF_UNIFORM || SF_WMAP
+#if SF_UNIFORM
   cx.ty = __builtin_amdgcn_readfirstlane(sf_tid_y);
   cx.wave = __builtin_amdgcn_readfirstlane(cx.tx >> 6);
 #else
@@ -927,16 +1015,7 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   }
 #endif
 #if SF_SKIP_ROWS
-#pragma unroll
-  for (int s = 0; s < SF_T; ++s) {
-    unsigned need = 0;
-#pragma unroll
-    for (int r = 0; r < SF_RJ; ++r) {
-      const int tr = sf_tid_y * SF_RJ + r;
-      need |= ((SF_NOJ || (tr >= s + 1 && tr < SF_TJH - (s + 1))) ? 1u : 0u) << r;
-    }
-    cx.need_rows[s] = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
-  }
+  sf_need_rows<1>(cx, sf_tid_y);
 #endif
 #if SF_BUFFER_IO
 #pragma unroll
@@ -949,7 +1028,7 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 
   sf_state st;
 #pragma unroll
-  for (int s = 0; s < SF_T; ++s)
+  for (int s = 0; s < SF_NW; ++s)
 #pragma unroll
     for (int w = 0; w < SF_SLOTS; ++w)
 #pragma unroll
@@ -987,7 +1066,7 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 #if SF_DPP == 4 && SF_WPR > 1
   // the virtual waves' edge words: window s is read by stage s + 1, whose boundary
   // constant they hold (never overwritten; the first step's barrier orders them)
-  sf_edge_prefill<1>(lds_all, cx);
+  sf_edge_prefill<0>(lds_all, cx);
 #endif
   // Two exchange images alternate every step (run-time offset); the window
   // phase cycles with period 3 (compile-time slot indices).
@@ -1001,18 +1080,18 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   // keeps the loop body free of control flow between the phases
   // (SF_RING4: four steps, up to three surplus ones)
   for (int p = p_begin; p < p_last; p += SF_SLOTS) {
-    sf_step<0>(st, lds_all + image, in, out, sc, cx, p, p_end SF_STAMP_PASS);
+    sf_step<0>(st, lds_all + image, in, outs, sc, cx, p, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
-    sf_step<1>(st, lds_all + image, in, out, sc, cx, p + 1, p_end SF_STAMP_PASS);
+    sf_step<1>(st, lds_all + image, in, outs, sc, cx, p + 1, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
-    sf_step<2>(st, lds_all + image, in, out, sc, cx, p + 2, p_end SF_STAMP_PASS);
+    sf_step<2>(st, lds_all + image, in, outs, sc, cx, p + 2, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
 #if SF_RING4
-    sf_step<3>(st, lds_all + image, in, out, sc, cx, p + 3, p_end SF_STAMP_PASS);
+    sf_step<3>(st, lds_all + image, in, outs, sc, cx, p + 3, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
 #endif
 #if SF_INFLIGHT == 2
-    sf_step<4>(st, lds_all + image, in, out, sc, cx, p + 4, p_end SF_STAMP_PASS);
+    sf_step<4>(st, lds_all + image, in, outs, sc, cx, p + 4, p_end SF_STAMP_PASS);
     if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
 #endif
   }

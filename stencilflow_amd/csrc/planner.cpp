@@ -30,8 +30,9 @@ size_t star_lds_bytes(const StarCfg& c, DT dt) {
     const size_t win = (size_t)c.BY * 2 * c.BX * c.VK + (size_t)(c.BY + 2) * c.RJ * (c.BX / 64 + 2) * 2;
     return std::max<size_t>(1, (size_t)c.lds_images * win) * size_of(dt);
   }
-  const size_t rows = c.noj ? 0 : (size_t)c.T * c.BY * 2 * c.BX * c.VK;
-  const size_t edge = (size_t)c.T * c.BY * c.RJ * (c.BX / 64 + ((c.dpp == 4 && c.BX > 64) ? 2 : 0)) * 2;
+  const size_t windows = c.dag.on ? (size_t)c.dag.nwin : (size_t)c.T;  // (kernels/star3d.h: SF_NW)
+  const size_t rows = c.noj ? 0 : windows * c.BY * 2 * c.BX * c.VK;
+  const size_t edge = windows * c.BY * c.RJ * (c.BX / 64 + ((c.dpp == 4 && c.BX > 64) ? 2 : 0)) * 2;
   return (rows + edge) * size_of(dt) * (c.lds_db ? 2 : 1);
 }
 
@@ -56,7 +57,9 @@ static int star_regs_estimate(const StarCfg& c, DT dt) {
   if (c.compact)  // three live planes per window, one more in flight per loaded window; fitted to
                   // the code objects of round 2 (box, T = 2: P = 16 -> 180, P = 20 -> 212)
     return (3 * c.nwin + 1 + c.nwin - c.T) * P * words + 52 + P;
-  return 3 * c.T * P * words + 20 + (33 * P) / 10 +
+  // (a DAG group: one window per field held, and an evaluation's temporaries per stage beyond the chain's)
+  const int windows = c.dag.on ? c.dag.nwin : c.T;
+  return 3 * windows * P * words + 20 + (33 * P) / 10 +
          ((c.prefetch2 || c.reverse == 2) ? P * words * c.pfd : 0);
 }
 
@@ -184,7 +187,11 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   // steps to land, no copy; the step loop is unrolled by 4)
   // (defaults: the ring for 2-D and f32 3-D -- C2 +10 %, C3 +1.7 %, hotspot chains
   // +1 % with k1.bio; staging registers for f64, whose ring needs a smaller tile)
-  base.prefetch2 = base.reverse ? 0 : (int)pl.opt.get("k1.pf2", (base.noj || dt == DT::F32) ? 2 : 1);
+  // (round 4: f64 3-D loads straight into the freed slot -- the staging registers cost 20-30 registers, which made
+  // C5's five-row tile spill under ROCm 7.2's hipRTC and fall back to four rows (433 us), and without them the
+  // five-row tile is as fast or faster under every compiler: 409.5-415 against 417 us with PyTorch's hipRTC,
+  // 410 against 412 us with ROCm's comgr, profiles/r04_compilers_c5_c3.log)
+  base.prefetch2 = base.reverse ? 0 : (int)pl.opt.get("k1.pf2", (base.noj || dt == DT::F32) ? 2 : 0);
   // (3: a five-slot ring, two planes in flight beside the window -- 20 registers more at five rows per thread)
   if (base.prefetch2 < 0 || base.prefetch2 > 3) throw Error(SF_ERR_INVALID, "k1.pf2 must be 0, 1, 2 or 3");
   base.uniform_loads = (int)pl.opt.get("k1.ul", 0);
@@ -210,7 +217,6 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   base.uniform = (int)pl.opt.get("k1.uni", 0);
   // halo rows of the tile no later stage reads are not evaluated (star3d.h: SF_SKIP_ROWS)
   base.skip_rows = (int)pl.opt.get("k1.skip", 0);
-  base.wmap = (int)pl.opt.get("k1.wmap", 0);
   // logical tile order inside an XCD's share of the grid: 1 = k-tiles fastest, so that the share is a band of whole
   // tile rows and all its k-neighbours (which re-read each other's halo columns) meet in one L2.  C5 (16 x 5 tiles):
   // FETCH 1.2445 -> 1.1922 GB per launch, 0.7 % faster (profiles/r03_c5_tile_order.log); no k-tiles: same order
@@ -305,19 +311,20 @@ struct StarChoice {
 };
 
 static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& memo,
-                              const std::vector<int>& kernels, DT dt) {
+                              const std::vector<int>& kernels, DT dt, const StarDag* dag = nullptr) {
   const Program& P = pl.P;
   StarCfg probe;
-  probe.T = (int)kernels.size();
+  probe.T = dag ? dag->depth : (int)kernels.size();
+  if (dag) probe.dag = *dag;
   const std::string sig = std::to_string(fnv1a(gen_star(P, kernels, probe).source));
   auto it = memo.find(sig);
   if (it != memo.end()) return it->second;
   const std::string prefix = std::string("sf_star") + (P.n[1] == 1 ? "2d_" : "3d_") + short_of(dt) + "_t" +
-                             std::to_string(kernels.size());
+                             std::to_string(probe.T) + (dag ? "g" + std::to_string(kernels.size()) : std::string());
   StarChoice out;
   std::vector<StarCfg> ranked;
   try {
-    ranked = rank_star_cfgs(pl, (int)kernels.size(), dt);
+    ranked = rank_star_cfgs(pl, probe.T, dt, dag ? &probe : nullptr);
   } catch (const Error&) {
     memo[sig] = out;
     return out;
@@ -616,7 +623,11 @@ static void describe_step(std::ostringstream& desc, const sf_plan& pl, const Ste
     desc << "[point]";
   desc << " in";
   for (int b : st.in_bufs) desc << " b" << b;
-  desc << " out b" << st.out_buf << " {vgpr " << ck.vgprs << " agpr " << ck.agprs << " spill " << ck.spills
+  desc << " out";
+  for (int b : st.out_bufs) desc << " b" << b;
+  if (st.star && st.cfg.dag.on)
+    desc << " [dag: " << st.cfg.dag.stages.size() << " stages, " << st.cfg.dag.nwin << " windows]";
+  desc << " {vgpr " << ck.vgprs << " agpr " << ck.agprs << " spill " << ck.spills
        << " scratch " << ck.scratch << "}";
   // results produced under the diagnostic environment switches must not pass for normal runs
   if (ck.foreign) desc << " [foreign object: $SF_HIP_OBJECT_DIR]";
@@ -663,6 +674,167 @@ static void validate_options(const sf_plan& pl) {
     throw Error(SF_ERR_INVALID, "k1.vk must be 1, 2 or 4");
   if (pl.opt.kv.count("k1.pfd") && pl.opt.get("k1.pfd", 1) != 1 && pl.opt.get("k1.pfd", 1) != 3)
     throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
+}
+
+// ---- DAG groups (kernels/star3d.h: stages over register windows) ---------------------------------------------
+// What a kernel reads as a stage of a group whose input field is F and whose earlier stages produced `inside`:
+// up to two of those fields through radius-1 stars (`primary`, `second`), every other field at the point itself
+// from memory.  False if the kernel cannot be such a stage.
+struct DagShape {
+  std::string primary, second;
+  std::vector<std::string> aux;
+  std::map<std::string, std::string> bc;  // source field -> the boundary constant this kernel declares for it ("" none)
+};
+
+static bool dag_stage_shape(const Program& P, const Kernel& K, const std::string& F, const std::map<std::string, int>& inside,
+                            DagShape* out) {
+  if (K.acc.empty() || (K.dt != DT::F32 && K.dt != DT::F64)) return false;
+  DagShape sh;
+  std::vector<std::string> sources;
+  for (auto& a : K.acc) {
+    const Field& f = P.field(a.field);
+    const bool source = a.field == F || inside.count(a.field) != 0;
+    int nz = 0;
+    for (int d = 0; d < 3; ++d) {
+      if (a.off[d] != 0) ++nz;
+      if (a.off[d] < -1 || a.off[d] > 1) return false;
+    }
+    if (source) {
+      if (f.dt != K.dt || !f.full() || nz > 1) return false;
+      if (P.n[1] == 1 && a.off[1] != 0) return false;
+      if (nz == 1 && a.bckind != "copy") {
+        if (a.bckind != "constant" && a.bckind != "shrink") return false;
+        if (!literal_exact_in(a.bcval, K.dt)) return false;
+        auto it = sh.bc.find(a.field);
+        if (it != sh.bc.end() && it->second != a.bcval) return false;
+        sh.bc[a.field] = a.bcval;
+      }
+      if (std::find(sources.begin(), sources.end(), a.field) == sources.end()) sources.push_back(a.field);
+    } else {
+      if (nz != 0) return false;
+      if (f.dt != DT::F32 && f.dt != DT::F64) return false;
+      if (!f.full() && f.has[0] + f.has[1] + f.has[2] == 0) return false;
+      if (std::find(sh.aux.begin(), sh.aux.end(), a.field) == sh.aux.end()) sh.aux.push_back(a.field);
+    }
+  }
+  if (sources.empty() || sources.size() > 2) return false;
+  sh.primary = sources[0];
+  if (sources.size() == 2) sh.second = sources[1];
+  if (out) *out = sh;
+  return true;
+}
+
+// The largest DAG group that starts at kernel k0 and takes kernels k0, k0 + 1, ... in program order: every stage
+// reads fields of the level before its own (the window of a field holds three planes: a reader lags its source by
+// exactly one step), depth <= max_depth, windows <= max_windows, auxiliary fields <= kMaxStarAux.  Returns the kernels in
+// stage order (level by level) with the description codegen needs; `count` = how many program kernels were taken.
+struct DagGroup {
+  std::vector<int> kernels;  // stage order
+  StarDag dag;
+  std::vector<std::string> aux;
+  int count = 0;
+};
+
+static bool build_dag_group(const Program& P, int k0, int count, const std::map<std::string, std::vector<int>>& readers,
+                            DagGroup* out) {
+  const int K = (int)P.kernels.size();
+  if (k0 + count > K) return false;
+  StarShape first;
+  if (!star_eligible(P, P.kernels[k0], &first)) return false;
+  const std::string F = first.primary;
+  const DT dt = P.kernels[k0].dt;
+  std::map<std::string, int> inside;  // field -> index in `taken`
+  std::vector<int> taken;
+  std::vector<DagShape> shapes;
+  std::vector<int> depth;
+  std::map<std::string, std::string> window_bc;  // source field -> the constant its readers declare
+  std::set<std::string> aux;
+  for (int n = k0; n < k0 + count; ++n) {
+    const Kernel& Kn = P.kernels[n];
+    if (Kn.dt != dt) return false;
+    DagShape sh;
+    if (!dag_stage_shape(P, Kn, F, inside, &sh)) return false;
+    auto level_of = [&](const std::string& f) { return f == F ? 0 : depth[inside.at(f)]; };
+    const int d = level_of(sh.primary) + 1;
+    if (!sh.second.empty() && level_of(sh.second) + 1 != d) return false;  // (both sources one level below)
+    for (auto& kv : sh.bc) {
+      auto it = window_bc.find(kv.first);
+      if (it != window_bc.end() && it->second != kv.second) return false;  // readers of one window disagree
+      window_bc[kv.first] = kv.second;
+    }
+    for (auto& f : sh.aux) {
+      if (inside.count(f)) return false;
+      aux.insert(f);
+    }
+    if ((int)aux.size() > kMaxStarAux) return false;
+    inside[Kn.name] = (int)taken.size();
+    taken.push_back(n);
+    shapes.push_back(sh);
+    depth.push_back(d);
+  }
+  // stage order: level by level (the readers of the input window first), program order within a level
+  std::vector<int> order(taken.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depth[a] < depth[b]; });
+  DagGroup g;
+  g.count = count;
+  g.dag.on = true;
+  std::map<std::string, int> window_of;  // field -> register window
+  window_of[F] = 0;
+  int nwin = 1;
+  // a stage fills a window if a later stage of the group reads its field
+  std::set<std::string> read_inside;
+  for (auto& sh : shapes) {
+    if (sh.primary != F) read_inside.insert(sh.primary);
+    if (!sh.second.empty() && sh.second != F) read_inside.insert(sh.second);
+  }
+  for (int i : order)
+    if (read_inside.count(P.kernels[taken[i]].name)) window_of[P.kernels[taken[i]].name] = nwin++;
+  int last_input_reader = -1;
+  for (size_t pos = 0; pos < order.size(); ++pos) {
+    const int i = order[pos];
+    const Kernel& Kn = P.kernels[taken[i]];
+    StarDag::Stage st;
+    st.primary = shapes[i].primary;
+    st.second = shapes[i].second;
+    st.src = window_of.at(st.primary);
+    st.src2 = st.second.empty() ? -1 : window_of.at(st.second);
+    st.depth = depth[i];
+    auto w = window_of.find(Kn.name);
+    st.dst = w == window_of.end() ? -1 : w->second;
+    // materialised: a program output, or read by a kernel outside the group
+    bool outside = P.field(Kn.name).role == Role::Output;
+    auto rd = readers.find(Kn.name);
+    if (rd != readers.end())
+      for (int r : rd->second)
+        if (r < k0 || r >= k0 + count) outside = true;
+    if (outside) {
+      st.out = (int)g.dag.outputs.size();
+      g.dag.outputs.push_back(Kn.name);
+    }
+    if (st.dst < 0 && st.out < 0) return false;  // (a dead operator: left to the plain paths)
+    if (st.src == 0 || st.src2 == 0) last_input_reader = (int)pos;
+    g.dag.depth = std::max(g.dag.depth, st.depth);
+    g.dag.stages.push_back(st);
+    g.kernels.push_back(taken[i]);
+  }
+  if (last_input_reader < 0 || g.dag.outputs.empty() || g.dag.outputs.size() > 4) return false;
+  g.dag.stages[last_input_reader].refill = true;
+  g.dag.nwin = nwin;
+  g.dag.nout = (int)g.dag.outputs.size();
+  g.aux.assign(aux.begin(), aux.end());
+  if (out) *out = g;
+  return true;
+}
+
+// is the group a plain chain (what the star path plans without this machinery)?
+static bool dag_is_chain(const DagGroup& g) {
+  for (size_t s = 0; s < g.dag.stages.size(); ++s) {
+    const StarDag::Stage& st = g.dag.stages[s];
+    if (st.src != (int)s || st.src2 >= 0 || st.depth != (int)s + 1) return false;
+    if (s + 1 < g.dag.stages.size() ? (st.dst != (int)s + 1 || st.out >= 0) : (st.dst >= 0 || st.out != 0)) return false;
+  }
+  return true;
 }
 
 // Depth-first topological order of the operators: an operator is followed by a consumer that has become ready,
@@ -762,6 +934,68 @@ void build_plan(sf_plan& pl) {
   // (any row length: the vector width follows it, rank_star_cfgs)
   const bool star_ok_dims = (P.nd >= 2) && P.n[0] > 1;
 
+  // ---- DAG groups (round 4): forks, joins and intermediates with several readers inside one launch
+  // readers of every field, by kernel index
+  std::map<std::string, std::vector<int>> readers;
+  for (int k = 0; k < K; ++k) {
+    std::set<std::string> seen;
+    for (auto& a : P.kernels[k].acc)
+      if (seen.insert(a.field).second) readers[a.field].push_back(k);
+  }
+  // register windows a DAG group may hold (option dag.windows; a chain of depth T holds T).  Measured on the
+  // generator's fork / join programs (profiles/r04_dag_fork_perf.log): 2-D kernels have registers to spare (one
+  // row per thread) -- six windows hold a fork, both branches, the join and the operator after it: 1.40 ->
+  // 2.11e6 Mcells/s; 3-D f32 with a third window evaluates both branches of a fork from one read (12-row tiles:
+  // 1.19 -> 1.28e6); 3-D f64 with a fourth 5.4 -> 7.4e5.
+  const bool dag_on = pl.opt.get("dag", 1) != 0 && !generic_only && star_ok_dims && pl.opt.get("star", 1) != 0;
+  const int dag_windows = (int)pl.opt.get("dag.windows", P.n[1] == 1 ? 6 : fuse + 1);
+  // the chain the star path would form at k (its conditions, no compilation), or 1
+  auto star_chain_len = [&](int k) {
+    StarShape sh;
+    if (!star_eligible(P, P.kernels[k], &sh)) return 1;
+    int len = 1;
+    std::set<std::string> aux(sh.aux.begin(), sh.aux.end());
+    while (len < fuse && k + len < K) {
+      const Kernel& kc = P.kernels[k + len - 1];
+      StarShape ns;
+      if (!star_eligible(P, P.kernels[k + len], &ns) || ns.primary != kc.name) break;
+      if (P.field(kc.name).role != Role::Temp || consumers[kc.name] != 1 || P.kernels[k + len].dt != kc.dt) break;
+      bool ok = true;
+      for (auto& f : ns.aux)
+        for (int g = k; g < k + len; ++g)
+          if (P.kernels[g].name == f) ok = false;
+      aux.insert(ns.aux.begin(), ns.aux.end());
+      if (!ok || (int)aux.size() > kMaxStarAux) break;
+      ++len;
+    }
+    return len;
+  };
+  // field passes (reads + writes of whole fields) of the chain-only plan from kernel k until it has covered `until`
+  auto chain_plan_cost = [&](int k, int until, int* end) {
+    double cost = 0;
+    while (k < until && k < K) {
+      StarShape sh;
+      if (star_eligible(P, P.kernels[k], &sh)) {
+        const int len = star_chain_len(k);
+        std::set<std::string> aux;
+        for (int g = k; g < k + len; ++g) {
+          StarShape gs;
+          star_eligible(P, P.kernels[g], &gs);
+          aux.insert(gs.aux.begin(), gs.aux.end());
+        }
+        cost += 2.0 + (double)aux.size();
+        k += len;
+      } else {
+        std::set<std::string> fields;
+        for (auto& a : P.kernels[k].acc) fields.insert(a.field);
+        cost += 1.0 + (double)fields.size();
+        k += 1;
+      }
+    }
+    if (end) *end = k;
+    return cost;
+  };
+
   // ---- group kernels into launches
   std::map<std::string, StarChoice> star_memo;
   for (int k = 0; k < K;) {
@@ -805,9 +1039,48 @@ void build_plan(sf_plan& pl) {
         st.kernels.push_back(k);
       }
     } else if (star) {
+      // a DAG group first: the largest one that moves fewer field passes per operator than the chains it replaces
+      // (the comparison runs to the end of the last chain either plan would form, so that cutting a branch in
+      // two to fill a group does not pass for a gain)
+      bool dagged = false;
+      if (dag_on) {
+        const int chain_len = star_chain_len(k);
+        for (int count = std::min(K - k, 12); count > chain_len && !dagged; --count) {
+          DagGroup g;
+          if (!build_dag_group(P, k, count, readers, &g) || dag_is_chain(g)) continue;
+          if (g.dag.depth > fuse || g.dag.nwin > dag_windows) continue;
+          int end_chain = k, end_dag = k + count;
+          const double cost_chain = chain_plan_cost(k, k + count, &end_chain);
+          const double cost_dag = 1.0 + (double)g.aux.size() + (double)g.dag.nout +
+                                  (end_dag < end_chain ? chain_plan_cost(end_dag, end_chain, &end_dag) : 0.0);
+          if (cost_dag / (double)(end_dag - k) >= cost_chain / (double)(end_chain - k) - 1e-9) continue;
+          StarChoice choice = select_star(pl, star_memo, g.kernels, P.kernels[k].dt, &g.dag);
+          if (!choice.ok) continue;
+          st.star = true;
+          st.kernels = g.kernels;
+          st.cfg = choice.cfg;
+          st.ck = choice.ck;
+          st.alts = choice.alts;
+          st.sig = choice.sig;
+          // (groups of the same structure share the compiled kernel and the memoised choice; the field names in
+          // the description are this group's)
+          st.cfg.dag = g.dag;
+          for (auto& alt : st.alts) alt.first.dag = g.dag;
+          st.out_names = g.dag.outputs;
+          dagged = true;
+          if (pl.opt.get("debug", 0) != 0) {
+            std::fprintf(stderr, "[sf_hip] DAG group at %s: %d operators, depth %d, %d windows, outputs", P.kernels[k].name.c_str(),
+                         count, g.dag.depth, g.dag.nwin);
+            for (auto& o : g.dag.outputs) std::fprintf(stderr, " %s", o.c_str());
+            std::fprintf(stderr, " (passes %.0f over %d operators against %.0f over %d for chains)\n", cost_dag, end_dag - k,
+                         cost_chain, end_chain - k);
+          }
+        }
+      }
       std::vector<int> group{k};
       std::set<std::string> group_aux(shape.aux.begin(), shape.aux.end());
-      while ((int)group.size() < fuse && k + (int)group.size() < K) {
+      if (dagged) group.clear();
+      while (!dagged && (int)group.size() < fuse && k + (int)group.size() < K) {
         const int cur = group.back(), nxt = cur + 1;
         const Kernel& kc = P.kernels[cur];
         StarShape nshape;
@@ -836,7 +1109,9 @@ void build_plan(sf_plan& pl) {
         if (choice.ok) break;
         group.pop_back();
       }
-      if (choice.ok) {
+      if (dagged) {
+        // (planned above)
+      } else if (choice.ok) {
         st.star = true;
         st.kernels = group;
         st.cfg = choice.cfg;
@@ -965,6 +1240,17 @@ void build_plan(sf_plan& pl) {
         if (si == 0) r.push_back(sh.primary);
         if (!sh.extra.empty() && std::find(r.begin() + 1, r.end(), sh.extra) == r.end()) r.push_back(sh.extra);
       }
+    } else if (st.star && st.cfg.dag.on) {
+      // argument 0: the group's input field (window 0); then, in stage order and order of first use, the fields
+      // read at the point itself from memory (as gen_star numbers them)
+      const StarDag& dag = st.cfg.dag;
+      for (auto& ds : dag.stages)
+        if (ds.src == 0 && r.empty()) r.push_back(ds.primary);
+      for (size_t si = 0; si < st.kernels.size(); ++si)
+        for (auto& a : P.kernels[st.kernels[si]].acc)
+          if (a.field != dag.stages[si].primary && a.field != dag.stages[si].second &&
+              std::find(r.begin() + 1, r.end(), a.field) == r.end())
+            r.push_back(a.field);
     } else if (st.star) {
       StarShape sh0;
       star_eligible(P, P.kernels[st.kernels[0]], &sh0);
@@ -1003,31 +1289,36 @@ void build_plan(sf_plan& pl) {
       st.in_bufs.push_back(it->second);
       st.read_names.push_back(f);
     }
-    const Field& of = P.field(P.kernels[st.kernels.back()].name);
-    int ob = -1;
-    if (of.role == Role::Output) {
-      ob = make_buffer(of);
-      pl.output_buf[of.io_index] = ob;
-    } else {
-      Buffer probe;
-      {
-        // size the candidate without registering it
-        const size_t before = pl.buffers.size();
-        const int tmp = make_buffer(of);
-        probe = pl.buffers[tmp];
-        pl.buffers.resize(before);
-      }
-      auto key = std::make_pair(probe.bytes(), (int)probe.dt);
-      auto it = free_pool.find(key);
-      if (it != free_pool.end()) {
-        ob = it->second;
-        free_pool.erase(it);
-      } else {
+    // the fields the launch materialises (one: the last operator's, unless a DAG group names several)
+    if (st.out_names.empty()) st.out_names.push_back(P.kernels[st.kernels.back()].name);
+    for (auto& oname : st.out_names) {
+      const Field& of = P.field(oname);
+      int ob = -1;
+      if (of.role == Role::Output) {
         ob = make_buffer(of);
+        pl.output_buf[of.io_index] = ob;
+      } else {
+        Buffer probe;
+        {
+          // size the candidate without registering it
+          const size_t before = pl.buffers.size();
+          const int tmp = make_buffer(of);
+          probe = pl.buffers[tmp];
+          pl.buffers.resize(before);
+        }
+        auto key = std::make_pair(probe.bytes(), (int)probe.dt);
+        auto it = free_pool.find(key);
+        if (it != free_pool.end()) {
+          ob = it->second;
+          free_pool.erase(it);
+        } else {
+          ob = make_buffer(of);
+        }
       }
+      st.out_bufs.push_back(ob);
+      buf_of[of.name] = ob;
     }
-    st.out_buf = ob;
-    buf_of[of.name] = ob;
+    st.out_buf = st.out_bufs[0];
     // release temporaries whose last reader was this step
     std::set<std::string> released;
     for (auto& f : step_reads(st)) {

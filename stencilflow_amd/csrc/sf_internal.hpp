@@ -92,7 +92,9 @@ struct Step {
   std::vector<int> kernels;    // program kernel indices fused in this launch
   int ck = -1;                 // compiled kernel
   std::vector<int> in_bufs;    // argument order
-  int out_buf = -1;
+  int out_buf = -1;            // the (first) field the launch materialises
+  std::vector<int> out_bufs;   // all of them, output-pointer order (DAG groups: several); out_bufs[0] == out_buf
+  std::vector<std::string> out_names;
   std::vector<int> scalars;    // run-time scalars, argument / struct order
   std::vector<size_t> scalar_offsets;
   size_t scalars_bytes = 4;

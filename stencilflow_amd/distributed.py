@@ -860,13 +860,14 @@ class SlabRunner:
         self.outputs = [self.plan.step_output(s) for s in range(n)]
         # a *chain*: every launch reads exactly the field the previous one wrote
         self.is_chain = all(len(i) == 1 for i in self.inputs) and all(
-            self.inputs[s][0] == self.outputs[s - 1] for s in range(1, n))
+            self.inputs[s][0] == self.outputs[s - 1] for s in range(1, n)) and all(
+            len(self.plan.step_outputs(s)) == 1 for s in range(n))
         self._valid = 0
         self._early = None  # (step, handles) of an exchange started a launch ahead
         self.early_exchange = bool(early_exchange)
         # program inputs no launch writes (extra fields, auxiliary fields): their ghost planes are
         # filled ONCE per execution, to the full halo depth, at the first launch that reads them
-        written = set(self.outputs)
+        written = {b for s in range(n) for b in self.plan.step_outputs(s)}
         self._static = {self.plan.input_buffer(i) for i in range(len(self.plan.input_names))} - written
         self._fresh = set()
         if world > 1 and hasattr(self.exchanger, "attach"):

@@ -266,6 +266,106 @@ def star_program(seed):
     return prog
 
 
+def dag_program(seed):
+    """Fork / join programs of radius-1 star operators (the structure bin/synthesize.py -fork_frequency emits,
+    randomised): chains that fork into two branches of random length which a two-field operator joins again,
+    intermediates with several readers, intermediate program outputs, an optional auxiliary field read at the
+    point itself -- what the DAG groups of kernels/star3d.h fuse (round 4).  Boundary constants of the readers
+    of one field mostly agree (the condition for sharing a register window), sometimes not."""
+    rng = np.random.default_rng(seed + 4242)
+    nd = 3 if rng.random() < 0.55 else 2
+    its = ["i", "j", "k"][3 - nd:]
+    if nd == 3:
+        dims = [int(rng.integers(5, 25)), int(rng.integers(3, 41)), 4 * int(rng.integers(2, 41))]
+    else:
+        dims = [int(rng.integers(6, 120)), 4 * int(rng.integers(2, 80))]
+    dtype = "float32" if rng.random() < 0.65 else "float64"
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": [],
+            "dimensions": dims, "program": {}}
+    use_aux = rng.random() < 0.3
+    if use_aux:
+        prog["inputs"]["p"] = {"data": "constant:0.5", "data_type": dtype}
+    field_bc = {}  # field -> the constant most of its readers declare
+
+    def bc_of(field):
+        if field not in field_bc:
+            field_bc[field] = int(rng.integers(0, 2)) if rng.random() < 0.3 else float(rng.choice(EXACT))
+        if rng.random() < 0.08:  # a reader that disagrees: such operators cannot share the field's window
+            return float(rng.choice(EXACT))
+        return field_bc[field]
+
+    def star_of(field):
+        offs = [(d, o) for d in range(nd) for o in (-1, 1) if rng.random() < 0.7]
+        if not offs:
+            offs.append((int(rng.integers(0, nd)), int(rng.choice([-1, 1]))))
+        if rng.random() < 0.5:
+            offs.append((0, 0))
+        terms = []
+        for t in rng.permutation(len(offs)):
+            d, o = offs[int(t)]
+            idx = [it if e != d or o == 0 else "%s%+d" % (it, o) for e, it in enumerate(its)]
+            acc = "%s[%s]" % (field, ",".join(idx))
+            terms.append(acc if rng.random() < 0.6 else "%r*%s" % (float(np.round(rng.uniform(-1, 1), 4)), acc))
+        expr = terms[0]
+        for t in terms[1:]:
+            expr = "%s %s %s" % (expr, rng.choice(["+", "+", "-"]), t)
+        return expr
+
+    def add(name, sources):
+        expr = " + ".join("(%s)" % star_of(f) for f in sources)
+        bcs = {f: {"type": "constant", "value": bc_of(f)} for f in sources}
+        if use_aux and rng.random() < 0.3:
+            expr = "%s + p[%s]" % (expr, ",".join(its))
+            bcs["p"] = {"type": "constant", "value": 0.0}
+        expr = "%r * (%s)" % (float(np.round(rng.uniform(0.05, 0.3), 8)), expr)
+        prog["program"][name] = {"computation_string": "%s = %s" % (name, expr), "boundary_conditions": bcs,
+                                 "data_type": dtype}
+        if rng.random() < 0.08:
+            prog["outputs"].append(name)
+
+    prev, count = "a", 0
+    for section in range(int(rng.integers(1, 4))):
+        for _ in range(int(rng.integers(0, 3))):  # a piece of chain
+            name = "c%d" % count
+            count += 1
+            add(name, [prev])
+            prev = name
+        kind = rng.random()
+        if kind < 0.7:  # fork into two branches, joined again
+            ends = []
+            for br in "xy":
+                cur = prev
+                for d in range(int(rng.integers(1, 3))):
+                    name = "f%d%s%d" % (section, br, d)
+                    add(name, [cur])
+                    cur = name
+                ends.append(cur)
+            name = "j%d" % section
+            if rng.random() < 0.85:
+                add(name, ends)
+            else:  # no join: both branch ends are results
+                prog["outputs"].extend(e for e in ends if e not in prog["outputs"])
+                add(name, [ends[0]])
+            prev = name
+        elif kind < 0.85:  # an intermediate with two readers that are both results
+            name = "m%d" % section
+            add(name, [prev])
+            for br in "xy":
+                add("r%d%s" % (section, br), [name])
+                prog["outputs"].append("r%d%s" % (section, br))
+            prev = name
+    if prev == "a":
+        add("c%d" % count, ["a"])
+        prev = "c%d" % count
+    if prev not in prog["outputs"]:
+        prog["outputs"].append(prev)
+    prog["outputs"] = list(dict.fromkeys(prog["outputs"]))
+    text = " ".join(k["computation_string"] for k in prog["program"].values())
+    if use_aux and "p[" not in text:
+        del prog["inputs"]["p"]
+    return prog
+
+
 def with_copy_boundaries(prog, seed, share=0.6):
     """The program with the boundary condition of a random share of its operators' streamed
     fields (those read off-centre) turned into `copy` -- an out-of-domain read takes the value at

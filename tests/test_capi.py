@@ -142,7 +142,7 @@ def test_memory_instruction_modes_compile_clean(tmp_path):
     with plan_of(programs.diffusion_advection_laplacian((32, 64, 128))) as plan:
         assert "#define SF_BUFFER_IO 1" in plan.kernel_source(0)
     with pytest.raises(ValueError):
-        plan_of(programs.jacobi3d((64, 64, 128), 4), {"k1.pf2": 3})
+        plan_of(programs.jacobi3d((64, 64, 128), 4), {"k1.pf2": 4})  # (3 = the five-slot ring of round 4)
 
 
 def test_environment_options_and_generic_buffer_loads(tmp_path, monkeypatch):
@@ -279,3 +279,60 @@ def test_round4_entry_points_without_a_device():
     lib = backend.load_library()
     assert lib.sf_halo_fail(None) == -1 and b"sf_halo_fail" in lib.sf_last_error()
     assert lib.sf_halo_abandon(None) == -1 and b"sf_halo_abandon" in lib.sf_last_error()
+
+
+def test_fork_branches_are_planned_next_to_each_other(tmp_path):
+    """The generator's fork / join program (reference bin/synthesize.py:228-253) lists the operators of its two
+    branches interleaved (b3a0 b3b0 b3a1 b3b1: networkx' topological order); planned depth first each branch
+    is a chain of its own and fuses: 20 launches become 14 (dag=0: without the DAG groups of round 4, which fuse
+    further).  reorder=0 keeps the record's order; a plain chain is planned alike either way."""
+    prog, _ = programs.synthesize("float32", 16, 0.0, 64, 64, 64, 1, 1, 1, fork_frequency=0.25)
+    path = programs.write_program(prog, str(tmp_path / "fork.json"))
+    sfir = lower(sf.KernelChainGraph(path))
+    with backend.Plan(sfir, options={"dag": 0}) as plan:
+        text = plan.describe()
+        assert plan.num_launches == 14, text
+        assert ": b3a0 b3a1 [star T=2" in text and ": b3b0 b3b1 [star T=2" in text
+        assert plan.output_names == ["b15"]
+    with backend.Plan(sfir, options={"reorder": 0, "dag": 0}) as plan:
+        assert plan.num_launches == 20
+    chain = programs.write_program(programs.jacobi3d((64, 64, 64), 9), str(tmp_path / "chain.json"))
+    csfir = lower(sf.KernelChainGraph(chain))
+    with backend.Plan(csfir) as a, backend.Plan(csfir, options={"reorder": 0}) as b:
+        assert a.describe() == b.describe()
+
+
+def test_compiler_identity_and_code_objects(tmp_path):
+    """sf_compiler_id names the libamd_comgr the process compiles through (hipRTC binds it by soname: import order
+    decides) and ends sf_plan_describe; sf_plan_kernel_object hands out the ELF the plan would load;
+    sf_plan_step_kernel maps launches to compiled kernels."""
+    path = programs.write_program(programs.jacobi3d((64, 64, 64), 5), str(tmp_path / "p.json"))
+    with backend.Plan(lower(sf.KernelChainGraph(path))) as plan:
+        ident = plan.compiler()
+        assert "hiprtc" in ident and "comgr" in ident and "libamd_comgr" in ident
+        assert plan.describe().rstrip().splitlines()[-1].strip() == "compiler: " + ident
+        code, flags = plan.kernel_object(0)
+        assert code[:4] == b"\x7fELF" and isinstance(flags, str)
+        names = plan.kernel_names()
+        assert [names[plan.step_kernel(s)] for s in range(plan.num_steps)] == \
+            [ln.split()[1].rstrip(":") for ln in plan.describe().splitlines() if ln.strip().startswith("launch ")]
+        assert plan.kernel_launch_times() == {}  # nothing profiled yet
+
+
+def test_a_pinned_compiler_that_is_not_the_one_in_use_is_refused(tmp_path):
+    """$SF_HIP_COMGR: a process that compiles through another libamd_comgr than the one named must not plan."""
+    import subprocess
+    import sys
+    path = programs.write_program(programs.jacobi3d((32, 32, 32), 2), str(tmp_path / "p.json"))
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "import stencilflow_amd as sf\n"
+            "from stencilflow_amd import backend\n"
+            "from stencilflow_amd.lowering import lower\n"
+            "backend.load_library()\n"
+            "os.environ['SF_HIP_COMGR'] = %r\n"  # named only after the library (and its comgr) are loaded
+            "try:\n"
+            "    backend.Plan(lower(sf.KernelChainGraph(%r)))\n"
+            "except RuntimeError as e:\n"
+            "    print('refused:', e)\n") % (ROOT, "/opt/rocm/lib/libhiprtc.so", path)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "refused:" in r.stdout and "SF_HIP_COMGR pins the device compiler" in r.stdout, r.stdout + r.stderr

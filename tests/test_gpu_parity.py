@@ -784,7 +784,26 @@ def test_random_programs_under_slab_decomposition(tmp_path, seed):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     status, detail = mod.run_seed(seed, str(tmp_path))
-    assert status in ("ok", "skip"), detail
+    _SLAB_FUZZ_STATUS[seed] = status
+    if status == "skip":
+        # not a pass: the seed drew a program that cannot be decomposed (1-D, or slabs thinner than the halo);
+        # reported by name, and bounded by the test that follows
+        pytest.skip("slab_fuzz seed {}: {}".format(seed, detail or "a 1-D program has no slab axis to split"))
+    assert status == "ok", detail
+
+
+_SLAB_FUZZ_STATUS = {}
+
+
+def test_slab_fuzz_skips_are_counted_and_bounded():
+    """VERDICT r03 (weak 3): a skipped seed used to pass silently.  At most 2 of the 16 seeds above may skip,
+    and the ones that do are printed."""
+    if len(_SLAB_FUZZ_STATUS) < 16:
+        pytest.skip("runs after the 16 seeds of test_random_programs_under_slab_decomposition (a -k selection left some out)")
+    skipped = sorted(s for s, st in _SLAB_FUZZ_STATUS.items() if st == "skip")
+    print("slab_fuzz: {} of 16 seeds skipped: {}".format(len(skipped), skipped))
+    assert len(skipped) <= 2, skipped
+    assert sum(1 for st in _SLAB_FUZZ_STATUS.values() if st == "ok") >= 14
 
 
 def test_full_benchmark_configuration_bit_exact():
@@ -917,6 +936,40 @@ def test_full_size_generator_workloads_bit_exact(args, kwargs, stages, kernel):
     with Plan(lower(chain)) as plan:
         assert kernel in plan.describe(), plan.describe()
         assert list(plan.output_names) == [out] and list(plan.input_names) == ["a"]
+        plan.run([x], [got], 1)
+    ref = c_oracle.CompiledReference(prog)
+    ref.threads = _oracle_threads()
+    want = ref.run({"a": x})[out]
+    assert np.array_equal(got, want), npo.max_rel_err(want, got)
+
+
+@pytest.mark.parametrize("dims,options,expect", [
+    ((512, 512, 512), {"dag": 0}, "14 launches"),               # depth-first order: each branch a chain of its own
+    ((512, 512, 512), None, "[dag: 4 stages, 3 windows]"),       # both branches of a fork from one read
+    ((4096, 4096), None, "[dag: 6 stages"),                      # 2-D: fork, branches, join and what follows in one launch
+])
+def test_full_size_fork_join_programs_bit_exact(dims, options, expect):
+    """VERDICT r03 (next 2): the reference generator's fork / join program (`synthesize float32 16 0 ... 1 1 1
+    -fork_frequency 0.25`: 28 operators -- chains, two branches of two operators every fourth stage, a two-field
+    operator joining them; bin/synthesize.py:228-253) at full size on random data, all results against the C
+    oracle.  3-D: the depth-first operator order (each branch fuses like a chain), and with a third register
+    window the sibling groups (both branches of a fork evaluated from one read of the forked field, two fields
+    materialised); 2-D: DAG groups that hold a fork, its branches, the join and the chain after it."""
+    import tempfile
+    from oracle import c_oracle
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    size = list(dims) + [0] * (3 - len(dims))
+    ext = [1] * len(dims) + [0] * (3 - len(dims))
+    prog, _ = programs.synthesize("float32", 16, 0.0, size[0], size[1], size[2], ext[0], ext[1], ext[2], fork_frequency=0.25)
+    assert len(prog["program"]) == 28
+    x = np.random.default_rng(SEED + 41).uniform(-1, 1, dims).astype(np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        chain = sf.KernelChainGraph(programs.write_program(prog, os.path.join(tmp, "fork.json")))
+    out = prog["outputs"][0]
+    got = np.zeros(dims, np.float32)
+    with Plan(lower(chain), options=options) as plan:
+        assert expect in plan.describe(), plan.describe()
         plan.run([x], [got], 1)
     ref = c_oracle.CompiledReference(prog)
     ref.threads = _oracle_threads()

@@ -559,3 +559,113 @@ def test_random_compact_chains_under_slab_decomposition(seed, tmp_path):
         assert np.array_equal(got, want[name], equal_nan=True), (seed, name, runners[0].plan.describe()[:500])
     for r in runners:
         r.close()
+
+
+# ---- DAG groups of kernels/star3d.h (round 4): forks, joins, intermediates with several readers ---------------------
+DAG_CPU_SEEDS = list(range(700, 706))
+DAG_GPU_SEEDS = list(range(700, 716))  # (tools/star_fuzz.py --generator dag carries the volume: profiles/r04_dag_fuzz*.log)
+
+
+def _dag_case(seed, tmp_path):
+    from tests.random_programs import dag_program
+    prog = dag_program(seed)
+    rng = np.random.default_rng(seed + 7)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    path = programs.write_program(prog, str(tmp_path / "p.json"))
+    # 3-D programs get room for DAG groups every second seed (by default they hold as many windows as a chain)
+    opt = {"fuse": int(rng.integers(2, 5))}
+    if seed % 2 == 0:
+        opt["dag.windows"] = int(rng.integers(3, 6))
+    return prog, ins, sf.KernelChainGraph(path), opt
+
+
+@pytest.mark.parametrize("seed", DAG_CPU_SEEDS)
+def test_random_dag_programs_plan(seed, tmp_path):
+    """Fork / join programs are planned (CPU: hipRTC only) with every output named, and the two oracles agree."""
+    prog, ins, chain, opt = _dag_case(seed, tmp_path)
+    a = npo.run_reference(prog, inputs=ins)
+    b = c_oracle.CompiledReference(prog).run(inputs=ins)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (seed, k)
+    with Plan(lower(chain), options=opt) as plan:
+        assert sorted(plan.output_names) == sorted(prog["outputs"])
+        for s in range(plan.num_steps):
+            assert 1 <= len(plan.step_outputs(s)) <= 4 and plan.step_outputs(s)[0] == plan.step_output(s)
+
+
+def test_dag_groups_form_where_they_save_field_passes(tmp_path):
+    """2-D fork: the two branches, the join and what follows become one launch; 3-D holds one register window more
+    than a chain and evaluates both branches of a fork from one read of the forked field (dag.windows=2: as many
+    as a chain, no group forms).  dag=0 turns the machinery off."""
+    prog2, _ = programs.synthesize("float32", 16, 0.0, 256, 512, 0, 1, 1, 0, fork_frequency=0.25)
+    sfir2 = lower(sf.KernelChainGraph(programs.write_program(prog2, str(tmp_path / "f2.json"))))
+    with Plan(sfir2) as plan:
+        text = plan.describe()
+        assert "[dag: 6 stages, 6 windows]" in text and "[dag: 6 stages, 5 windows]" in text, text
+        two = [s for s in range(plan.num_steps) if len(plan.step_outputs(s)) == 2]
+        assert len(two) >= 1  # the group that ends in two branch ends materialises both
+        launches = plan.num_launches
+    with Plan(sfir2, options={"dag": 0}) as plan:
+        assert "[dag:" not in plan.describe() and plan.num_launches > launches
+    prog3, _ = programs.synthesize("float32", 16, 0.0, 64, 64, 64, 1, 1, 1, fork_frequency=0.25)
+    sfir3 = lower(sf.KernelChainGraph(programs.write_program(prog3, str(tmp_path / "f3.json"))))
+    with Plan(sfir3, options={"dag.windows": 2}) as plan:
+        assert "[dag:" not in plan.describe() and plan.num_launches == 14
+    with Plan(sfir3) as plan:  # (default in 3-D: one window more than a chain of the same depth)
+        assert plan.describe().count("[dag: 4 stages, 3 windows]") == 3 and plan.num_launches == 11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", DAG_GPU_SEEDS)
+def test_hip_matches_oracle_on_random_dag_programs(seed, tmp_path):
+    prog, ins, chain, opt = _dag_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain), options=opt) as plan:
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]])
+                for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, opt, plan.describe()[:600])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(720, 726)))
+def test_random_dag_programs_under_slab_decomposition(seed, tmp_path):
+    """DAG groups on two or three in-process slabs of unequal height: a launch reaches as many planes as the group
+    is deep, and a group that materialises several fields leaves all of them to be exchanged."""
+    from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
+    prog, ins, chain, opt = _dag_case(seed, tmp_path)
+    prog["dimensions"][0] = max(prog["dimensions"][0], 40)
+    p = npo.load_program(prog)
+    rng = np.random.default_rng(seed + 13)
+    ins = {name: rng.uniform(-1, 1, npo._dims_shape(p, npo._input_dims(p, name))).astype(npo._NP[desc["data_type"]])
+           for name, desc in p["inputs"].items()}
+    want = npo.run_reference(prog, inputs=ins)
+    sfir = lower(sf.KernelChainGraph(programs.write_program(prog, str(tmp_path / "p.json"))))
+    shape, world = tuple(prog["dimensions"]), int(rng.integers(2, 4))
+    exch = LocalExchanger(world)
+    runners = [SlabRunner(sfir, shape, r, world, options=opt, exchanger=exch.for_rank(r), groups_per_exchange=1)
+               for r in range(world)]
+    split = "i" if len(shape) == 3 else "j"
+    for r in runners:
+        local = []
+        for name in r.plan.input_names:
+            idims = npo._input_dims(p, name)
+            arr = np.ascontiguousarray(ins[name])
+            local.append(np.ascontiguousarray(arr[r.lo:r.hi]) if idims and idims[0] == split else arr)
+        r.upload(local)
+    run_lockstep(runners)
+    for oi, name in enumerate(runners[0].plan.output_names):
+        got = np.zeros(shape, dtype=want[name].dtype)
+        for r in runners:
+            parts = [np.zeros(r.local_shape, dtype=want[n].dtype) for n in r.plan.output_names]
+            r.download(parts)
+            got[r.lo:r.hi] = parts[oi]
+        assert np.array_equal(got, want[name], equal_nan=True), (seed, name, opt)
+    for r in runners:
+        r.close()

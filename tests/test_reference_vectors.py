@@ -248,3 +248,49 @@ def test_hip_against_the_reference_simulator_on_radius_2_stars(golden_dir, tmp_p
         assert np.array_equal(got[out], exp)
     else:
         assert _within_tolerance(exp, got[out], name)
+
+
+# ---- the six CANCELLING programs again on data in [0, 1) (tests/golden/simulator_unit.json, round 4): no sum cancels,
+# ---- so the rule of BASELINE.json's north_star applies as it stands -- per point, 1e-6 of the point's own value
+def _unit_names():
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "simulator_unit.json")
+    with open(here) as f:
+        return sorted(json.load(f)["programs"])
+
+
+def _unit(golden_dir, name):
+    with open(os.path.join(golden_dir, "simulator_unit.json")) as f:
+        return json.load(f)["programs"][name]
+
+
+def test_unit_twins_cover_every_cancelling_program():
+    assert set(_unit_names()) == {n + "_unit" for n in CANCELLING}
+
+
+@pytest.mark.parametrize("name", _unit_names())
+def test_oracle_against_the_reference_simulator_per_point_on_unit_data(golden_dir, name):
+    entry = _unit(golden_dir, name)
+    weak = npo.run_reference(entry["program"], typing="nep50")
+    own = npo.run_reference(entry["program"])
+    compiled = c_oracle.CompiledReference(entry["program"]).run()
+    for out, exp in _expected(entry).items():
+        assert float(exp.min()) > 0.0  # nothing cancels: the strict rule is meaningful at every point
+        assert np.array_equal(weak[out], exp), (name, out)  # the Simulator's own typing: bit for bit
+        assert np.array_equal(own[out], compiled[out]), (name, out)
+        assert npo.max_rel_err(exp, own[out]) <= TOL, (name, out, npo.max_rel_err(exp, own[out]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", _unit_names())
+def test_hip_against_the_reference_simulator_per_point_on_unit_data(golden_dir, tmp_path, name):
+    from tests.test_gpu_parity import _inputs_of, _run_gpu
+    entry = _unit(golden_dir, name)
+    path = str(tmp_path / (name + ".json"))
+    with open(path, "w") as f:
+        json.dump(entry["program"], f)
+    ins = _inputs_of(path)
+    got, _ = _run_gpu(path, ins)
+    own = npo.run_reference(path, inputs=ins)
+    for out, exp in _expected(entry).items():
+        assert np.array_equal(got[out], own[out]), (name, out)  # HIP == oracle, bit for bit
+        assert npo.max_rel_err(exp, got[out]) <= TOL, (name, out)  # HIP vs the reference: 1e-6 per point

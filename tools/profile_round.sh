@@ -22,14 +22,17 @@ if [ "${SF_PROFILE_SYSTEM_COMGR:-0}" != "1" ]; then
 fi
 # workloads: c3 c2 c5 = the bench workloads; box = the generator's 27-point chain (compact
 # kernel); wide = its radius-2 cross chain (wide-star kernel); generic = c3 forced onto the
-# generic operator kernel (16 / 40 operators)
-for wl in ${SF_PROFILE_WORKLOADS:-c3 c2 c5 box wide generic}; do
+# generic operator kernel (16 / 40 operators); dense = the generator's 125-point box (dense kernel); fork = its
+# fork / join program (several kernels: one record each)
+for wl in ${SF_PROFILE_WORKLOADS:-c3 c2 c5 box wide dense fork generic}; do
   [ "$wl" = none ] && continue
   out=gpurun_out/prof_${tag}_$wl
   rm -rf $out; mkdir -p $out
   case $wl in
     box) base="--workload box --stages 16"; short="--workload box --stages 16";;
     wide) base="--workload wide --stages 16"; short="--workload wide --stages 16";;
+    dense) base="--workload dense --stages 4 --steps 10"; short="--workload dense --stages 4";;
+    fork) base="--workload fork --stages 16 --steps 10"; short="--workload fork --stages 16";;
     generic) base="--workload c3 --stages 40 --options generic_only=1"; short="--workload c3 --stages 40 --options generic_only=1";;
     *) base="--workload $wl"; short="--workload $wl --stages 100";;
   esac

@@ -8,6 +8,8 @@ usage: star_fuzz.py [--seeds 300] [--first 0] [--options "k1.rev=1"] [--generato
 (--generator wide: chains of radius-2 stars, kernels/wstar3d.h; fusion depth 1-3;
  --generator dense: operators with dense radius-2 neighbourhoods, kernels/dense3d.h;
  --generator compact: the 27 offsets of radius 1, kernels/compact3d.h (tools/compact_fuzz.py is its own tool);
+ --generator dag: forks, joins and intermediates with several readers, kernels/star3d.h's DAG groups (round 4;
+   --options "dag.windows=4" lets 3-D programs form them too);
  --copy (or --generator copy = star --copy): a share of the boundary conditions becomes `copy` -- the
    reference's CPU expansion and the oracles have none (stencil/cpu.py:87), so the fused result is
    compared with the library's generic kernel, one operator per launch)"""
@@ -26,7 +28,7 @@ from stencilflow_amd.backend import Plan  # noqa: E402
 from stencilflow_amd.lowering import lower  # noqa: E402
 from oracle import numpy_oracle as npo  # noqa: E402
 
-from tests.random_programs import (compact_program, dense_program, dense_sum_program, star_program,  # noqa: E402
+from tests.random_programs import (compact_program, dag_program, dense_program, dense_sum_program, star_program,  # noqa: E402
                                    wide_program, with_copy_boundaries)
 
 
@@ -36,20 +38,21 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--options", default="")
     ap.add_argument("--dump", type=int, default=-1, help="print the program of one seed and exit")
-    ap.add_argument("--generator", choices=["star", "wide", "dense", "dense_sum", "compact", "copy"], default="star")
+    ap.add_argument("--generator", choices=["star", "wide", "dense", "dense_sum", "compact", "copy", "dag"], default="star")
     ap.add_argument("--seconds", type=float, default=0, help="stop after this many seconds (0: run all seeds)")
     ap.add_argument("--copy", action="store_true",
                     help="turn a share of the boundary conditions into `copy`; reference: the generic kernel")
     args = ap.parse_args()
     if args.generator == "copy":
         args.generator, args.copy = "star", True
-    plain = {"wide": wide_program, "dense": dense_program, "dense_sum": dense_sum_program, "compact": compact_program}.get(args.generator, star_program)
+    plain = {"wide": wide_program, "dense": dense_program, "dense_sum": dense_sum_program, "compact": compact_program,
+             "dag": dag_program}.get(args.generator, star_program)
     make = (lambda seed: with_copy_boundaries(plain(seed), seed)) if args.copy else plain
     if args.dump >= 0:
         print(json.dumps(make(args.dump), indent=1))
         return
     base = {k: v for k, v in (kv.split("=") for kv in args.options.split(";") if kv)}
-    nfail = nstar = nlaunch = ndone = 0
+    nfail = nstar = nlaunch = ndone = ndag = 0
     import time
     t_begin = time.perf_counter()
     with tempfile.TemporaryDirectory() as tmp:
@@ -89,6 +92,7 @@ def main():
                 continue
             desc = plan.describe()
             nstar += desc.count("[star") + desc.count("[wide star") + desc.count("[dense") + desc.count("[compact")
+            ndag += desc.count("[dag:")
             if (seed - args.first + 1) % 25 == 0:  # a long run must keep writing
                 print("# %d programs, %d failures so far" % (seed - args.first + 1, nfail), flush=True)
             nlaunch += plan.num_launches
@@ -106,7 +110,7 @@ def main():
                                       "first_bad": bad[0].tolist(), "dims": prog["dimensions"],
                                       "maxrel": npo.max_rel_err(want[n], got),
                                       "sched": desc[:600]}), flush=True)
-    print("programs: %d, launches: %d (fused kernels: %d), failures: %d" % (ndone, nlaunch, nstar, nfail))
+    print("programs: %d, launches: %d (fused kernels: %d, DAG groups: %d), failures: %d" % (ndone, nlaunch, nstar, ndag, nfail))
 
 
 if __name__ == "__main__":
