@@ -141,6 +141,14 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
   return best_li;
 }
 
+// Extra compiler flags of a kernel family: `<family>.slp=0|1` turns the SLP vectoriser off / on for it.  On gfx950 a
+// v_pk_add_f32 holds the vector pipe as long as the two v_add_f32 it replaces, its operand pairs are assembled with
+// moves and two dependent ones need wait states between them (an `s_nop` each): measured slower wherever it was
+// tried -- 27-point box (round 2), 125-point box 505 -> 450 us per launch (round 4, profiles/r04_dense_slp.log).
+static std::string slp_flags(const sf_plan& pl, const char* family, int dflt) {
+  return pl.opt.get(std::string(family) + ".slp", dflt) != 0 ? "" : "-fno-slp-vectorize";
+}
+
 // chunk length used for a launch over `range` planes (options k1.li / k2.li pin it)
 long long star_chunk_length(const sf_plan& pl, const StarCfg& c, DT dt, int range, int ranges) {
   long long li = pl.opt.get(c.noj ? "k2.li" : "k1.li", 0);
@@ -338,7 +346,7 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
     StarKernelSource g = gen_star(P, kernels, ranked[ci]);
     int ck = -1;
     try {
-      ck = intern_kernel(pl, prefix, g.source);
+      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "star", 1));
     } catch (const Error& e) {
       // a shape the compiler rejects is no candidate (a pinned shape reports it);
       // the group is shortened and in the end the generic kernel takes over
@@ -398,7 +406,7 @@ static StarChoice select_wide(sf_plan& pl, std::map<std::string, StarChoice>& me
     StarKernelSource g = gen_wide(P, kernels, ranked[ci]);
     int ck = -1;
     try {
-      ck = intern_kernel(pl, prefix, g.source);
+      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "wide", 1));
     } catch (const Error& e) {
       if (pinned || e.status != SF_ERR_COMPILE) throw;
       if (pl.opt.get("debug", 0) != 0)
@@ -475,6 +483,7 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     c.dense = true;
     c.dense_scalar = variant.second;
     c.dense_sum = variant.sum;
+    c.dense_il = (int)pl.opt.get("dense.il", 0);
     c.VK = dt == DT::F64 ? 2 : 4;  // 16 bytes of output per lane and row
     c.BX = sh.bx;
     c.BY = sh.by;
@@ -501,7 +510,7 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     if (it != memo.end()) return it->second;
     int ck = -1;
     try {
-      ck = intern_kernel(pl, prefix, g.source);
+      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "dense", 0));
     } catch (const Error& e) {
       if (e.status != SF_ERR_COMPILE) throw;
       if (pl.opt.get("debug", 0) != 0)
