@@ -84,6 +84,19 @@ def synthetic(shape, dtype=np.float32):
     return synthetic_planes(0, shape[0], shape[1:], dtype)
 
 
+def measured_valu_busy(kernel):
+    """Share of the vector issue slots this code object kept busy in the committed PMC pass (SQ_ACTIVE_INST_VALU /
+    SQ_WAVE_CYCLES x waves per SIMD; profiles/hbm_traffic.json), or None.  Near 1 the kernel is bound by vector
+    issue, whatever its HBM fraction says."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            v = json.load(f)[kernel].get("valu_busy")
+        return None if v is None else float(v)
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch of exactly this code object (kernel name including
     the hash of its generated source) from the committed rocprofv3 PMC passes
@@ -398,6 +411,10 @@ def time_single(wl, options, steps, warmup, device=0):
             roof["scope"] = "whole chain execution ({} launches of {} kernels); `kernel` is the one with most work".format(
                 plan.num_launches, kernels)
             roof["program"] = prog
+        busy = measured_valu_busy(name)
+        roof["valu_busy"] = busy
+        roof["limiter"] = None if busy is None else ("vector issue (VALU slots %.0f %% busy)" % (100 * busy) if busy >= 0.85 else
+                                                     "memory path (VALU slots %.0f %% busy)" % (100 * busy))
         roof.update(launch_spread(plan, name))
         med = float(np.median(step_ms))
         return {"value": cells / elapsed / 1e6, "ms_per_step": elapsed / steps * 1e3,

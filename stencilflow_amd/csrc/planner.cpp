@@ -346,7 +346,9 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
     StarKernelSource g = gen_star(P, kernels, ranked[ci]);
     int ck = -1;
     try {
-      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "star", 1));
+      // (off since round 4: float-typed sums -- integer boundary literals, the generator's programs -- gain 0.5-8 %
+      // without the packed adds, nothing loses: profiles/r04_slp_families.log)
+      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "star", 0));
     } catch (const Error& e) {
       // a shape the compiler rejects is no candidate (a pinned shape reports it);
       // the group is shortened and in the end the generic kernel takes over
@@ -406,7 +408,8 @@ static StarChoice select_wide(sf_plan& pl, std::map<std::string, StarChoice>& me
     StarKernelSource g = gen_wide(P, kernels, ranked[ci]);
     int ck = -1;
     try {
-      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "wide", 1));
+      // (3-D wide stars are the one family that gains from the packed adds: 8.8e5 against 8.0e5 without; 2-D: off, +2 %)
+      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "wide", P.n[1] == 1 ? 0 : 1));
     } catch (const Error& e) {
       if (pinned || e.status != SF_ERR_COMPILE) throw;
       if (pl.opt.get("debug", 0) != 0)

@@ -116,6 +116,7 @@ struct sf_plan {
   sf::Options opt{nullptr};
   int device = 0;
   bool device_ready = false;
+  bool self_checked = false;  // the plan-time self-check has run to its end (a verdict for every fused kernel)
   hipStream_t stream = nullptr;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   bool timed = false, profile = false;

@@ -96,8 +96,18 @@ def main():
             for old in [k for k, v in result.items()
                         if isinstance(v, dict) and v.get("family", re.sub(r"_[0-9a-f]{8}$", "", k)) == family]:
                 del result[old]
+            # vector-issue occupancy from the third PMC pass: every wave executes a vector instruction for
+            # SQ_ACTIVE_INST_VALU of its SQ_WAVE_CYCLES (both in quad-cycles; one instruction = one quad-cycle on
+            # gfx950), and SQ_WAVES / 1024 waves share a SIMD (all resident at once for these kernels)
+            active, cycles, waves = (counter_means(root, "SQ_ACTIVE_INST_VALU"), counter_means(root, "SQ_WAVE_CYCLES"),
+                                     counter_means(root, "SQ_WAVES"))
+            busy = None
+            if kernel in active and kernel in cycles and kernel in waves and cycles[kernel] > 0:
+                busy = active[kernel] / cycles[kernel] * (waves[kernel] / 1024.0)
             result[kernel] = {
                 "kernel": kernel, "family": family,
+                "valu_busy": busy,
+                "valu_instructions_per_launch": active.get(kernel),
                 "hbm_bytes_per_launch": fetch[kernel] * 1024.0 * 2.0 + write[kernel] * 1024.0,
                 "fetch_size_kb_reported": fetch[kernel],
                 "write_size_kb_reported": write[kernel],
