@@ -390,12 +390,14 @@ def time_single(wl, options, steps, warmup, device=0):
         kernel_ms = float(sum(step_ms))
         stats = plan.kernel_stats()
         launches = plan.num_launches * steps
-        name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"] * max(1, stats[k]["launches"]))
+        # (the plan also lists the tile-shape candidates it compiled and did not take: only launched kernels count)
+        launched = {plan.kernel_names()[plan.step_kernel(s)] for s in range(plan.num_steps)}
+        name = max(launched, key=lambda k: stats[k]["algorithmic_bytes_per_launch"] * max(1, stats[k]["launches"]))
         fused = wl["stages"] / plan.num_launches  # operators evaluated per launch
         cells = float(np.prod(wl["shape"])) * wl["stages"] * steps
         compulsory = float(np.prod(wl["shape"])) * wl["bpu"]  # the field once in, once out
         traffic = measured_traffic(name)
-        kernels = len(set(plan.kernel_names()))
+        kernels = len(launched)
         if kernels == 1:
             roof = roofline_block(name, traffic if traffic is not None else compulsory, traffic, kernel_ms * 1e-3,
                                   launches, launches, wl, fused, cells / launches)

@@ -1020,11 +1020,13 @@ void build_plan(sf_plan& pl) {
         if (a.off[1] != 0) star = false;
     }
     // radius-2 stars (bin/synthesize.py with an extent of 2): kernels/wstar3d.h, two fused by default
-    // (ten planes of register window per thread: f64 and deeper groups shrink the tile too far)
+    // (ten planes of register window per thread: deeper groups shrink the tile too far)
     const bool wide = !generic_only && star_ok_dims && pl.opt.get("wide", 1) != 0 && wide_eligible(P, P.kernels[k]);
     if (wide) {
       std::vector<int> group{k};
-      const int wfuse = (int)std::max<long long>(1, pl.opt.get("fuse", P.kernels[k].dt == DT::F64 ? 1 : 2));
+      // (f64 too since round 4: 64x8 threads x 5 rows, 238 registers -- 3.4 -> 6.3e5 Mcells/s on the generator's
+      // radius-2 cross 512^3, profiles/r04_c5_tiles_wide_f64.log)
+      const int wfuse = (int)std::max<long long>(1, pl.opt.get("fuse", 2));
       while ((int)group.size() < wfuse && k + (int)group.size() < K) {
         const int cur = group.back(), nxt = cur + 1;
         const Kernel& kc = P.kernels[cur];

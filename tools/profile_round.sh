@@ -53,6 +53,7 @@ done
 # the slab kernels of bench.py --gpus N (own code objects: the global plane count is a constant of the source):
 # rank 0's launches of one process without neighbours, tools/slab_traffic.py
 for n in ${SF_PROFILE_SLABS:-2 4 8}; do
+  [ "$n" = none ] && continue
   out=gpurun_out/prof_${tag}_slab$n
   rm -rf $out; mkdir -p $out
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 tools/slab_traffic.py --world $n --out $out/planes.json > $out/trace.log 2>&1
