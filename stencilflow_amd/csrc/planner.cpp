@@ -241,7 +241,11 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   // C5 +1.4 %; the cache-resident 64 MiB field of C2 loses 13 % with them).
   const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] *
                              (double)P.n[2] * (double)size_of(dt);
-  base.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
+  // (round 4, bit 2: the rows of a tile no other block reads -- neither a neighbouring tile's halo nor its source of
+  // halo rows -- are LOADED non-temporally as well, as a flat copy's loads would be; the shared rows keep the default
+  // policy and meet their second reader in the XCD's L2.  C3 199.9 -> 198.1-198.6 us on one box, 200.1 -> 198.1-198.2
+  // on another (profiles/r04_c3_prio_nt_fork.log); all-rows non-temporal loads, k1.nt=3, had lost 4-8 % in round 2)
+  base.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 5 : 0);
   const std::string pfx = base.noj ? "k2." : "k1.";
   const long long pin_bx = pl.opt.get(pfx + "bx", 0);
   const long long pin_by = base.noj ? 1 : pl.opt.get("k1.by", 0);
