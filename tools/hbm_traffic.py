@@ -92,9 +92,11 @@ def main():
             if kernel not in write:
                 continue
             family = re.sub(r"_[0-9a-f]{8}$", "", kernel)
-            # one record per kernel family: a new code object replaces the old record
+            # one record per kernel family AND workload: a new code object replaces the old record of the same
+            # workload (the fork program runs star kernels of the family C3's kernel belongs to)
             for old in [k for k, v in result.items()
-                        if isinstance(v, dict) and v.get("family", re.sub(r"_[0-9a-f]{8}$", "", k)) == family]:
+                        if isinstance(v, dict) and v.get("family", re.sub(r"_[0-9a-f]{8}$", "", k)) == family and
+                        v.get("workload", wl) == wl and k != kernel]:
                 del result[old]
             # vector-issue occupancy from the third PMC pass: every wave executes a vector instruction for
             # SQ_ACTIVE_INST_VALU of its SQ_WAVE_CYCLES (both in quad-cycles; one instruction = one quad-cycle on
@@ -105,7 +107,7 @@ def main():
             if kernel in active and kernel in cycles and kernel in waves and cycles[kernel] > 0:
                 busy = active[kernel] / cycles[kernel] * (waves[kernel] / 1024.0)
             result[kernel] = {
-                "kernel": kernel, "family": family,
+                "kernel": kernel, "family": family, "workload": wl,
                 "valu_busy": busy,
                 "valu_instructions_per_launch": active.get(kernel),
                 "hbm_bytes_per_launch": fetch[kernel] * 1024.0 * 2.0 + write[kernel] * 1024.0,

@@ -115,7 +115,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
-    ap.add_argument("--generator", choices=["mixed", "star", "wide", "compact", "dense"], default="mixed",
+    ap.add_argument("--generator", choices=["mixed", "star", "wide", "compact", "dense", "dag"], default="mixed",
                     help="mixed = star chains and random DAGs (the default); the others: tests/random_programs.py")
     ap.add_argument("--copy", action="store_true", help="`copy` boundaries; reference: undivided run on the generic kernel")
     ap.add_argument("--seconds", type=float, default=0, help="stop after this many seconds (0: all seeds)")
