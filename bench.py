@@ -85,9 +85,11 @@ def synthetic(shape, dtype=np.float32):
 
 
 def measured_valu_busy(kernel):
-    """Share of the vector issue slots this code object kept busy in the committed PMC pass (SQ_ACTIVE_INST_VALU /
-    SQ_WAVE_CYCLES x waves per SIMD; profiles/hbm_traffic.json), or None.  Near 1 the kernel is bound by vector
-    issue, whatever its HBM fraction says."""
+    """Average number of waves per SIMD that were inside a vector instruction during this code object's committed
+    PMC pass (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x resident waves per SIMD; profiles/hbm_traffic.json), or None.
+    A wave can issue one vector instruction per 4 cycles (1.0 per wave); f32 instructions of two waves overlap on a
+    SIMD, f64 ones hold the double-precision pipe for 4 cycles -- so ~1.0 saturates an f64-typed kernel (C2) and an
+    f32 one can pass it (the dense kernel: 1.34)."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
@@ -413,10 +415,7 @@ def time_single(wl, options, steps, warmup, device=0):
             roof["scope"] = "whole chain execution ({} launches of {} kernels); `kernel` is the one with most work".format(
                 plan.num_launches, kernels)
             roof["program"] = prog
-        busy = measured_valu_busy(name)
-        roof["valu_busy"] = busy
-        roof["limiter"] = None if busy is None else ("vector issue (VALU slots %.0f %% busy)" % (100 * busy) if busy >= 0.85 else
-                                                     "memory path (VALU slots %.0f %% busy)" % (100 * busy))
+        roof["valu_waves_active_per_simd"] = measured_valu_busy(name)
         roof.update(launch_spread(plan, name))
         med = float(np.median(step_ms))
         return {"value": cells / elapsed / 1e6, "ms_per_step": elapsed / steps * 1e3,

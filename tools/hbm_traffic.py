@@ -25,6 +25,25 @@ def counter_means(root, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+def resident_waves_per_simd(root):
+    """kernel -> waves of it that fit one SIMD at a time, from the launch records of the PMC passes (work-group size,
+    LDS per block, VGPRs per lane): min over the limits of registers (512 per lane and SIMD), LDS (160 KiB per unit),
+    wave slots (8 per SIMD)."""
+    out = {}
+    for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                k = r["Kernel_Name"]
+                if not k.startswith("sf_") or k in out:
+                    continue
+                wpb = max(1, int(r["Workgroup_Size"]) // 64)
+                vgpr = max(8, (int(r["VGPR_Count"]) + int(r.get("Accum_VGPR_Count") or 0) + 7) // 8 * 8)
+                lds = int(r["LDS_Block_Size"])
+                blocks = min(4 * (512 // vgpr) // wpb, (160 * 1024 // lds) if lds > 0 else 64, 32 // wpb)
+                out[k] = max(1, blocks) * wpb / 4.0
+    return out
+
+
 def counter_sums(root, counter):
     """kernel -> (sum over dispatches, number of dispatches) of one PMC pass."""
     acc = defaultdict(lambda: [0.0, 0])
@@ -100,15 +119,20 @@ def main():
                 del result[old]
             # vector-issue occupancy from the third PMC pass: every wave executes a vector instruction for
             # SQ_ACTIVE_INST_VALU of its SQ_WAVE_CYCLES (both in quad-cycles; one instruction = one quad-cycle on
-            # gfx950), and SQ_WAVES / 1024 waves share a SIMD (all resident at once for these kernels)
+            # gfx950) = `valu_share_per_wave`; times the waves that share a SIMD = the average number of waves per
+            # SIMD inside a vector instruction.  Not a fraction of a roofline by itself: f32 instructions of two waves
+            # overlap (the dense kernel reaches 1.34), f64 ones hold the double-precision pipe (C2 sits at 1.02).
             active, cycles, waves = (counter_means(root, "SQ_ACTIVE_INST_VALU"), counter_means(root, "SQ_WAVE_CYCLES"),
                                      counter_means(root, "SQ_WAVES"))
             busy = None
             if kernel in active and kernel in cycles and kernel in waves and cycles[kernel] > 0:
-                busy = active[kernel] / cycles[kernel] * (waves[kernel] / 1024.0)
+                # (a launch with more waves than fit at once keeps `resident` of them on a SIMD)
+                resident = resident_waves_per_simd(root).get(kernel, waves[kernel] / 1024.0)
+                busy = active[kernel] / cycles[kernel] * min(waves[kernel] / 1024.0, resident)
             result[kernel] = {
                 "kernel": kernel, "family": family, "workload": wl,
                 "valu_busy": busy,
+                "valu_share_per_wave": (active[kernel] / cycles[kernel]) if (kernel in active and kernel in cycles and cycles[kernel] > 0) else None,
                 "valu_instructions_per_launch": active.get(kernel),
                 "hbm_bytes_per_launch": fetch[kernel] * 1024.0 * 2.0 + write[kernel] * 1024.0,
                 "fetch_size_kb_reported": fetch[kernel],

@@ -19,9 +19,9 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2>$OUT/ben
 python - <<'PY'
 import json
 r = json.load(open("gpurun_out/r04_final_fuzz/bench_line.json"))
-print("value %.4e" % r["value"], {k: r["roofline"].get(k) for k in ("frac", "basis", "avg_launch_us", "min_us", "median_us", "max_us", "valu_busy", "limiter")})
+print("value %.4e" % r["value"], {k: r["roofline"].get(k) for k in ("frac", "basis", "avg_launch_us", "min_us", "median_us", "max_us", "valu_waves_active_per_simd")})
 for o in r["other_configs"]:
     if "error" in o: print("ERROR", o); continue
     ro = o["roofline"]
-    print("%-56s %.4e frac %.3f basis %s busy %s %s" % (o["workload"][:56], o["value"], ro["frac"], ro["basis"], ro.get("valu_busy"), (ro.get("program") or {}).get("pmc_over_compulsory")))
+    print("%-56s %.4e frac %.3f basis %s busy %s %s" % (o["workload"][:56], o["value"], ro["frac"], ro["basis"], ro.get("valu_waves_active_per_simd"), (ro.get("program") or {}).get("pmc_over_compulsory")))
 PY
