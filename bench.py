@@ -343,9 +343,9 @@ def program_traffic(plan, shape, bpu):
     complete = True
     per_kernel = {}
     for s in range(plan.num_steps):
-        reads = len(set(plan.step_inputs(s)))
-        need += (reads + 1) * field
-        per_kernel.setdefault(plan.step_kernel(s), []).append((reads + 1) * field)
+        passes = len(set(plan.step_inputs(s))) + len(plan.step_outputs(s))  # (a DAG group writes several fields)
+        need += passes * field
+        per_kernel.setdefault(plan.step_kernel(s), []).append(passes * field)
     for k, needs in per_kernel.items():
         t = measured_traffic(names[k])
         if t is None:

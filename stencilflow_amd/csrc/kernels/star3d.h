@@ -67,6 +67,27 @@
 #define SF_DAG 0
 #endif
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
+// SF_WIDE (2-D, one wave per block, float fields whose operators are typed double): the register windows hold the
+// values ALREADY CONVERTED to double.  A value is read by up to three steps and four neighbours; kept as float it is
+// converted at every use (4.0 v_cvt_f64_f32 per update in the C2 loop), kept as double once when it enters the
+// window (a float widens exactly: the results are the same bits).  Twice the window registers -- which the 2-D
+// kernels have -- and two DPP moves per lane-edge value instead of one.
+#ifndef SF_WIDE
+#define SF_WIDE 0
+#endif
+#if SF_WIDE
+typedef double sf_wt;
+#else
+typedef sf_t sf_wt;
+#endif
+typedef sf_wt sf_wvec __attribute__((ext_vector_type(SF_VK)));
+__device__ __forceinline__ sf_wvec sf_widen(const sf_vec v) {
+#if SF_WIDE
+  return __builtin_convertvector(v, sf_wvec);
+#else
+  return v;
+#endif
+}
 // the fields a launch materialises (argument `out` is p[0]; further outputs of a DAG group follow in `more`)
 struct sf_outptrs {
   sf_t* p[SF_NOUT > 0 ? SF_NOUT : 1];
@@ -184,7 +205,7 @@ struct sf_state
     : sf_auxslots<SF_NS>
 #endif
 {
-  sf_vec w[SF_NW][SF_SLOTS][SF_RJ];
+  sf_wvec w[SF_NW][SF_SLOTS][SF_RJ];
 #if SF_REVERSE == 2 || SF_PREFETCH2 == 1
   // input planes in flight: a ring of SF_PFD (1 or 3) planes, so a load has
   // SF_PFD full steps to land (slot = phase % SF_PFD)
@@ -438,9 +459,20 @@ __device__ __forceinline__ sf_aux_passed sf_aux_take(const sf_ctx& cx, const int
 #endif
 
 __device__ __forceinline__ void sf_load_plane(const sf_t* __restrict__ in, const sf_ctx& cx,
-                                              const int p, sf_vec (&dst)[SF_RJ], const bool enabled = true) {
+                                              const int p, sf_wvec (&dst)[SF_RJ], const bool enabled = true) {
+  (void)in;
+#if SF_WIDE
+  // (prologue only: the step loop loads into the float staging registers and widens on the copy)
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    sf_vec v = (sf_vec)sf_win<0>::bc();
+    SF_LOAD_ROW_IF(enabled, v, p, r);
+    dst[r] = sf_widen(v);
+  }
+#else
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) SF_LOAD_ROW_IF(enabled, dst[r], p, r);
+#endif
 }
 
 // Stage 1 is done with row r of the input window's "prev" slot: the row takes its next plane.
@@ -456,7 +488,7 @@ __device__ __forceinline__ void sf_refill_row(sf_state& st, const sf_ctx& cx, co
 #elif SF_PREFETCH2
   // it takes row r of plane p+1 from the staging registers (loaded during the previous step),
   // which then receive row r of plane p+2
-  st.w[0][iprev][r] = st.pf[PH % SF_PFD][r];
+  st.w[0][iprev][r] = sf_widen(st.pf[PH % SF_PFD][r]);
   SF_LOAD_ROW_IF(load_next, st.pf[PH % SF_PFD][r], p + 1 + SF_PFD, r);
 #elif SF_SPREAD_LOADS
   // it receives row r of input plane p+1 -- loads are spread over stage 1 instead of issued in a burst
@@ -469,18 +501,19 @@ __device__ __forceinline__ void sf_refill_row(sf_state& st, const sf_ctx& cx, co
 template <int W, int PH>
 struct sf_rowsrc {
   static constexpr int iprev = PH % SF_SLOTS, icur = (PH + 1) % SF_SLOTS, inext = (PH + 2) % SF_SLOTS;
-  sf_vec jm, jpl;  // the row above the one being evaluated; the first row of the thread row below
+  sf_wvec jm, jpl;  // the row above the one being evaluated; the first row of the thread row below
 #if SF_DPP == 4 && SF_WPR > 1
   sf_t e_lo[SF_RJ], e_hi[SF_RJ];
 #endif
-  sf_vec c, im, ip, jp;  // of the current row
-  sf_t km_e, kp_e;       // k-1 of the vector's first element, k+1 of its last
+  sf_wvec c, im, ip, jp;  // of the current row
+  sf_wt km_e, kp_e;       // k-1 of the vector's first element, k+1 of its last
 
   __device__ __forceinline__ void begin(const sf_state& st, const sf_t* lds, const sf_ctx& cx) {
     const int tx = cx.tx, ty = cx.ty;
     // first / last row of the neighbouring thread rows (LDS)
     jm = st.w[W][icur][0];
     jpl = st.w[W][icur][SF_RJ - 1];
+#if !SF_WIDE
     if constexpr (!SF_NOJ && SF_EXPERIMENT != 4) {
       // No test of the thread row: the first / last thread row of the tile reads an image that
       // exists (its own) -- rows 0 and SF_RJ-1 there are halo rows, whatever they take as their
@@ -489,6 +522,7 @@ struct sf_rowsrc {
       jm = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(W, ty > 0 ? ty - 1 : 0, 1) + tx * SF_VK]);
       jpl = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(W, ty < SF_BY - 1 ? ty + 1 : ty, 0) + tx * SF_VK]);
     }
+#endif
 #if SF_DPP == 4 && SF_WPR > 1
 #pragma unroll
     for (int r = 0; r < SF_RJ; ++r) {
@@ -522,33 +556,33 @@ struct sf_rowsrc {
     // select follows -- and a boundary constant of +0 is what bound_ctrl writes.
     const int ty = cx.ty;
     if (SF_WPR > 1 && cx.wave > 0)
-      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], lds[sf_edge_at(W, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]);
+      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], (sf_wt)lds[sf_edge_at(W, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]);
     else if (sf_win<W>::bc_zero)
       km_e = sf_neighbour_lane<true>(c[SF_VK - 1]);
     else
-      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], sf_win<W>::bc());
+      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], (sf_wt)sf_win<W>::bc());
     if (SF_WPR > 1 && cx.wave < SF_WPR - 1)
-      kp_e = sf_neighbour_lane_or<false>(c[0], lds[sf_edge_at(W, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]);
+      kp_e = sf_neighbour_lane_or<false>(c[0], (sf_wt)lds[sf_edge_at(W, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]);
     else if (sf_win<W>::bc_zero)
       kp_e = sf_neighbour_lane<false>(c[0]);
     else
-      kp_e = sf_neighbour_lane_or<false>(c[0], sf_win<W>::bc());
+      kp_e = sf_neighbour_lane_or<false>(c[0], (sf_wt)sf_win<W>::bc());
 #else
     const int ty = cx.ty;
     km_e = (SF_EXPERIMENT == 3) ? c[SF_VK - 1] : sf_neighbour_lane<true>(c[SF_VK - 1]);
     kp_e = (SF_EXPERIMENT == 3) ? c[0] : sf_neighbour_lane<false>(c[0]);
     if (SF_EXPERIMENT != 3 && cx.lane == 0)
       km_e = (SF_WPR > 1 && cx.wave > 0)
-                 ? lds[sf_edge_at(W, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]
-                 : sf_win<W>::bc();
+                 ? (sf_wt)lds[sf_edge_at(W, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]
+                 : (sf_wt)sf_win<W>::bc();
     if (SF_EXPERIMENT != 3 && cx.lane == 63)
       kp_e = (SF_WPR > 1 && cx.wave < SF_WPR - 1)
-                 ? lds[sf_edge_at(W, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]
-                 : sf_win<W>::bc();
+                 ? (sf_wt)lds[sf_edge_at(W, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]
+                 : (sf_wt)sf_win<W>::bc();
 #endif
   }
-  __device__ __forceinline__ sf_t km(const int v) const { return (v > 0) ? c[v > 0 ? v - 1 : 0] : km_e; }
-  __device__ __forceinline__ sf_t kp(const int v) const { return (v < SF_VK - 1) ? c[v < SF_VK - 1 ? v + 1 : v] : kp_e; }
+  __device__ __forceinline__ sf_wt km(const int v) const { return (v > 0) ? c[v > 0 ? v - 1 : 0] : km_e; }
+  __device__ __forceinline__ sf_wt kp(const int v) const { return (v < SF_VK - 1) ? c[v < SF_VK - 1 ? v + 1 : v] : kp_e; }
   // a row that is not evaluated still is the next row's j-neighbour
   __device__ __forceinline__ void skip(const sf_state& st, const int r) { jm = st.w[W][icur][r]; }
   __device__ __forceinline__ void next() { jm = c; }
@@ -690,7 +724,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
       }
       // becomes plane "next" of the window.  SF_REVERSE: its reader ran earlier in
       // this step and is done with the slot that held its plane "prev".
-      st.w[dst >= 0 ? dst : 0][SF_REVERSE ? iprev : inext][r] = o;
+      st.w[dst >= 0 ? dst : 0][SF_REVERSE ? iprev : inext][r] = sf_widen(o);
     }
 #if SF_ROW_FENCE
     __builtin_amdgcn_sched_barrier(0);  // rows in order: bounds the live f64 temporaries
@@ -819,6 +853,7 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
       }
 #endif
   // publish the rows / columns other threads need of every window's current plane
+#if !SF_WIDE  // (a lone wave per block publishes nothing)
 #pragma unroll
   for (int s = 0; s < SF_NW; ++s) {
     if constexpr (!SF_NOJ && SF_EXPERIMENT != 4) {
@@ -838,6 +873,10 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
       }
     }
   }
+#else
+  static_assert(SF_NOJ && SF_WPR == 1 && !SF_OPAQUE && SF_PREFETCH2 == 1 && !SF_REVERSE, "SF_WIDE: 2-D, one wave per block, staging registers");
+  (void)icur;
+#endif
   // SF_EXPERIMENT 2/4: timing-only builds without the barrier (invalid results)
   if (SF_USE_LDS && SF_EXPERIMENT != 2 && SF_EXPERIMENT != 4) __syncthreads();
   SF_STAMP_AT(0);
@@ -1032,7 +1071,7 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 #pragma unroll
     for (int w = 0; w < SF_SLOTS; ++w)
 #pragma unroll
-      for (int r = 0; r < SF_RJ; ++r) st.w[s][w][r] = (sf_vec)(sf_t)0;
+      for (int r = 0; r < SF_RJ; ++r) st.w[s][w][r] = (sf_wvec)(sf_wt)0;
 
   // p_end bounds the input planes read; p_last the steps (SF_REVERSE drains
   // T-1 more steps because its stages lag further)

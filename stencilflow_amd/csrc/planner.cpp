@@ -225,6 +225,17 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   base.uniform = (int)pl.opt.get("k1.uni", 0);
   // halo rows of the tile no later stage reads are not evaluated (star3d.h: SF_SKIP_ROWS)
   base.skip_rows = (int)pl.opt.get("k1.skip", 0);
+  // s_setprio for the younger half of a block's waves (star3d.h: SF_PRIO; measured -0.7 % on C3, off)
+  base.prio = (int)pl.opt.get("k1.prio", 0);
+  if (base.prio < 0 || base.prio > 3) throw Error(SF_ERR_INVALID, "k1.prio must lie in [0, 3]");
+  // 2-D float programs with double-typed operators on one-wave blocks: windows of converted values (star3d.h:
+  // SF_WIDE); needs the staging registers (the copy into the window is where a plane is converted)
+  base.wide = (pl.opt.get("k2.wide", 0) != 0 && base.noj && dt == DT::F32 && !base.reverse && !base.compact && base.R == 1) ? 1 : 0;
+  if (base.wide) {
+    base.prefetch2 = 1;
+    base.pfd = (int)pl.opt.get("k1.pfd", 3);
+    base.opaque = 0;
+  }
   // logical tile order inside an XCD's share of the grid: 1 = k-tiles fastest, so that the share is a band of whole
   // tile rows and all its k-neighbours (which re-read each other's halo columns) meet in one L2.  C5 (16 x 5 tiles):
   // FETCH 1.2445 -> 1.1922 GB per launch, 0.7 % faster (profiles/r03_c5_tile_order.log); no k-tiles: same order
