@@ -258,6 +258,53 @@ def test_zero_reach_launch_inside_a_chain_keeps_the_ghost_planes(native):
     _spawn(_zero_reach_worker, 3, (48, 20, 64), native)
 
 
+def _dag_native_worker(rank, world, port, native):
+    """The generator's fork / join program (2-D: DAG groups with two outputs, a join launch reading two slab-split
+    fields) on three processes, the library's own schedule and SlabRunner's, against the oracle."""
+    import torch  # noqa: F401
+    sys.path.insert(0, ROOT)
+    import stencilflow_amd as sf
+    from oracle import numpy_oracle as npo
+    from stencilflow_amd import programs
+    from stencilflow_amd.distributed import PeerExchanger, SlabRunner
+    from stencilflow_amd.lowering import lower
+    import tempfile
+    _init(rank, world, port)
+    exchanger = PeerExchanger(rank, world, "d{}".format(port), device=0)
+    prog, _ = programs.synthesize("float32", 12, 0.0, 96, 256, 0, 1, 1, 0, fork_frequency=0.25)
+    shape = tuple(prog["dimensions"])
+    with tempfile.TemporaryDirectory() as tmp:
+        sfir = lower(sf.KernelChainGraph(programs.write_program(prog, os.path.join(tmp, "p.json"))))
+    x = np.random.default_rng(17).uniform(-1, 1, shape).astype(np.float32)
+    runner = SlabRunner(sfir, shape, rank, world, device=0, exchanger=exchanger, groups_per_exchange=1)
+    assert "[dag:" in runner.plan.describe() and not runner.is_chain
+    assert any(len(runner.plan.step_outputs(s)) == 2 for s in range(runner.plan.num_steps))
+    runner.upload([x[runner.lo:runner.hi]])
+    if native:
+        runner.execute_native()
+        runner.synchronize_native()
+    else:
+        runner.execute()
+        runner.synchronize()
+    exchanger.check()
+    out = np.zeros(runner.local_shape, np.float32)
+    runner.download([out])
+    want = npo.run_reference(prog, {"a": x})[prog["outputs"][0]]
+    assert np.array_equal(out, want[runner.lo:runner.hi])
+    import torch.distributed as dist
+    dist.barrier()
+    runner.close()
+    exchanger.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("native", [False, True])
+def test_dag_groups_across_processes(native):
+    """Round 4: launches that materialise several fields under slab decomposition, both forms of the schedule."""
+    _spawn(_dag_native_worker, 3, native)
+
+
 def _c4_worker(rank, world, port, shape, stages, transport, out_dir):
     """One rank of C4's grid: its slab of seeded random data through `stages`
     operators, result written to out_dir/slab<rank>.dat."""
