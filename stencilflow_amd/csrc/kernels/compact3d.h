@@ -67,11 +67,40 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #ifndef SF_SKIP_ROWS
 #define SF_SKIP_ROWS 0
 #endif
+#ifndef SF_LDS_AHEAD
+#define SF_LDS_AHEAD 1
+#endif
+// Timing diagnostics (plan option debug.whatif; the results are WRONG): 1 no barrier, 2 no LDS reads (the
+// registers keep what they hold), 4 no lane exchange, 8 no loads of the streamed planes, 16 no stores,
+// 32 nothing published to LDS.
+#ifndef SF_WHATIF
+#define SF_WHATIF 0
+#endif
 #define SF_SLOTS 4
 #define SF_NWIN (SF_T + SF_NX)
 #define SF_TJH (SF_BY * SF_RJ)
 #define SF_TKH (SF_BX * SF_VK)
-#define SF_WPR (SF_BX / 64)
+// Lane neighbours (k-1 of a thread's first element, k+1 of its last).  SF_XLANE 0 (default): DPP wave_shr / wave_shl
+// with the wave-edge words from LDS.  SF_XLANE 1 (plan option k1.xlane=1): NO cross-lane vector instruction -- on
+// gfx950 a single DPP move (v_readlane, v_permlane alike) switches off, for ~2000 cycles, the overlap of two waves' f32
+// instructions on a SIMD (tools/micro/valu_rate.hip: 7 v_add_f32 + 1 DPP: 0.97 quad-cycles per instruction against
+// 0.53 for the adds alone, profiles/r04_valu_rate.log).  Rows that are published in full anyway (a thread row's first
+// and last row) are read back from the row image one element to the left and to the right (the images carry a pad on
+// either side holding the boundary constant); the rows in between go through ds_swizzle_b32 (rotation within 32
+// lanes, an LDS-pipe instruction) and the lanes at a 32-lane edge take the word their neighbour segment published.
+// Bit-exact (compact fuzz), and SLOWER than DPP on the 27-point box at every tile shape (profiles/r04_box_xlane.log:
+// the shifted reads have a stride of four words, an 8-way bank conflict, and the staging costs ~25 registers):
+// kept as a measured alternative, not chosen.
+#ifndef SF_XLANE
+#define SF_XLANE 0
+#endif
+#ifndef SF_XBATCH
+#define SF_XBATCH 0
+#endif
+#define SF_SEG (SF_XLANE ? 32 : 64)
+#define SF_WPR (SF_BX / SF_SEG) /* segments (waves or half-waves) per row */
+#define SF_ROW_PAD ((SF_XLANE && !SF_NOJ) ? 4 : 0)
+#define SF_ROW_STRIDE (SF_TKH + 2 * SF_ROW_PAD)
 #if SF_NOJ
 #define SF_TJI 1  // 2-D programs: the stream axis is j, there is no tiled row axis (one row per thread)
 #else
@@ -88,7 +117,7 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 // kind plus a compile-time offset.  The edge words of all images come first (a few
 // KB: one base register reaches all of them through the 16-bit offset field),
 // the row images follow.
-#define SF_ROWS_ELEMS (SF_BY * 2 * SF_TKH)
+#define SF_ROWS_ELEMS (SF_BY * 2 * SF_ROW_STRIDE)
 #define SF_EDGE_WAVES (SF_WPR + 2)
 #define SF_EDGE_ELEMS ((SF_BY + 2) * SF_RJ * SF_EDGE_WAVES * 2)
 #define SF_WIN_ELEMS (SF_ROWS_ELEMS + SF_EDGE_ELEMS)
@@ -163,7 +192,8 @@ struct sf_state {
 struct sf_ctx {
   const sf_t* in;
   sf_auxptrs xp;
-  int tx, ty, lane, wave;
+  int tx, ty, lane, wave;  // lane / wave: within / index of the SF_SEG-lane segment of the row
+  bool seg_first, seg_last;
   // run-time parts of the LDS addresses (elements): this thread's vector in the first
   // / last row of the thread row below / above (clamped at the tile's ends), in its
   // own rows, and the edge word (thread row ty - 1, row 0, wave - 1, side 0)
@@ -177,7 +207,7 @@ struct sf_ctx {
 #endif
 };
 
-__host__ __device__ constexpr int sf_rows_at(int ty, int which) { return (ty * 2 + which) * SF_TKH; }
+__host__ __device__ constexpr int sf_rows_at(int ty, int which) { return (ty * 2 + which) * SF_ROW_STRIDE + SF_ROW_PAD; }
 // (ty in -1 .. SF_BY, w in -1 .. SF_WPR)
 __host__ __device__ constexpr int sf_edge_at(int ty, int r, int w, int side) {
   return ((((ty + 1) * SF_RJ + r) * SF_EDGE_WAVES + (w + 1)) * 2 + side);
@@ -198,6 +228,21 @@ __device__ __forceinline__ T sf_neighbour_lane_or(T x, T edge) {
     int rlo = __builtin_amdgcn_update_dpp((int)(e & 0xffffffffll), (int)(v & 0xffffffffll), ctrl, 0xf, 0xf, false);
     int rhi = __builtin_amdgcn_update_dpp((int)(e >> 32), (int)(v >> 32), ctrl, 0xf, 0xf, false);
     asm("" : "+v"(rlo), "+v"(rhi));
+    return __builtin_bit_cast(T, ((long long)rhi << 32) | (unsigned int)rlo);
+  }
+}
+
+// value of the adjacent lane within its 32-lane segment through the LDS crossbar (no LDS memory is touched);
+// lanes at the segment's end receive the value of its other end and replace it (sf_merge_row)
+template <bool FROM_LOWER, typename T>
+__device__ __forceinline__ T sf_rotate_lane(T x) {
+  constexpr int pattern = FROM_LOWER ? 0xC420 /* swizzle(ROTATE, 1, 1): lane i reads i - 1 */ : 0xC020 /* reads i + 1 */;
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), pattern));
+  } else {
+    const long long v = __builtin_bit_cast(long long, x);
+    const int rlo = __builtin_amdgcn_ds_swizzle((int)(v & 0xffffffffll), pattern);
+    const int rhi = __builtin_amdgcn_ds_swizzle((int)(v >> 32), pattern);
     return __builtin_bit_cast(T, ((long long)rhi << 32) | (unsigned int)rlo);
   }
 }
@@ -267,72 +312,165 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const sf_t* fiel
 struct sf_nbr {
   sf_vec lo[3], hi[3];
   sf_t km[3][SF_RJ + 2], kp[3][SF_RJ + 2];
+#if SF_XLANE
+  sf_t ekm[3], ekp[3];  // segment-edge words of the one row whose rotated values are in flight
+#endif
 };
 
 __host__ __device__ constexpr unsigned sf_plane_bits(unsigned m, int d) { return (m >> (d * 9)) & 0x1ffu; }
 
-// source row RR (-1 .. SF_RJ) of window WIN at phase PH
-template <int WIN, unsigned NEED, int PH, int RR>
-__device__ __forceinline__ void sf_prepare_row(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx) {
-  constexpr int slot[3] = {PH % SF_SLOTS, (PH + 1) % SF_SLOTS, (PH + 2) % SF_SLOTS};
-  constexpr bool diag = sf_win<WIN>::diag;
+// Source row RR (-1 .. SF_RJ) of window WIN at phase PH, in two halves so that the LDS latency is covered by the
+// evaluation of a whole output row (SF_LDS_AHEAD; measured on the 27-point box: every second instruction the waves
+// waited on was an `s_waitcnt lgkmcnt(0)` ten instructions behind its `ds_read2_b32`):
+//   sf_fetch_row  issues the LDS reads -- the neighbouring thread row's row (RR = -1 / SF_RJ) and the two wave-edge
+//                 words of the row, which land in the very registers that will hold k-1 / k+1;
+//   sf_merge_row  exchanges the lane neighbours through DPP; the lanes at a wave edge keep the LDS word.
+template <int WIN, unsigned NEED, int PH, int RR, int d>
+struct sf_row_plan {
+  static constexpr bool diag = sf_win<WIN>::diag;
   // image that holds plane d: diagonal windows publish `next` every step (ring of 4:
   // next is this step's image, cur the previous one, prev the one before); star-like
   // windows publish `cur` (ring of 2)
-  constexpr int image[3] = {diag ? (PH + 2) % 4 : 0, diag ? (PH + 3) % 4 : PH % 2, diag ? PH % 4 : 0};
-  constexpr bool below = RR < 0, above = RR >= SF_RJ;
-  sf_static_for<0, 3>([&](auto D) {
-    constexpr int d = decltype(D)::value;
-    constexpr unsigned bits = sf_plane_bits(NEED, d);
-    // rows of this plane that some output row reads as its j-1 / j / j+1 neighbour
-    constexpr bool as_jm = (bits & 0x007u) != 0, as_jp = (bits & 0x1c0u) != 0;
-    constexpr bool want_row = below ? as_jm : (above ? as_jp : bits != 0);
-    constexpr bool want_km = want_row && (bits & 0x049u) != 0 && (!below || (bits & 0x001u)) && (!above || (bits & 0x040u));
-    constexpr bool want_kp = want_row && (bits & 0x124u) != 0 && (!below || (bits & 0x004u)) && (!above || (bits & 0x100u));
-    if constexpr (want_row) {
-      constexpr int g = sf_win_base<WIN>::value + image[d];
-      sf_vec row;
-      // thread row that owns the row (relative to ty), and its index there
-      constexpr int dty = below ? -1 : (above ? 1 : 0);
-      constexpr int orow = below ? SF_RJ - 1 : (above ? 0 : RR);
-      if constexpr (below) {
-        row = *reinterpret_cast<const sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_lo]);
-        nb.lo[d] = row;
-      } else if constexpr (above) {
-        row = *reinterpret_cast<const sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_hi]);
-        nb.hi[d] = row;
-      } else {
-        row = st.w[WIN][slot[d]][RR < 0 ? 0 : (RR >= SF_RJ ? SF_RJ - 1 : RR)];
+  static constexpr int image = d == 0 ? (diag ? (PH + 2) % 4 : 0) : (d == 1 ? (diag ? (PH + 3) % 4 : PH % 2) : (diag ? PH % 4 : 0));
+  static constexpr bool below = RR < 0, above = RR >= SF_RJ;
+  static constexpr unsigned bits = sf_plane_bits(NEED, d);
+  // rows of this plane that some output row reads as its j-1 / j / j+1 neighbour
+  static constexpr bool as_jm = (bits & 0x007u) != 0, as_jp = (bits & 0x1c0u) != 0;
+  static constexpr bool want_row = below ? as_jm : (above ? as_jp : bits != 0);
+  static constexpr bool want_km = want_row && (bits & 0x049u) != 0 && (!below || (bits & 0x001u)) && (!above || (bits & 0x040u));
+  static constexpr bool want_kp = want_row && (bits & 0x124u) != 0 && (!below || (bits & 0x004u)) && (!above || (bits & 0x100u));
+  static constexpr int g = sf_win_base<WIN>::value + image;
+  // thread row that owns the row (relative to ty), and its index there
+  static constexpr int dty = below ? -1 : (above ? 1 : 0);
+  static constexpr int orow = below ? SF_RJ - 1 : (above ? 0 : RR);
+  // the row is in the row image in full (first / last row of a thread row): SF_XLANE reads its neighbours there
+  static constexpr bool published = !SF_NOJ && (RR <= 0 || RR >= SF_RJ - 1);
+  // cx.edge0 addresses (ty - 1, row 0, wave - 1, side 0): the rest is compile-time
+  static constexpr int e_lo = sf_edge_at(dty, orow, -1, 1) - sf_edge_at(-1, 0, -1, 0);
+  static constexpr int e_hi = sf_edge_at(dty, orow, 1, 0) - sf_edge_at(-1, 0, -1, 0);
+};
+
+template <int WIN, unsigned NEED, int PH, int RR>
+__device__ __forceinline__ void sf_fetch_row(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx) {
+  if constexpr (RR >= -1 && RR <= SF_RJ && (SF_WHATIF & 2) != 0) {  // diagnostics: opaque values instead of LDS reads
+    sf_static_for<0, 3>([&](auto D) {
+      using plan = sf_row_plan<WIN, NEED, PH, RR, decltype(D)::value>;
+      constexpr int d = decltype(D)::value;
+      if constexpr (plan::want_row) {
+        sf_t z = (sf_t)cx.tx;
+        asm volatile("" : "+v"(z));
+        if constexpr (plan::below) nb.lo[d] = (sf_vec)z;
+        if constexpr (plan::above) nb.hi[d] = (sf_vec)z;
+        if constexpr (plan::want_km) nb.km[d][RR + 1] = z;
+        if constexpr (plan::want_kp) nb.kp[d][RR + 1] = z;
       }
-      // cx.edge0 addresses (ty - 1, row 0, wave - 1, side 0): the rest is compile-time
-      constexpr int e_lo = sf_edge_at(dty, orow, -1, 1) - sf_edge_at(-1, 0, -1, 0);
-      constexpr int e_hi = sf_edge_at(dty, orow, 1, 0) - sf_edge_at(-1, 0, -1, 0);
-      if constexpr (want_km)  // k-1: the lane below, or the lower wave's last element
-        nb.km[d][RR + 1] = sf_neighbour_lane_or<true>(row[SF_VK - 1], lds_all[SF_EDGE_IMAGE(g) + cx.edge0 + e_lo]);
-      if constexpr (want_kp)  // k+1
-        nb.kp[d][RR + 1] = sf_neighbour_lane_or<false>(row[0], lds_all[SF_EDGE_IMAGE(g) + cx.edge0 + e_hi]);
+    });
+  }
+  if constexpr (RR >= -1 && RR <= SF_RJ && !(SF_WHATIF & 2)) {
+    sf_static_for<0, 3>([&](auto D) {
+      using plan = sf_row_plan<WIN, NEED, PH, RR, decltype(D)::value>;
+      constexpr int d = decltype(D)::value;
+      if constexpr (plan::want_row) {
+        if constexpr (plan::below) nb.lo[d] = *reinterpret_cast<const sf_vec*>(&lds_all[SF_ROWS_IMAGE(plan::g) + cx.row_lo]);
+        if constexpr (plan::above) nb.hi[d] = *reinterpret_cast<const sf_vec*>(&lds_all[SF_ROWS_IMAGE(plan::g) + cx.row_hi]);
+#if SF_XLANE
+        if constexpr (plan::published) {
+          // this thread's vector in the row image, one element to the left / right of it
+          const int at = plan::below ? cx.row_lo : (plan::above ? cx.row_hi : (RR == 0 ? cx.row_own : cx.row_own + SF_ROW_STRIDE));
+          if constexpr (plan::want_km) nb.km[d][RR + 1] = lds_all[SF_ROWS_IMAGE(plan::g) + at - 1];
+          if constexpr (plan::want_kp) nb.kp[d][RR + 1] = lds_all[SF_ROWS_IMAGE(plan::g) + at + SF_VK];
+        } else {
+          constexpr int slot[3] = {PH % SF_SLOTS, (PH + 1) % SF_SLOTS, (PH + 2) % SF_SLOTS};
+          const sf_vec row = st.w[WIN][slot[d]][RR < 0 ? 0 : (RR >= SF_RJ ? SF_RJ - 1 : RR)];
+          if constexpr (plan::want_km) {
+            nb.ekm[d] = lds_all[SF_EDGE_IMAGE(plan::g) + cx.edge0 + plan::e_lo];
+            nb.km[d][RR + 1] = sf_rotate_lane<true>(row[SF_VK - 1]);
+          }
+          if constexpr (plan::want_kp) {
+            nb.ekp[d] = lds_all[SF_EDGE_IMAGE(plan::g) + cx.edge0 + plan::e_hi];
+            nb.kp[d][RR + 1] = sf_rotate_lane<false>(row[0]);
+          }
+        }
+#else
+        if constexpr (plan::want_km) nb.km[d][RR + 1] = lds_all[SF_EDGE_IMAGE(plan::g) + cx.edge0 + plan::e_lo];
+        if constexpr (plan::want_kp) nb.kp[d][RR + 1] = lds_all[SF_EDGE_IMAGE(plan::g) + cx.edge0 + plan::e_hi];
+#endif
+      }
+    });
+  }
+}
+
+template <int WIN, unsigned NEED, int PH, int RR>
+__device__ __forceinline__ void sf_merge_row(sf_nbr& nb, const sf_state& st, const sf_ctx& cx) {
+  constexpr int slot[3] = {PH % SF_SLOTS, (PH + 1) % SF_SLOTS, (PH + 2) % SF_SLOTS};
+  sf_static_for<0, 3>([&](auto D) {
+    using plan = sf_row_plan<WIN, NEED, PH, RR, decltype(D)::value>;
+    constexpr int d = decltype(D)::value;
+    if constexpr (plan::want_row) {
+      sf_vec row;
+      if constexpr (plan::below) row = nb.lo[d];
+      else if constexpr (plan::above) row = nb.hi[d];
+      else row = st.w[WIN][slot[d]][RR < 0 ? 0 : (RR >= SF_RJ ? SF_RJ - 1 : RR)];
+      if constexpr ((SF_WHATIF & 4) != 0) {
+        if constexpr (plan::want_km) nb.km[d][RR + 1] = row[SF_VK - 1];
+        if constexpr (plan::want_kp) nb.kp[d][RR + 1] = row[0];
+      } else {
+#if SF_XLANE
+        if constexpr (!plan::published) {  // (a published row's neighbours came from the row image as they are)
+          if constexpr (plan::want_km) nb.km[d][RR + 1] = cx.seg_first ? nb.ekm[d] : nb.km[d][RR + 1];
+          if constexpr (plan::want_kp) nb.kp[d][RR + 1] = cx.seg_last ? nb.ekp[d] : nb.kp[d][RR + 1];
+        }
+#else
+        if constexpr (plan::want_km)  // k-1: the lane below, or the lower wave's last element
+          nb.km[d][RR + 1] = sf_neighbour_lane_or<true>(row[SF_VK - 1], nb.km[d][RR + 1]);
+        if constexpr (plan::want_kp)  // k+1
+          nb.kp[d][RR + 1] = sf_neighbour_lane_or<false>(row[0], nb.kp[d][RR + 1]);
+#endif
+      }
     }
   });
 }
 
+// LDS reads of the first source rows of a stage step (-1, 0, 1); issued by the stage BEFORE (at its last output row) or,
+// for the first stage of a step, right behind the barrier.
+template <int WIN, unsigned NEED, int PH>
+__device__ __forceinline__ void sf_gather_begin(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx) {
+#if SF_XBATCH
+  return;  // (all source rows are prepared at the start of the stage step: sf_gather_prepare)
+#endif
+  sf_fetch_row<WIN, NEED, PH, -1>(nb, st, lds_all, cx);
+  sf_fetch_row<WIN, NEED, PH, 0>(nb, st, lds_all, cx);
+  sf_fetch_row<WIN, NEED, PH, 1>(nb, st, lds_all, cx);
+}
+
 // The source rows output row R needs that are not prepared yet: -1, 0 and 1 before the first output
-// row, R + 1 afterwards (also run for an output row that is skipped: the rows after it build on it).
+// row, R + 1 afterwards (also run for an output row that is skipped: the rows after it build on it);
+// the LDS reads of the row after that are issued for the next output row to find.
 template <int WIN, unsigned NEED, int PH, int R>
 __device__ __forceinline__ void sf_gather_prepare(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx) {
+#if SF_XBATCH
+  // All source rows of the stage step at once, before its first output row: the DPP moves of a stage step come in ONE
+  // burst.  On gfx950 a DPP move switches off the overlap of two waves' f32 instructions on the SIMD for ~2000 cycles
+  // (tools/micro/valu_rate.hip); spread over the rows, as they are otherwise, the moves keep it off for good.
   if constexpr (R == 0) {
-    sf_prepare_row<WIN, NEED, PH, -1>(nb, st, lds_all, cx);
-    sf_prepare_row<WIN, NEED, PH, 0>(nb, st, lds_all, cx);
+    sf_static_for<0, SF_RJ + 2>([&](auto RR) { sf_fetch_row<WIN, NEED, PH, decltype(RR)::value - 1>(nb, st, lds_all, cx); });
+    sf_static_for<0, SF_RJ + 2>([&](auto RR) { sf_merge_row<WIN, NEED, PH, decltype(RR)::value - 1>(nb, st, cx); });
   }
-  sf_prepare_row<WIN, NEED, PH, R + 1>(nb, st, lds_all, cx);
+  return;
+#endif
+  if constexpr (R == 0) {
+    sf_merge_row<WIN, NEED, PH, -1>(nb, st, cx);
+    sf_merge_row<WIN, NEED, PH, 0>(nb, st, cx);
+  }
+  sf_merge_row<WIN, NEED, PH, R + 1>(nb, st, cx);
+  sf_fetch_row<WIN, NEED, PH, R + 2>(nb, st, lds_all, cx);
 }
 
 // Neighbourhood of output row R: n[v][(d*3+e)*3+f] for the SF_VK points of the row,
 // read from window WIN through mask NEED at phase PH.
 template <int WIN, unsigned NEED, int PH, int R>
-__device__ __forceinline__ void sf_gather(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx,
-                                          sf_t (&n)[SF_VK][27]) {
+__device__ __forceinline__ void sf_gather(const sf_nbr& nb, const sf_state& st, sf_t (&n)[SF_VK][27]) {
   constexpr int slot[3] = {PH % SF_SLOTS, (PH + 1) % SF_SLOTS, (PH + 2) % SF_SLOTS};
-  sf_gather_prepare<WIN, NEED, PH, R>(nb, st, lds_all, cx);
   sf_static_for<0, 3>([&](auto D) {
     constexpr int d = decltype(D)::value;
     sf_static_for<0, 3>([&](auto E) {
@@ -365,7 +503,7 @@ __device__ __forceinline__ void sf_refill(sf_state& st, const sf_ctx& cx, const 
   if constexpr (S == 1) {
     // input window: prev (plane p-2) is dead, plane p+1 is in flight in the fourth
     // slot, so prev's row receives plane p+2 (two steps to land, no copy)
-    st.w[0][iprev][R] = sf_load_row<stage::bc_zero>(cx, cx.in, p + 2, R, p + 2 < p_end, stage::bc());
+    if constexpr (!(SF_WHATIF & 8)) st.w[0][iprev][R] = sf_load_row<stage::bc_zero>(cx, cx.in, p + 2, R, p + 2 < p_end, stage::bc());
   }
   if constexpr (stage::xneed != 0) {
     // extra field: this stage consumed planes q-1..q+1, q+2 is in flight: request q+3,
@@ -383,7 +521,8 @@ __device__ __forceinline__ void sf_refill(sf_state& st, const sf_ctx& cx, const 
 template <int S, int PH>
 __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all, const sf_scalars& sc,
                                               sf_t* __restrict__ out, const sf_ctx& cx, const int p,
-                                              const int p_end) {
+                                              const int p_end, sf_nbr& nbn, sf_nbr& nbx, sf_nbr& nbn_next,
+                                              sf_nbr& nbx_next) {
   using stage = sf_stage<S>;
   constexpr int src = S - 1;
   constexpr int iprev = PH % SF_SLOTS, inew = (PH + 3) % SF_SLOTS;
@@ -394,15 +533,23 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all,
   const bool store_plane = (S == SF_T) && q >= cx.cb && q < cx.ce && plane_in;
   sf_t pad = (sf_t)0;
   if constexpr (S < SF_T) pad = sf_stage<(S < SF_T ? S + 1 : S)>::bc();
-  sf_nbr nbn, nbx;
   sf_static_for<0, SF_RJ>([&](auto RR) {
     constexpr int r = decltype(RR)::value;
+    sf_gather_prepare<src, stage::need, PH, r>(nbn, st, lds_all, cx);
+    if constexpr (has_x) sf_gather_prepare<xw, stage::xneed, PH, r>(nbx, st, lds_all, cx);
+    if constexpr (r == SF_RJ - 1 && S > 1) {
+      // the stage that runs next in this step (S - 1; the stages of a step are independent of each other)
+      using below = sf_stage<(S > 1 ? S - 1 : 1)>;
+      sf_gather_begin<(S > 1 ? S - 2 : 0), below::need, PH>(nbn_next, st, lds_all, cx);
+      if constexpr (below::xneed != 0) sf_gather_begin<(below::xneed != 0 ? below::xwin : 0), below::xneed, PH>(nbx_next, st, lds_all, cx);
+    }
+#if SF_LDS_AHEAD
+    __builtin_amdgcn_sched_barrier(0);  // the reads above are issued before the row is evaluated, not behind it
+#endif
 #if SF_SKIP_ROWS
     // a halo row of the tile no later stage reads (star3d.h: SF_SKIP_ROWS; wave-uniform test): the windows
     // move on, the neighbour rows are prepared for the rows that follow, nothing is evaluated
     if (!((cx.need_rows[S - 1] >> r) & 1u)) {
-      sf_gather_prepare<src, stage::need, PH, r>(nbn, st, lds_all, cx);
-      if constexpr (has_x) sf_gather_prepare<xw, stage::xneed, PH, r>(nbx, st, lds_all, cx);
       if constexpr (r > 0) sf_refill<S, PH, r - 1>(st, cx, p, p_end);
       if constexpr (r == SF_RJ - 1) sf_refill<S, PH, r>(st, cx, p, p_end);
       return;
@@ -416,8 +563,8 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all,
         n[v][b] = (sf_t)0;
         x[v][b] = (sf_t)0;
       }
-    sf_gather<src, stage::need, PH, r>(nbn, st, lds_all, cx, n);
-    if constexpr (has_x) sf_gather<xw, stage::xneed, PH, r>(nbx, st, lds_all, cx, x);
+    sf_gather<src, stage::need, PH, r>(nbn, st, n);
+    if constexpr (has_x) sf_gather<xw, stage::xneed, PH, r>(nbx, st, x);
     sf_vec o;
 #pragma unroll
     for (int v = 0; v < SF_VK; ++v) o[v] = stage::apply(n[v], x[v], sc, q + cx.goff, cx.j0 + r, cx.k0 + v);
@@ -430,7 +577,11 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all,
       char* base = reinterpret_cast<char*>(out) + (long long)(q + cx.halo) * (long long)SF_PLANE_BYTES;
       const __amdgpu_buffer_rsrc_t rs =
           __builtin_amdgcn_make_buffer_rsrc(base, 0, store_plane ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
-      sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
+      if constexpr ((SF_WHATIF & 16) != 0) {
+        asm volatile("" : : "v"(o), "s"(rs));  // evaluated, not stored
+      } else {
+        sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
+      }
     } else {
       // outside the global domain the next stage must read ITS constant
       if (!(cx.tile_inside && plane_in)) {
@@ -448,10 +599,12 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all,
 
 template <int S, int PH>
 __device__ __forceinline__ void sf_stages_desc(sf_state& st, const sf_t* lds_all, const sf_scalars& sc,
-                                               sf_t* __restrict__ out, const sf_ctx& cx, const int p, const int p_end) {
+                                               sf_t* __restrict__ out, const sf_ctx& cx, const int p, const int p_end,
+                                               sf_nbr& nbn, sf_nbr& nbx) {
   if constexpr (S >= 1) {
-    sf_stage_step<S, PH>(st, lds_all, sc, out, cx, p, p_end);
-    sf_stages_desc<S - 1, PH>(st, lds_all, sc, out, cx, p, p_end);
+    sf_nbr nbn_next, nbx_next;
+    sf_stage_step<S, PH>(st, lds_all, sc, out, cx, p, p_end, nbn, nbx, nbn_next, nbx_next);
+    sf_stages_desc<S - 1, PH>(st, lds_all, sc, out, cx, p, p_end, nbn_next, nbx_next);
   }
 }
 
@@ -465,16 +618,16 @@ __device__ __forceinline__ void sf_publish(const sf_state& st, sf_t* lds_all, co
       constexpr int g = sf_win_base<W>::value + (diag ? PH % 4 : PH % 2);
       if constexpr (!SF_NOJ) {
         *reinterpret_cast<sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_own]) = st.w[W][slot][0];
-        *reinterpret_cast<sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_own + SF_TKH]) = st.w[W][slot][SF_RJ - 1];
+        *reinterpret_cast<sf_vec*>(&lds_all[SF_ROWS_IMAGE(g) + cx.row_own + SF_ROW_STRIDE]) = st.w[W][slot][SF_RJ - 1];
       }
       // own edge words: (ty, r, wave, side) = edge0 + compile-time offset
       constexpr int own = sf_edge_at(0, 0, 0, 0) - sf_edge_at(-1, 0, -1, 0);
-      if (cx.lane == 0) {
+      if (cx.seg_first) {
 #pragma unroll
         for (int r = 0; r < SF_RJ; ++r)
           lds_all[SF_EDGE_IMAGE(g) + cx.edge0 + own + r * SF_EDGE_WAVES * 2] = st.w[W][slot][r][0];
       }
-      if (cx.lane == 63) {
+      if (cx.seg_last) {
 #pragma unroll
         for (int r = 0; r < SF_RJ; ++r)
           lds_all[SF_EDGE_IMAGE(g) + cx.edge0 + own + r * SF_EDGE_WAVES * 2 + 1] = st.w[W][slot][r][SF_VK - 1];
@@ -491,7 +644,20 @@ __device__ __forceinline__ void sf_edge_prefill(sf_t* lds_all, const sf_ctx& cx)
     if constexpr (sf_win<W>::lateral) {
       constexpr int consumer = sf_win_info<W>::consumer;
       const sf_t bc = (W < SF_T) ? sf_stage<(consumer > 0 ? consumer : 1)>::bc() : sf_stage<(consumer > 0 ? consumer : 1)>::xbc();
-      if (cx.lane == 0 && (cx.wave == 0 || cx.wave == SF_WPR - 1)) {
+#if SF_ROW_PAD
+      // the element left of a row's first and right of its last column in the row images
+      if (cx.tx == 0) {
+#pragma unroll
+        for (int image = 0; image < sf_win<W>::ring; ++image)
+#pragma unroll
+          for (int which = 0; which < 2; ++which) {
+            sf_t* row = lds_all + SF_ROWS_IMAGE(sf_win_base<W>::value + image) + (cx.ty * 2 + which) * SF_ROW_STRIDE;
+            row[SF_ROW_PAD - 1] = bc;
+            row[SF_ROW_PAD + SF_TKH] = bc;
+          }
+      }
+#endif
+      if (cx.seg_first && (cx.wave == 0 || cx.wave == SF_WPR - 1)) {
 #pragma unroll
         for (int image = 0; image < sf_win<W>::ring; ++image)
 #pragma unroll
@@ -524,9 +690,13 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds_all, sf_t* __res
         else asm volatile("" : "+v"(st.w[w][s][r]));
       }
 #endif
-  sf_publish<0, PH>(st, lds_all, cx);
-  __syncthreads();
-  sf_stages_desc<SF_T, PH>(st, lds_all, sc, out, cx, p, p_end);
+  if constexpr (!(SF_WHATIF & 32)) sf_publish<0, PH>(st, lds_all, cx);
+  if constexpr (!(SF_WHATIF & 1)) __syncthreads();
+  sf_nbr nbn, nbx;
+  sf_gather_begin<SF_T - 1, sf_stage<SF_T>::need, PH>(nbn, st, lds_all, cx);
+  if constexpr (sf_stage<SF_T>::xneed != 0)
+    sf_gather_begin<(sf_stage<SF_T>::xneed != 0 ? sf_stage<SF_T>::xwin : 0), sf_stage<SF_T>::xneed, PH>(nbx, st, lds_all, cx);
+  sf_stages_desc<SF_T, PH>(st, lds_all, sc, out, cx, p, p_end, nbn, nbx);
 }
 
 // first planes of an extra field's window (stage S at step p0 consumes q-1, q, q+1
@@ -562,13 +732,15 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   const int sf_tid_x = (int)threadIdx.x, sf_tid_y = (int)threadIdx.y;
   cx.tx = sf_tid_x;
   cx.ty = sf_tid_y;
-  cx.wave = cx.tx >> 6;
-  cx.lane = cx.tx & 63;
+  cx.wave = cx.tx / SF_SEG;
+  cx.lane = cx.tx % SF_SEG;
+  cx.seg_first = cx.lane == 0;
+  cx.seg_last = cx.lane == SF_SEG - 1;
   cx.goff = goff;
   cx.halo = halo;
-  cx.row_own = sf_rows_at(0, 0) + cx.ty * 2 * SF_TKH + cx.tx * SF_VK;
-  cx.row_lo = ((cx.ty > 0 ? cx.ty - 1 : 0) * 2 + 1) * SF_TKH + cx.tx * SF_VK;
-  cx.row_hi = ((cx.ty < SF_BY - 1 ? cx.ty + 1 : SF_BY - 1) * 2) * SF_TKH + cx.tx * SF_VK;
+  cx.row_own = sf_rows_at(cx.ty, 0) + cx.tx * SF_VK;
+  cx.row_lo = sf_rows_at(cx.ty > 0 ? cx.ty - 1 : 0, 1) + cx.tx * SF_VK;
+  cx.row_hi = sf_rows_at(cx.ty < SF_BY - 1 ? cx.ty + 1 : SF_BY - 1, 0) + cx.tx * SF_VK;
   cx.edge0 = (cx.ty * SF_RJ * SF_EDGE_WAVES + cx.wave) * 2;  // = sf_edge_at(ty - 1, 0, wave - 1, 0)
 
   // XCD-aware block order: j-adjacent tiles (sharing halo rows) land on one XCD / L2

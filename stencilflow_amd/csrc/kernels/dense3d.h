@@ -28,6 +28,12 @@
 //   struct sf_dense {bc(), bc_zero, template<int PH> apply_row(tb, r, sc, o, gi, gj, gk0)}: the VK outputs of one row,
 //   every row segment (VK + 2R elements of one (di, dj)) read from LDS as aligned 16-byte chunks;
 //   SF_DENSE_ROWS 1 (the operator is one plain sum): apply_rows(tb, sc, out[RJ][VK]) instead, all rows in step.
+//   SF_DENSE_STREAM 1 (a plain sum whose terms come plane by plane, lowest plane first -- the generator's order, so the
+//   partial sum of output plane q meets its terms in the order of the text while the planes q-R .. q+R stream past):
+//   accumulate<PH>(tb, acc[5][RJ][VK]) adds the plane that has just arrived to the accumulators of the output planes
+//   it belongs to, finish(sc, acc[s], out) scales the finished one.  A plane is read from LDS ONCE instead of five
+//   times (1.5 instead of 7.6 ds_read_b128 per point of the 125-point box), the LDS ring shrinks to two slots, and
+//   SFD_DLAST (the highest plane offset of the text) says which output plane a step completes.
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 typedef sf_t sf_pair __attribute__((ext_vector_type(2)));
@@ -37,7 +43,23 @@ typedef sf_t sf_chunk __attribute__((ext_vector_type(16 / sizeof(sf_t))));
 typedef unsigned sf_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 
+#ifndef SF_DENSE_STREAM
+#define SF_DENSE_STREAM 0
+#endif
+// Timing diagnostics of the streaming form (plan option debug.whatif; the results are WRONG): 1 no barrier, 2 the plane
+// is not written to LDS, 8 no loads of the streamed planes, 16 results evaluated but not stored.
+#ifndef SF_WHATIF
+#define SF_WHATIF 0
+#endif
+#ifndef SF_DENSE_LOAD_EARLY
+#define SF_DENSE_LOAD_EARLY 0
+#endif
+#if SF_DENSE_STREAM
+#define SF_SLOTS 2  // LDS: the plane being read and the one being written
+#define SF_ACCS 5   // accumulator sets: output planes p - R .. p + R are open while plane p is read
+#else
 #define SF_SLOTS 6
+#endif
 #define SF_OOB 0x80000000u
 #define SF_PLANE_ELEMS ((long long)SF_N1 * (long long)SF_N2)
 #define SF_PLANE_BYTES ((unsigned)(SF_PLANE_ELEMS * (long long)sizeof(sf_t)))
@@ -118,6 +140,7 @@ __device__ __forceinline__ void sf_load_plane(const sf_ctx& cx, const int p, sf_
   }
 }
 
+#if !SF_DENSE_STREAM
 // One step: plane p (in `regs`) goes to slot PH, the loads of plane p + 1 are issued, output plane
 // q = p - R is evaluated and stored.
 template <int PH>
@@ -159,6 +182,59 @@ __device__ __forceinline__ void sf_step(sf_t* lds, sf_pair (&regs)[SF_NLOADS], s
   }
 #endif
 }
+
+#endif  // !SF_DENSE_STREAM
+
+#if SF_DENSE_STREAM
+// One step of the streaming form: plane p (in `regs`) goes to LDS slot `slot`, the loads of plane p + 1 are issued,
+// the plane is added to the open output planes (set of output plane q: (q - p_begin) mod 5, so with
+// PH = (p - p_begin) mod 5 the plane at offset di belongs to set (PH - di) mod 5), output plane p - SFD_DLAST is
+// finished and stored.
+template <int PH>
+__device__ __forceinline__ void sf_step_stream(sf_t* lds, sf_pair (&regs)[SF_NLOADS], sf_t* __restrict__ out,
+                                               const sf_scalars& sc, const sf_ctx& cx, const int p, const int p_end,
+                                               const int slot, sf_dense::acc_t (&acc)[SF_ACCS][SF_RJ][SF_VK]) {
+  sf_t* sl = lds + slot * SF_SLOT_ELEMS;
+  if constexpr (!(SF_WHATIF & 2)) {
+#pragma unroll
+    for (int n = 0; n < SF_NLOADS; ++n)
+      if (cx.ld_lds[n] >= 0) *reinterpret_cast<sf_pair*>(&sl[cx.ld_lds[n]]) = regs[n];
+  }
+#if SF_DENSE_LOAD_EARLY
+  // requested before the barrier (the LDS writes above have taken their operands): the wait at the barrier is part of
+  // the time the loads have to land
+  if constexpr (!(SF_WHATIF & 8)) sf_load_plane(cx, p + 1, regs, p + 1 < p_end);
+  if constexpr (!(SF_WHATIF & 1)) __syncthreads();  // (two slots: the waves still reading the other slot are at most one step behind)
+#else
+  if constexpr (!(SF_WHATIF & 1)) __syncthreads();  // (two slots: the waves still reading the other slot are at most one step behind)
+  if constexpr (!(SF_WHATIF & 8)) sf_load_plane(cx, p + 1, regs, p + 1 < p_end);  // lands during the evaluation below
+#endif
+  sf_dense::template accumulate<PH>(sl + cx.tb, acc);
+  // the sums are complete HERE: left alone, the compiler sinks the adds of an output plane towards the step that
+  // finishes it and keeps the operands -- whole planes of the patch -- alive until then (244 registers instead of ~100)
+#pragma unroll
+  for (int a = 0; a < SF_ACCS; ++a)
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r)
+#pragma unroll
+      for (int v = 0; v < SF_VK; ++v) asm volatile("" : "+v"(acc[a][r][v]));
+  const int q = p - SFD_DLAST;
+  const bool store_plane = q >= cx.cb && q < cx.ce && (q + cx.goff >= 0) && (q + cx.goff < SF_N0G);
+  char* base = reinterpret_cast<char*>(out) + (long long)(q + cx.halo) * (long long)SF_PLANE_BYTES;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(base, 0, store_plane ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
+  sf_t rows[SF_RJ][SF_VK];
+  sf_dense::finish(sc, acc[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    sf_vec o;
+#pragma unroll
+    for (int v = 0; v < SF_VK; ++v) o[v] = rows[r][v];
+    if constexpr ((SF_WHATIF & 16) != 0) asm volatile("" : : "v"(o), "s"(rs));
+    else sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
+  }
+}
+#endif
 
 extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, sf_auxptrs aux, int halo,
@@ -218,6 +294,25 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   sf_load_plane(cx, p_begin, regs, true);
   // the slots of planes before p_begin are never read for a stored plane: the first stored plane is
   // cb = p_begin + R, whose oldest operand plane is p_begin
+#if SF_DENSE_STREAM
+  // (an output plane before cb collects planes that were never added to it: it is not stored; the first stored plane
+  //  cb = p_begin + R opens at step p_begin + R + d0 >= p_begin, with the first term of the text -- an assignment)
+  sf_dense::acc_t acc[SF_ACCS][SF_RJ][SF_VK];
+#pragma unroll
+  for (int a = 0; a < SF_ACCS; ++a)
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r)
+#pragma unroll
+      for (int v = 0; v < SF_VK; ++v) acc[a][r][v] = (sf_dense::acc_t)0;
+  for (int p = p_begin; p < p_end; p += SF_ACCS) {
+    const int s0 = (p - p_begin) & 1;  // five steps per trip: the slot parity alternates from trip to trip
+    sf_step_stream<0>(lds, regs, out, sc, cx, p, p_end, s0, acc);
+    sf_step_stream<1>(lds, regs, out, sc, cx, p + 1, p_end, s0 ^ 1, acc);
+    sf_step_stream<2>(lds, regs, out, sc, cx, p + 2, p_end, s0, acc);
+    sf_step_stream<3>(lds, regs, out, sc, cx, p + 3, p_end, s0 ^ 1, acc);
+    sf_step_stream<4>(lds, regs, out, sc, cx, p + 4, p_end, s0, acc);
+  }
+#else
   for (int p = p_begin; p < p_end; p += SF_SLOTS) {
     sf_step<0>(lds, regs, out, sc, cx, p, p_end);
     sf_step<1>(lds, regs, out, sc, cx, p + 1, p_end);
@@ -226,4 +321,5 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     sf_step<4>(lds, regs, out, sc, cx, p + 4, p_end);
     sf_step<5>(lds, regs, out, sc, cx, p + 5, p_end);
   }
+#endif
 }

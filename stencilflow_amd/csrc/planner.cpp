@@ -27,7 +27,9 @@ size_t star_lds_bytes(const StarCfg& c, DT dt) {
   if (c.compact) {
     // kernels/compact3d.h: per window a ring of images (first / last row of every
     // thread row + the wave-edge columns of every row incl. two virtual waves)
-    const size_t win = (size_t)c.BY * 2 * c.BX * c.VK + (size_t)(c.BY + 2) * c.RJ * (c.BX / 64 + 2) * 2;
+    // (SF_XLANE: segments of 32 lanes, and four pad elements on either side of a row of the row images)
+    const size_t seg = c.xlane ? 32 : 64, pad = (c.xlane && !c.noj) ? 4 : 0;
+    const size_t win = (size_t)c.BY * 2 * (c.BX * c.VK + 2 * pad) + (size_t)(c.BY + 2) * c.RJ * (c.BX / seg + 2) * 2;
     return std::max<size_t>(1, (size_t)c.lds_images * win) * size_of(dt);
   }
   const size_t windows = c.dag.on ? (size_t)c.dag.nwin : (size_t)c.T;  // (kernels/star3d.h: SF_NW)
@@ -225,6 +227,10 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   base.uniform = (int)pl.opt.get("k1.uni", 0);
   // halo rows of the tile no later stage reads are not evaluated (star3d.h: SF_SKIP_ROWS)
   base.skip_rows = (int)pl.opt.get("k1.skip", 0);
+  base.whatif = (int)pl.opt.get("debug.whatif", 0);  // timing diagnostics, wrong results
+  base.lds_ahead = (int)pl.opt.get("k1.ahead", 1);
+  base.xlane = (int)pl.opt.get("k1.xlane", 0);
+  base.xbatch = (int)pl.opt.get("k1.xbatch", 0);
   // s_setprio for the younger half of a block's waves (star3d.h: SF_PRIO; measured -0.7 % on C3, off)
   base.prio = (int)pl.opt.get("k1.prio", 0);
   if (base.prio < 0 || base.prio > 3) throw Error(SF_ERR_INVALID, "k1.prio must lie in [0, 3]");
@@ -478,6 +484,7 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     Shape first;
     bool second;  // operands read from LDS where the text uses them
     bool sum;     // plain-sum form: the thread's rows accumulated in step, row segments shared between them
+    bool stream = false;  // plain sum, terms ordered by plane: every plane read from LDS once (SF_DENSE_STREAM)
   };
   std::vector<Variant> variants;
   // An operator that is one plain sum (the generator's boxes): several rows per thread, so that a row segment
@@ -486,6 +493,16 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
   //  against 0.666 row by row; four rows per thread 0.605-0.616: with 124 adds per point the kernel is bound by
   //  vector issue -- 0.42 ms at full rate -- not by LDS bytes any more)
   static const Shape sums3d[] = {{64, 4, 2}, {64, 8, 2}, {32, 8, 2}};
+  // The streaming form first (gen_dense refuses it when the terms are not ordered by plane): more rows per thread pay
+  // there, the accumulators of five open output planes being the only state
+  // (125-point box 512^3, profiles/r04_dense_stream.log: 64x2x4 0.397 ms per operator, 32x4x4 0.39, 64x2x2 0.41,
+  //  64x4x2 0.43, 64x4x4 0.47, against 0.44 for the form that reads every plane five times)
+  static const Shape streams3d[] = {{64, 2, 4}, {32, 4, 4}, {64, 2, 2}, {64, 4, 2}};
+  if (pl.opt.get("dense.sum", 1) != 0 && pl.opt.get("dense.stream", 1) != 0 && dense_sum_form(P, P.kernels[kidx], nullptr)) {
+    if (pin_bx && (noj || (pin_by && pin_rj))) variants.push_back({todo[0], false, true, true});
+    else if (noj) for (const Shape& sh : shapes2d) variants.push_back({sh, false, true, true});
+    else for (const Shape& sh : streams3d) variants.push_back({sh, false, true, true});
+  }
   if (pl.opt.get("dense.sum", 1) != 0 && dense_sum_form(P, P.kernels[kidx], nullptr)) {
     if (pin_bx && (noj || (pin_by && pin_rj))) variants.push_back({todo[0], false, true});
     else if (noj) for (const Shape& sh : shapes2d) variants.push_back({sh, false, true});
@@ -501,6 +518,9 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     c.dense = true;
     c.dense_scalar = variant.second;
     c.dense_sum = variant.sum;
+    c.dense_stream = variant.stream ? 1 : 0;
+    c.whatif = (int)pl.opt.get("debug.whatif", 0);  // timing diagnostics, wrong results
+    c.dense_early = variant.stream ? (int)pl.opt.get("dense.early", 0) : 0;
     c.dense_il = (int)pl.opt.get("dense.il", 0);
     c.VK = dt == DT::F64 ? 2 : 4;  // 16 bytes of output per lane and row
     c.BX = sh.bx;
@@ -516,13 +536,19 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     c.HK = 0;
     c.NKT = (int)((P.n[2] + tk - 1) / tk);
     c.NJT = noj ? 1 : (int)((P.n[1] + tj - 1) / tj);
-    const size_t lds = 6 * (size_t)(tj + (noj ? 0 : 4)) * (size_t)(tk + 4) * size_of(dt);
+    const size_t lds = (variant.stream ? 2 : 6) * (size_t)(tj + (noj ? 0 : 4)) * (size_t)(tk + 4) * size_of(dt);
     if (lds > 160 * 1024) continue;
     c.lds_bytes = lds;
     const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] * (double)P.n[2] *
                                (double)size_of(dt);
     c.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
-    StarKernelSource g = gen_dense(P, kidx, c);
+    StarKernelSource g;
+    try {
+      g = gen_dense(P, kidx, c);
+    } catch (const Error&) {
+      if (!variant.stream) throw;
+      continue;  // (the terms are not ordered by plane)
+    }
     const std::string sig = "dense" + std::to_string(fnv1a(g.source));
     auto it = memo.find(sig);
     if (it != memo.end()) return it->second;
@@ -538,8 +564,8 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     const CompiledKernel& k = pl.kernels[ck];
     if (pl.opt.get("debug", 0) != 0)
       std::fprintf(stderr, "[sf_hip] dense candidate block %dx%d rows/thread %d%s: vgpr %d agpr %d spill %d scratch %d lds %d\n", sh.bx,
-                   sh.by, sh.rj, variant.sum ? " (plain sum, rows in step)" : variant.second ? " (operands read where used)" : "", k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
-    if (!kernel_unsafe(k) && !kernel_slow(k)) {
+                   sh.by, sh.rj, variant.stream ? " (plain sum, planes streamed)" : variant.sum ? " (plain sum, rows in step)" : variant.second ? " (operands read where used)" : "", k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
+    if (!kernel_unsafe(k) && (!kernel_slow(k) || (pin_bx != 0 && pl.opt.get("allow_spills", 0) != 0))) {
       out.ok = true;
       out.cfg = c;
       out.ck = ck;

@@ -336,3 +336,31 @@ def test_a_pinned_compiler_that_is_not_the_one_in_use_is_refused(tmp_path):
             "    print('refused:', e)\n") % (ROOT, "/opt/rocm/lib/libhiprtc.so", path)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "refused:" in r.stdout and "SF_HIP_COMGR pins the device compiler" in r.stdout, r.stdout + r.stderr
+
+
+def test_dense_and_compact_kernel_forms_of_round_4(tmp_path):
+    """Plan-time view (no device) of round 4's kernel forms: the generator's 125-point box -- terms plane by plane -- takes
+    the dense kernel's streaming form (two LDS slots instead of six) unless dense.stream=0; the 27-point box takes the
+    compact kernel with its LDS reads issued a row ahead, and the measured alternatives of its lane exchange (k1.xbatch,
+    k1.xlane, k1.ahead=0) compile without spilling at a tile the register budget allows."""
+    big, _ = programs.synthesize("float32", 2, 0.0, 64, 64, 64, 2, 2, 2, stencil_shape="box")
+    sfir = lower(sf.KernelChainGraph(programs.write_program(big, str(tmp_path / "big.json"))))
+    with backend.Plan(sfir) as plan:
+        src = plan.kernel_source(0)
+        assert "[dense" in plan.describe() and "#define SF_DENSE_STREAM 1" in src and "#define SFD_DLAST 2" in src
+        stream_lds = plan.kernel_resources()[plan.kernel_names()[0]]["lds"]
+    with backend.Plan(sfir, options={"dense.stream": 0}) as plan:
+        assert "#define SF_DENSE_STREAM 1" not in plan.kernel_source(0)
+        assert plan.kernel_resources()[plan.kernel_names()[0]]["lds"] == 3 * stream_lds
+    box, _ = programs.synthesize("float32", 2, 0.0, 64, 64, 64, 1, 1, 1, stencil_shape="box")
+    sfir = lower(sf.KernelChainGraph(programs.write_program(box, str(tmp_path / "box.json"))))
+    with backend.Plan(sfir) as plan:
+        assert "[compact" in plan.describe()
+        assert "#define SF_XLANE 1" not in plan.kernel_source(0) and "#define SF_XBATCH 1" not in plan.kernel_source(0)
+    for opt, macro in (({"k1.xbatch": 1}, "#define SF_XBATCH 1"), ({"k1.xlane": 1}, "#define SF_XLANE 1"),
+                       ({"k1.ahead": 0}, "#define SF_LDS_AHEAD 0")):
+        with backend.Plan(sfir, options=opt) as plan:
+            assert "[compact" in plan.describe(), (opt, plan.describe())
+            assert macro in plan.kernel_source(0), opt
+            res = plan.kernel_resources()[plan.kernel_names()[0]]
+            assert res["spills"] == 0 and res["scratch"] == 0, (opt, res)

@@ -878,11 +878,14 @@ def test_full_c2_configuration_bit_exact():
     ((12, 18, 40), "float32", {"type": "shrink"}, True),
     ((70, 136), "float32", {"type": "constant", "value": 0.0}, True),
 ])
-def test_generator_box_of_extent_two_in_the_plain_sum_form(tmp_path, dims, dtype, bc, sum_form):
-    """The generator's box of extent 2 (125 points, 25 in 2-D) is ONE left-associated sum: the dense
-    kernel then accumulates all rows of a thread in step, term by term in the order of the text, and a row
-    segment read from LDS serves every row that needs it (codegen.hpp: dense_sum_form).  Same results,
-    bit for bit, as the oracle -- whatever type the boundary literal gives the sum."""
+@pytest.mark.parametrize("stream", [1, 0])
+def test_generator_box_of_extent_two_in_the_plain_sum_form(tmp_path, dims, dtype, bc, sum_form, stream):
+    """The generator's box of extent 2 (125 points, 25 in 2-D) is ONE left-associated sum whose terms come plane by
+    plane: the dense kernel reads every plane from LDS once and adds it to the five output planes that are open
+    (SF_DENSE_STREAM, the default since round 4); with dense.stream=0 it accumulates all rows of a thread in step,
+    term by term in the order of the text, a row segment read from LDS serving every row that needs it
+    (codegen.hpp: dense_sum_form).  Same results, bit for bit, as the oracle -- whatever type the boundary literal
+    gives the sum."""
     full = list(dims) + [0] * (3 - len(dims))
     ext = [2 if d else 0 for d in full]
     prog, _ = programs.synthesize(dtype, 2, 0.0, *full, *ext, stencil_shape="box")
@@ -895,9 +898,10 @@ def test_generator_box_of_extent_two_in_the_plain_sum_form(tmp_path, dims, dtype
     from stencilflow_amd.backend import Plan
     from stencilflow_amd.lowering import lower
     got = np.zeros(dims, dtype)
-    with Plan(lower(chain)) as plan:
+    with Plan(lower(chain), options={"dense.stream": stream}) as plan:
         assert "[dense" in plan.describe(), plan.describe()
         assert ("#define SF_DENSE_ROWS 1" in plan.kernel_source(0)) == sum_form
+        assert ("#define SF_DENSE_STREAM 1" in plan.kernel_source(0)) == bool(stream)
         plan.run([x], [got], 1)
     if bc["type"] == "copy":
         with Plan(lower(chain), options={"generic_only": 1}) as ref:

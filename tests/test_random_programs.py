@@ -516,6 +516,25 @@ def test_hip_matches_oracle_on_random_compact_chains(seed, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [{"k1.ahead": 0}, {"k1.xbatch": 1}, {"k1.xlane": 1}])
+@pytest.mark.parametrize("seed", COMPACT_GPU_SEEDS[:4])
+def test_compact_lane_exchange_variants_match_the_oracle(seed, extra, tmp_path):
+    """The measured alternatives of compact3d.h's neighbour exchange (round 4: LDS reads not issued a row ahead; the DPP
+    moves of a stage step in one burst; no DPP at all -- ds_swizzle and shifted reads of the row images) compute what
+    the default computes: bit for bit the oracle's results."""
+    prog, ins, chain, opt = _compact_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain), options={**opt, **extra}) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]])
+                for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, extra, n, plan.describe()[:600])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(200, 206)))
 def test_random_compact_chains_under_slab_decomposition(seed, tmp_path):
     """Compact chains (incl. stages with an extra streamed field, which the runner

@@ -79,7 +79,10 @@ def main_loop(insts):
         m = re.search(r"(-?\d+)\s*$", args)
         if not m:
             continue
-        target = a + 4 + 4 * int(m.group(1))  # SOPP branch: PC + 4 + simm16 * 4
+        simm = int(m.group(1))
+        if simm >= 32768:  # llvm-objdump prints the 16-bit field unsigned
+            simm -= 65536
+        target = a + 4 + 4 * simm  # SOPP branch: PC + 4 + simm16 * 4
         if target in addr_ix and addr_ix[target] < i:
             span = i - addr_ix[target]
             if best is None or span > best[1] - best[0]:
@@ -105,7 +108,7 @@ def updates_per_iteration(name, mac):
     elif name.startswith("sf_wstar"):
         unroll = 5
     elif name.startswith("sf_dense"):
-        unroll, t = 6, 1
+        unroll, t = (5 if mac.get("SF_DENSE_STREAM", 0) else 6), 1  # (the streaming form rotates five accumulator sets)
         vk = mac.get("SF_VK", 4)
     else:
         return None
