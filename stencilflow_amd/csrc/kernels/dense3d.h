@@ -197,8 +197,8 @@ __device__ __forceinline__ void sf_step_stream(sf_t* lds, sf_pair (&regs)[SF_NLO
   sf_t* sl = lds + slot * SF_SLOT_ELEMS;
   if constexpr (!(SF_WHATIF & 2)) {
 #pragma unroll
-    for (int n = 0; n < SF_NLOADS; ++n)
-      if (cx.ld_lds[n] >= 0) *reinterpret_cast<sf_pair*>(&sl[cx.ld_lds[n]]) = regs[n];
+    for (int n = 0; n < SF_NLOADS; ++n)  // (only the last round of pairs can run out of pairs)
+      if (n < SF_NLOADS - 1 || cx.ld_lds[n] >= 0) *reinterpret_cast<sf_pair*>(&sl[cx.ld_lds[n]]) = regs[n];
   }
 #if SF_DENSE_LOAD_EARLY
   // requested before the barrier (the LDS writes above have taken their operands): the wait at the barrier is part of
