@@ -576,6 +576,10 @@ def dense_sum_program(seed):
             offs.append((0, ) * nd)
         if rng.random() < 0.5:
             offs = [offs[int(t)] for t in rng.permutation(len(offs))]
+        # (round 4; its own generator, so that the programs of earlier campaigns keep their seeds) two operators in
+        # five have their terms ordered by plane -- any order inside a plane --: the dense kernel's streaming form
+        if np.random.default_rng(77_000 + 7 * seed + s).random() < 0.4:
+            offs.sort(key=lambda o: o[0])
         terms = ["%s[%s]" % (prev, ",".join(it if o == 0 else "%s%+d" % (it, o) for it, o in zip(its, off))) for off in offs]
         expr = " + ".join(terms)
         c = rng.random()
