@@ -15,6 +15,25 @@ namespace sf {
 // ---------------------------------------------------------------- planner
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// A candidate the compiler rejects is skipped and the planner moves on -- to the next tile shape, in the end to another
+// kernel family or the generic kernel.  That is the right thing for a shape that does not fit (registers, LDS); for an
+// ERROR in the generated source it would hide a broken kernel family behind a slower plan (round 4: one wrong identifier
+// in compact3d.h and the 27-point box ran on the dense kernel, bit-exact and 30 % slower).  So anything that does not
+// read like a resource limit is reported on stderr, once per kernel family and process, whatever `debug` says.
+static void report_rejected_candidate(const sf_plan& pl, const char* family, const std::string& what, const Error& e) {
+  const std::string msg = e.what();
+  const bool resources = msg.find("ran out of registers") != std::string::npos || msg.find("local memory") != std::string::npos ||
+                         msg.find("LDS size") != std::string::npos || msg.find("exceeds limit") != std::string::npos;
+  if (pl.opt.get("debug", 0) != 0)
+    std::fprintf(stderr, "[sf_hip] %s candidate %s rejected by the compiler: %.400s\n", family, what.c_str(), msg.c_str());
+  if (resources) return;
+  static std::set<std::string> told;
+  if (!told.insert(family).second) return;
+  const size_t at = msg.find("error:");
+  std::fprintf(stderr, "[sf_hip] warning: a %s kernel failed to COMPILE and the planner falls back to other kernels: %.300s\n",
+               family, at == std::string::npos ? msg.c_str() : msg.c_str() + at);
+}
+
 size_t star_lds_bytes(const StarCfg& c, DT dt) {
   if (c.dense) return c.lds_bytes;  // kernels/dense3d.h (select_dense computed it)
   if (c.R == 2) {
@@ -374,9 +393,7 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
       // a shape the compiler rejects is no candidate (a pinned shape reports it);
       // the group is shortened and in the end the generic kernel takes over
       if (pinned || e.status != SF_ERR_COMPILE) throw;
-      if (pl.opt.get("debug", 0) != 0)
-        std::fprintf(stderr, "[sf_hip] candidate %zu/%zu rejected by the compiler: %.200s\n", ci + 1,
-                     ranked.size(), e.what());
+      report_rejected_candidate(pl, "star", std::to_string(ci + 1) + "/" + std::to_string(ranked.size()), e);
       ++rejected;
       continue;
     }
@@ -433,8 +450,7 @@ static StarChoice select_wide(sf_plan& pl, std::map<std::string, StarChoice>& me
       ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "wide", P.n[1] == 1 ? 0 : 1));
     } catch (const Error& e) {
       if (pinned || e.status != SF_ERR_COMPILE) throw;
-      if (pl.opt.get("debug", 0) != 0)
-        std::fprintf(stderr, "[sf_hip] wide candidate %zu/%zu rejected by the compiler: %.400s\n", ci + 1, ranked.size(), e.what());
+      report_rejected_candidate(pl, "wide-star", std::to_string(ci + 1) + "/" + std::to_string(ranked.size()), e);
       ++rejected;
       continue;
     }
@@ -557,8 +573,7 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
       ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "dense", 0));
     } catch (const Error& e) {
       if (e.status != SF_ERR_COMPILE) throw;
-      if (pl.opt.get("debug", 0) != 0)
-        std::fprintf(stderr, "[sf_hip] dense candidate %dx%dx%d rejected by the compiler: %.400s\n", sh.bx, sh.by, sh.rj, e.what());
+      report_rejected_candidate(pl, "dense", std::to_string(sh.bx) + "x" + std::to_string(sh.by) + "x" + std::to_string(sh.rj), e);
       continue;
     }
     const CompiledKernel& k = pl.kernels[ck];
@@ -629,9 +644,7 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
       ck = intern_kernel(pl, prefix, g.source, compact_flags(pl));
     } catch (const Error& e) {
       if (pinned || e.status != SF_ERR_COMPILE) throw;
-      if (pl.opt.get("debug", 0) != 0)
-        std::fprintf(stderr, "[sf_hip] compact candidate %zu/%zu rejected by the compiler: %.400s\n", ci + 1,
-                     ranked.size(), e.what());
+      report_rejected_candidate(pl, "compact", std::to_string(ci + 1) + "/" + std::to_string(ranked.size()), e);
       ++rejected;
       continue;
     }

@@ -364,3 +364,18 @@ def test_dense_and_compact_kernel_forms_of_round_4(tmp_path):
             assert macro in plan.kernel_source(0), opt
             res = plan.kernel_resources()[plan.kernel_names()[0]]
             assert res["spills"] == 0 and res["scratch"] == 0, (opt, res)
+
+
+def test_a_kernel_family_that_fails_to_compile_is_reported(tmp_path, monkeypatch, capfd):
+    """A tile shape the compiler rejects for lack of registers is skipped silently; an ERROR in a generated kernel is not:
+    the planner still falls back (here: the 27-point box lands on the dense kernel, correct and slower) but says so on
+    stderr.  The error is injected through SF_HIP_EXTRA_FLAGS: a macro that breaks an identifier only compact3d.h uses."""
+    box, _ = programs.synthesize("float32", 2, 0.0, 48, 48, 64, 1, 1, 1, stencil_shape="box")
+    sfir = lower(sf.KernelChainGraph(programs.write_program(box, str(tmp_path / "box.json"))))
+    monkeypatch.setenv("SF_HIP_CACHE_DIR", "off")
+    monkeypatch.setenv("SF_HIP_EXTRA_FLAGS", "-Dsf_fetch_row=+")
+    with backend.Plan(sfir) as plan:
+        text = plan.describe()
+    err = capfd.readouterr().err
+    assert "[compact" not in text and ("[dense" in text or "[point" in text), text
+    assert "warning: a compact kernel failed to COMPILE" in err, err
