@@ -1036,6 +1036,38 @@ void build_plan(sf_plan& pl) {
     }
     return len;
   };
+  // the group the compact path would form at k (its conditions, no compilation), or 0 where it does not apply
+  auto compact_chain_len = [&](int k) {
+    const bool compact_dims = ((P.nd == 3 && P.n[1] > 1) || P.nd == 2) && P.n[0] > 1 && pl.opt.get("compact", 1) != 0;
+    CompactShape cs;
+    if (generic_only || !compact_dims || !compact_eligible(P, P.kernels[k], &cs)) return 0;
+    auto diagonal = [](const CompactShape& sh) {
+      return compact_lateral(sh.need, 0) || compact_lateral(sh.need, 2) || compact_lateral(sh.xneed, 0) ||
+             compact_lateral(sh.xneed, 2);
+    };
+    bool group_diagonal = diagonal(cs);
+    std::set<std::string> extras;
+    if (!cs.extra.empty()) extras.insert(cs.extra);
+    int len = 1;
+    while (len < fuse && k + len < K) {
+      const Kernel& kc = P.kernels[k + len - 1];
+      CompactShape ns;
+      if (!compact_eligible(P, P.kernels[k + len], &ns, kc.name)) break;
+      if (P.nd == 2 && !pl.opt.kv.count("fuse") && len >= 2 && (group_diagonal || diagonal(ns))) break;
+      group_diagonal = group_diagonal || diagonal(ns);
+      if (P.field(kc.name).role != Role::Temp || consumers[kc.name] != 1 || P.kernels[k + len].dt != kc.dt) break;
+      if (!ns.extra.empty()) {
+        bool produced_inside = false;
+        for (int g = k; g < k + len; ++g)
+          if (P.kernels[g].name == ns.extra) produced_inside = true;
+        if (produced_inside) break;
+        extras.insert(ns.extra);
+        if ((int)extras.size() > kMaxStarAux) break;
+      }
+      ++len;
+    }
+    return len;
+  };
   // field passes (reads + writes of whole fields) of the chain-only plan from kernel k until it has covered `until`
   auto chain_plan_cost = [&](int k, int until, int* end) {
     double cost = 0;
@@ -1072,6 +1104,14 @@ void build_plan(sf_plan& pl) {
     if (star && P.n[1] == 1) {
       for (auto& a : P.kernels[k].acc)
         if (a.off[1] != 0) star = false;
+    }
+    // A star chain that ends early because the NEXT operator is not a star (the generator's operators with a second
+    // spatial field, a box after a cross) while the compact kernel -- whose 27 offsets include every star -- could take
+    // both: the longer group wins, it saves a write and a read of the field between them (round 4; the generator's
+    // `num_fields_spatial 0.5` chains: 5 launches -> 4).  compact.prefer=0 restores the star-first order.
+    if (star && pl.opt.get("compact.prefer", 1) != 0) {
+      const int ls = star_chain_len(k);
+      if (ls < fuse && compact_chain_len(k) > ls) star = false;
     }
     // radius-2 stars (bin/synthesize.py with an extent of 2): kernels/wstar3d.h, two fused by default
     // (ten planes of register window per thread: deeper groups shrink the tile too far)

@@ -379,3 +379,18 @@ def test_a_kernel_family_that_fails_to_compile_is_reported(tmp_path, monkeypatch
     err = capfd.readouterr().err
     assert "[compact" not in text and ("[dense" in text or "[point" in text), text
     assert "warning: a compact kernel failed to COMPILE" in err, err
+
+
+def test_a_short_star_chain_joins_the_compact_group_that_follows(tmp_path):
+    """The generator's chains with a second spatial field in every other operator (num_fields_spatial 0.5): operator 0 is a
+    star, operator 1 is not -- the star chain would end after one operator and every later group start one operator
+    late (5 launches for 8 operators).  The compact kernel takes both, so the planner forms the longer group (4
+    launches); compact.prefer=0 restores the star-first order."""
+    prog, _ = programs.synthesize("float32", 8, 0.5, 64, 64, 64, 1, 1, 1)
+    sfir = lower(sf.KernelChainGraph(programs.write_program(prog, str(tmp_path / "p.json"))))
+    with backend.Plan(sfir) as plan:
+        text = plan.describe()
+        assert text.count("\n  launch ") == 4 and text.count("[compact windows 3 T=2") == 4, text
+    with backend.Plan(sfir, options={"compact.prefer": 0}) as plan:
+        text = plan.describe()
+        assert text.count("\n  launch ") == 5 and "[star T=1" in text, text
