@@ -34,6 +34,12 @@
 //   it belongs to, finish(sc, acc[s], out) scales the finished one.  A plane is read from LDS ONCE instead of five
 //   times (1.5 instead of 7.6 ds_read_b128 per point of the 125-point box), the LDS ring shrinks to two slots, and
 //   SFD_DLAST (the highest plane offset of the text) says which output plane a step completes.
+//   SF_DENSE_T2 1 (round 4): TWO such operators with offsets in {-1,0,1}^3 in one launch -- `sf_dense` over the input
+//   ring, its finished planes (padded with the second operator's boundary constant outside the global domain) go into a
+//   second LDS ring, `sf_dense2` streams over that one a step later; three accumulator sets per operator, one barrier
+//   per step.  The block evaluates both operators on its whole thread tile and stores the second one's interior (one row
+//   -- and, when a row is cut into tiles, four columns -- on either side are recomputed by the neighbouring tile); no
+//   register windows and no lane exchange, so the f32 adds of co-resident waves overlap.
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 typedef sf_t sf_pair __attribute__((ext_vector_type(2)));
@@ -54,9 +60,14 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #ifndef SF_DENSE_LOAD_EARLY
 #define SF_DENSE_LOAD_EARLY 0
 #endif
+#ifndef SF_DENSE_T2
+#define SF_DENSE_T2 0
+#endif
 #if SF_DENSE_STREAM
-#define SF_SLOTS 2  // LDS: the plane being read and the one being written
+#define SF_SLOTS (SF_DENSE_T2 ? 4 : 2)  // LDS: the plane being read and the one being written (T2: of either ring)
+#ifndef SF_ACCS
 #define SF_ACCS 5   // accumulator sets: output planes p - R .. p + R are open while plane p is read
+#endif
 #else
 #define SF_SLOTS 6
 #endif
@@ -67,10 +78,17 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 
 #if SF_NOJ
 #define SF_TJ 1
+#ifndef SF_RJH
 #define SF_RJH 0  // no row axis: no halo rows
+#endif
 #else
 #define SF_TJ (SF_BY * SF_RJ)
+#ifndef SF_RJH
 #define SF_RJH SF_R
+#endif
+#endif
+#ifndef SF_KTILED
+#define SF_KTILED 1
 #endif
 #define SF_TK (SF_BX * SF_VK)
 #define SF_LROWS (SF_TJ + 2 * SF_RJH)
@@ -120,6 +138,9 @@ struct sf_ctx {
   int ld_lds[SF_NLOADS];
   unsigned st_off[SF_RJ];  // byte offset of the thread's output vector in row r, or SF_OOB
   int tb;                  // LDS element index of the thread's patch origin (row -RJH, column -R of its outputs)
+#if SF_DENSE_T2
+  unsigned jmask, kmask;   // rows / columns of the thread's points that lie inside the global domain
+#endif
 };
 
 // the thread's pairs of input plane p, padded with the boundary constant outside the global domain
@@ -236,6 +257,80 @@ __device__ __forceinline__ void sf_step_stream(sf_t* lds, sf_pair (&regs)[SF_NLO
 }
 #endif
 
+#if SF_DENSE_T2
+// One step of the fused form.  PH = (p - p_begin) mod 3 names the accumulator sets as in sf_step_stream.  Operator 1
+// reads input plane p from slot `s0` of ring 0 and finishes its plane q1 = p - SFD_DLAST, which goes to ring 1 (slot
+// parity of q1); operator 2 reads the plane that went there in the PREVIOUS step (q1 - 1: this step's barrier has
+// made it visible) and finishes output plane q1 - 1 - SFD2_DLAST.
+template <int PH>
+__device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_pair (&regs)[SF_NLOADS], sf_t* __restrict__ out,
+                                           const sf_scalars& sc, const sf_ctx& cx, const int p, const int p_load_end,
+                                           const int s0, sf_dense::acc_t (&acc1)[SF_ACCS][SF_RJ][SF_VK],
+                                           sf_dense2::acc_t (&acc2)[SF_ACCS][SF_RJ][SF_VK]) {
+  // (requesting planes TWO steps ahead -- two register sets, the loop unrolled by six -- was measured: slower,
+  //  profiles/r04_dense_t2.log)
+  sf_t* in_slot = lds + s0 * SF_SLOT_ELEMS;
+  if constexpr (!(SF_WHATIF & 2)) {
+#pragma unroll
+    for (int n = 0; n < SF_NLOADS; ++n)  // (only the last round of pairs can run out of pairs)
+      if (n < SF_NLOADS - 1 || cx.ld_lds[n] >= 0) *reinterpret_cast<sf_pair*>(&in_slot[cx.ld_lds[n]]) = regs[n];
+  }
+  if constexpr (!(SF_WHATIF & 1)) __syncthreads();
+  if constexpr (!(SF_WHATIF & 8)) sf_load_plane(cx, p + 1, regs, p + 1 < p_load_end);
+  // ---- operator 1: plane p joins the open planes, plane q1 is finished and published
+  sf_dense::template accumulate<PH>(in_slot + cx.tb, acc1);
+#pragma unroll
+  for (int a = 0; a < SF_ACCS; ++a)
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r)
+#pragma unroll
+      for (int v = 0; v < SF_VK; ++v) asm volatile("" : "+v"(acc1[a][r][v]));
+  const int q1 = p - SFD_DLAST;
+  const bool plane1_in = (q1 + cx.goff >= 0) && (q1 + cx.goff < SF_N0G);
+  sf_t mid[SF_RJ][SF_VK];
+  sf_dense::finish(sc, acc1[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], mid);
+  const int mid_par = (s0 + 2 - SFD_DLAST) & 1;
+  sf_t* mid_w = lds + (2 + mid_par) * SF_SLOT_ELEMS + cx.tb + SF_RJH * SF_LS + SF_R;
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    // outside the global domain operator 2 reads ITS boundary constant
+    const bool row_in = plane1_in && ((cx.jmask >> r) & 1u);
+#pragma unroll
+    for (int v = 0; v < SF_VK; v += 2) {
+      sf_pair w;
+      w[0] = (row_in && ((cx.kmask >> v) & 1u)) ? mid[r][v] : sf_dense2::bc();
+      w[1] = (row_in && ((cx.kmask >> (v + 1)) & 1u)) ? mid[r][v + 1] : sf_dense2::bc();
+      *reinterpret_cast<sf_pair*>(&mid_w[r * SF_LS + v]) = w;
+    }
+  }
+  // ---- operator 2 on the plane published a step ago
+  constexpr int PH2 = (PH - SFD_DLAST - 1 + 2 * SF_ACCS) % SF_ACCS;
+  const sf_t* mid_r = lds + (2 + (mid_par ^ 1)) * SF_SLOT_ELEMS + cx.tb;
+  sf_dense2::template accumulate<PH2>(mid_r, acc2);
+#pragma unroll
+  for (int a = 0; a < SF_ACCS; ++a)
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r)
+#pragma unroll
+      for (int v = 0; v < SF_VK; ++v) asm volatile("" : "+v"(acc2[a][r][v]));
+  const int q2 = q1 - 1 - SFD2_DLAST;
+  const bool store_plane = q2 >= cx.cb && q2 < cx.ce && (q2 + cx.goff >= 0) && (q2 + cx.goff < SF_N0G);
+  char* base = reinterpret_cast<char*>(out) + (long long)(q2 + cx.halo) * (long long)SF_PLANE_BYTES;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(base, 0, store_plane ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
+  sf_t rows[SF_RJ][SF_VK];
+  sf_dense2::finish(sc, acc2[(PH2 - SFD2_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    sf_vec o;
+#pragma unroll
+    for (int v = 0; v < SF_VK; ++v) o[v] = rows[r][v];
+    if constexpr ((SF_WHATIF & 16) != 0) asm volatile("" : : "v"(o), "s"(rs));
+    else sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
+  }
+}
+#endif
+
 extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, sf_auxptrs aux, int halo,
                    int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2) {
@@ -264,7 +359,13 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   }
   if (cx.cb >= cx.ce) return;
 
+#if SF_DENSE_T2
+  // the thread tile overlaps its neighbours: the second operator's results are valid one row (four columns when a row
+  // is cut into tiles) inside it
+  const int tj0 = SF_NOJ ? 0 : jt * (SF_TJ - 2) - 1, tk0 = SF_KTILED ? kt * (SF_TK - 8) - 4 : 0;
+#else
   const int tj0 = SF_NOJ ? 0 : jt * SF_TJ, tk0 = kt * SF_TK;  // first output point of the tile
+#endif
   // the pairs this thread loads of every plane (row-major over the slot, pairs of columns)
 #pragma unroll
   for (int n = 0; n < SF_NLOADS; ++n) {
@@ -281,12 +382,26 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     const int j = tj0 + (SF_NOJ ? 0 : ty * SF_RJ + r), k = tk0 + tx * SF_VK;
+#if SF_DENSE_T2
+    const int tr = ty * SF_RJ + r, tc = tx * SF_VK;
+    const bool valid = (SF_NOJ || (tr >= 1 && tr < SF_TJ - 1)) && (!SF_KTILED || (tc >= 4 && tc < SF_TK - 4));
+    const bool inside = valid && j >= 0 && j < SF_N1 && k >= 0 && k + SF_VK <= SF_N2;
+#else
     const bool inside = j < SF_N1 && k + SF_VK <= SF_N2;
+#endif
     cx.st_off[r] = inside ? (unsigned)((j * SF_N2 + k) * (int)sizeof(sf_t)) : SF_OOB;
   }
   cx.tb = (SF_NOJ ? 0 : ty * SF_RJ) * SF_LS + tx * SF_VK;
   cx.j0 = tj0 + (SF_NOJ ? 0 : ty * SF_RJ);
   cx.k0 = tk0 + tx * SF_VK;
+#if SF_DENSE_T2
+  cx.jmask = 0;
+  cx.kmask = 0;
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) cx.jmask |= ((SF_NOJ || (cx.j0 + r >= 0 && cx.j0 + r < SF_N1)) ? 1u : 0u) << r;
+#pragma unroll
+  for (int v = 0; v < SF_VK; ++v) cx.kmask |= ((cx.k0 + v >= 0 && cx.k0 + v < SF_N2) ? 1u : 0u) << v;
+#endif
 
   // input planes [p_begin, p_end) are read; step p writes plane p into slot (p - p_begin) mod 6
   const int p_begin = cx.cb - SF_R, p_end = cx.ce + SF_R;
@@ -294,7 +409,30 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   sf_load_plane(cx, p_begin, regs, true);
   // the slots of planes before p_begin are never read for a stored plane: the first stored plane is
   // cb = p_begin + R, whose oldest operand plane is p_begin
-#if SF_DENSE_STREAM
+#if SF_DENSE_T2
+  // ring 1 starts out as the second operator's boundary constant: its halo rows and columns are never written again
+  // (they are right where the tile touches the edge of the domain; elsewhere the results that read them are not stored)
+  for (int i = tid; i < 2 * SF_SLOT_ELEMS; i += SF_THREADS) lds[2 * SF_SLOT_ELEMS + i] = sf_dense2::bc();
+  sf_dense::acc_t acc1[SF_ACCS][SF_RJ][SF_VK];
+  sf_dense2::acc_t acc2[SF_ACCS][SF_RJ][SF_VK];
+#pragma unroll
+  for (int a = 0; a < SF_ACCS; ++a)
+#pragma unroll
+    for (int r = 0; r < SF_RJ; ++r)
+#pragma unroll
+      for (int v = 0; v < SF_VK; ++v) {
+        acc1[a][r][v] = (sf_dense::acc_t)0;
+        acc2[a][r][v] = (sf_dense2::acc_t)0;
+      }
+  // output plane q2 leaves at step q2 + SFD_DLAST + 1 + SFD2_DLAST; input planes up to ce + R - 1 are read
+  const int p_stop = cx.ce + SFD_DLAST + 1 + SFD2_DLAST;
+  for (int p = p_begin; p < p_stop; p += SF_ACCS) {
+    const int s0 = (p - p_begin) & 1;  // three steps per trip: the slot parity alternates from trip to trip
+    sf_step_t2<0>(lds, regs, out, sc, cx, p, p_end, s0, acc1, acc2);
+    sf_step_t2<1>(lds, regs, out, sc, cx, p + 1, p_end, s0 ^ 1, acc1, acc2);
+    sf_step_t2<2>(lds, regs, out, sc, cx, p + 2, p_end, s0, acc1, acc2);
+  }
+#elif SF_DENSE_STREAM
   // (an output plane before cb collects planes that were never added to it: it is not stored; the first stored plane
   //  cb = p_begin + R opens at step p_begin + R + d0 >= p_begin, with the first term of the text -- an assignment)
   sf_dense::acc_t acc[SF_ACCS][SF_RJ][SF_VK];

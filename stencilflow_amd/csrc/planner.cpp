@@ -593,6 +593,100 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
   return out;
 }
 
+// Two radius-1 plain sums in one streaming dense launch (kernels/dense3d.h: SF_DENSE_T2, codegen.hpp: gen_dense_t2).
+// Tiles overlap by one row (and, when a row is cut, four columns) on either side; four LDS slots of (TJ + 2) x (TK + 4).
+static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>& memo, int k1, int k2, DT dt) {
+  const Program& P = pl.P;
+  const bool noj = P.n[1] == 1;
+  struct Shape {
+    int bx, by, rj;
+  };
+  // (27-point box 512^3 f32, profiles/r04_dense_t2.log: 128x8x2 9.3e5 Mcells/s, 128x4x4 8.7e5, 128x6x2 8.5-8.7e5,
+  //  128x4x3 8.4e5, 64x8x2 7.7e5, 64x4x4 7.4e5 against 8.5e5 on the compact kernel; 9-point box 4096^2: 64 lanes 1.18e6,
+  //  128 lanes 1.11e6, 256 lanes 0.97e6 against 1.0e6)
+  static const Shape shapes3d_f32[] = {{128, 8, 2}, {128, 4, 4}, {128, 6, 2}, {64, 8, 2}, {64, 4, 4}};
+  static const Shape shapes3d_f64[] = {{256, 4, 2}, {128, 8, 2}, {128, 4, 4}, {64, 8, 2}};
+  static const Shape shapes2d[] = {{64, 1, 1}, {128, 1, 1}, {256, 1, 1}};
+  // dense.t2: 0 never, 1 (default) where a tile shape wastes at most a quarter of its lanes and rows on this grid,
+  // 2 wherever a shape compiles (tests, fuzz campaigns on small grids)
+  const bool force = pl.opt.get("dense.t2", 1) >= 2;
+  StarChoice out;
+  const std::string prefix = std::string(noj ? "sf_dense2d_" : "sf_dense3d_") + short_of(dt) + "_t2";
+  const long long pin_bx = pl.opt.get(noj ? "k2.bx" : "k1.bx", 0), pin_by = pl.opt.get("k1.by", 0), pin_rj = pl.opt.get("k1.rj", 0);
+  std::vector<Shape> todo;
+  if (pin_bx && (noj || (pin_by && pin_rj))) todo.push_back({(int)pin_bx, noj ? 1 : (int)pin_by, noj ? 1 : (int)pin_rj});
+  else if (noj) todo.assign(std::begin(shapes2d), std::end(shapes2d));
+  else if (dt == DT::F64) todo.assign(std::begin(shapes3d_f64), std::end(shapes3d_f64));
+  else todo.assign(std::begin(shapes3d_f32), std::end(shapes3d_f32));
+  for (const Shape& sh : todo) {
+    StarCfg c;
+    c.T = 1;
+    c.R = 2;  // (the group reaches two planes, one per operator: what the slab halo and the chunking see)
+    c.dense = true;
+    c.dense_sum = true;
+    c.dense_stream = 1;
+    c.dense_t2 = 1;
+    c.dense_k2 = k2;
+    c.whatif = (int)pl.opt.get("debug.whatif", 0);
+    c.VK = dt == DT::F64 ? 2 : 4;
+    c.BX = sh.bx;
+    c.BY = sh.by;
+    c.RJ = noj ? 1 : sh.rj;
+    c.noj = noj;
+    c.n0g = P.n[0];
+    c.n1 = P.n[1];
+    c.n2 = P.n[2];
+    if (sh.bx * sh.by > 1024 || sh.bx * sh.by < 64 || (sh.bx * sh.by) % 64 != 0) continue;
+    const long long tk = (long long)c.BX * c.VK, tj = noj ? 1 : (long long)c.BY * c.RJ;
+    if (!noj && tj < 3) continue;
+    c.ktiled = tk != P.n[2];
+    if (c.ktiled && tk <= 8) continue;
+    c.HK = 0;
+    c.NKT = c.ktiled ? (int)((P.n[2] + (tk - 8) - 1) / (tk - 8)) : 1;
+    c.NJT = noj ? 1 : (int)((P.n[1] + (tj - 2) - 1) / (tj - 2));
+    // what the tiles cover against what the grid holds (rows recomputed by the neighbouring tile, lanes beyond the row)
+    const double used = ((double)P.n[2] / ((double)c.NKT * (double)tk)) * (noj ? 1.0 : (double)P.n[1] / ((double)c.NJT * (double)tj));
+    if (!force && !pin_bx && used < 0.75) continue;
+    const size_t lds = 4 * (size_t)(tj + (noj ? 0 : 2)) * (size_t)(tk + 4) * size_of(dt);
+    if (lds > 160 * 1024) continue;
+    c.lds_bytes = lds;
+    const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] * (double)P.n[2] *
+                               (double)size_of(dt);
+    c.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
+    StarKernelSource g;
+    try {
+      g = gen_dense_t2(P, k1, k2, c);
+    } catch (const Error&) {
+      return out;  // (not a pair this form takes)
+    }
+    const std::string sig = "dense_t2" + std::to_string(fnv1a(g.source));
+    auto it = memo.find(sig);
+    if (it != memo.end()) return it->second;
+    int ck = -1;
+    try {
+      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "dense", 0));
+    } catch (const Error& e) {
+      if (e.status != SF_ERR_COMPILE) throw;
+      report_rejected_candidate(pl, "dense (two fused)", std::to_string(sh.bx) + "x" + std::to_string(sh.by) + "x" + std::to_string(sh.rj), e);
+      continue;
+    }
+    const CompiledKernel& k = pl.kernels[ck];
+    if (pl.opt.get("debug", 0) != 0)
+      std::fprintf(stderr, "[sf_hip] dense candidate block %dx%d rows/thread %d (two plain sums fused, planes streamed): vgpr %d agpr %d spill %d scratch %d lds %d\n",
+                   sh.bx, sh.by, sh.rj, k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
+    if (!kernel_unsafe(k) && (!kernel_slow(k) || (pin_bx != 0 && pl.opt.get("allow_spills", 0) != 0))) {
+      out.ok = true;
+      out.cfg = c;
+      out.ck = ck;
+      out.alts.push_back({c, ck});
+      out.sig = sig;
+      memo[sig] = out;
+      return out;
+    }
+  }
+  return out;
+}
+
 // Extra compiler flags of the compact kernels: without the SLP vectoriser hipcc
 // keeps the 26 adds of a box stencil scalar instead of pairing them into
 // v_pk_add_f32, whose operand pairs it has to assemble with moves (option compact.slp).
@@ -681,7 +775,7 @@ static void describe_step(std::ostringstream& desc, const sf_plan& pl, const Ste
   desc << "  launch " << ck.name << ": ";
   for (int k : st.kernels) desc << P.kernels[k].name << " ";
   if (st.star)
-    desc << (st.compact ? "[compact windows " + std::to_string(st.cfg.nwin) + " T=" : st.dense ? std::string("[dense T=") : st.wide ? std::string("[wide star T=") : std::string("[star T=")) << st.cfg.T << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
+    desc << (st.compact ? "[compact windows " + std::to_string(st.cfg.nwin) + " T=" : st.dense ? std::string("[dense T=") : st.wide ? std::string("[wide star T=") : std::string("[star T=")) << ((st.dense && st.cfg.dense_t2) ? 2 : st.cfg.T) << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
          << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " chunk "
          << star_chunk_length(pl, st.cfg, dt, (int)pl.n_local) << " lds " << star_lds_bytes(st.cfg, dt)
          << " B]";
@@ -1239,7 +1333,27 @@ void build_plan(sf_plan& pl) {
       CompactShape cshape;
       bool compact = !generic_only && compact_dims && compact_eligible(P, P.kernels[k], &cshape) &&
                      (cshape.extra.empty() || whole_domain);
-      if (compact) {
+      // two plain radius-1 sums (the generator's 27-point boxes): the dense kernel's fused streaming form where the pair
+      // qualifies and a tile shape fits the grid (dense.t2, select_dense_t2); else the compact kernel
+      bool dense_pair = false;
+      if (compact && cshape.extra.empty() && pl.opt.get("dense.t2", 1) != 0 && pl.opt.get("dense", 1) != 0 && k + 1 < K &&
+          fuse >= 2 && dense_t2_eligible(P, P.kernels[k], P.kernels[k + 1]) &&
+          P.field(P.kernels[k].name).role == Role::Temp && consumers[P.kernels[k].name] == 1) {
+        StarChoice choice = select_dense_t2(pl, star_memo, k, k + 1, P.kernels[k].dt);
+        if (choice.ok) {
+          st.star = true;
+          st.dense = true;
+          st.kernels = {k, k + 1};
+          st.cfg = choice.cfg;
+          st.ck = choice.ck;
+          st.alts = choice.alts;
+          st.sig = choice.sig;
+          dense_pair = true;
+        }
+      }
+      if (dense_pair) {
+        // (planned above)
+      } else if (compact) {
         std::vector<int> group{k};
         std::set<std::string> extras;
         if (!cshape.extra.empty()) extras.insert(cshape.extra);
@@ -1446,7 +1560,8 @@ void build_plan(sf_plan& pl) {
     if (st.star) {
       if (star_lds_bytes(st.cfg, dt) > 160 * 1024)
         throw Error(SF_ERR_INVALID, "star kernel: tile needs more than 160 KiB of LDS");
-      StarKernelSource g = st.dense  ? gen_dense(P, st.kernels[0], st.cfg)
+      StarKernelSource g = (st.dense && st.cfg.dense_t2) ? gen_dense_t2(P, st.kernels[0], st.kernels[1], st.cfg)
+                           : st.dense  ? gen_dense(P, st.kernels[0], st.cfg)
                            : st.wide ? gen_wide(P, st.kernels, st.cfg)
                            : st.compact ? gen_compact(P, st.kernels, st.cfg) : gen_star(P, st.kernels, st.cfg);
       st.scalars = g.scalars;

@@ -604,6 +604,65 @@ def dense_sum_program(seed):
     return prog
 
 
+def box_sum_program(seed):
+    """Chains of 2-6 operators, each ONE left-associated sum over a random subset of {-1,0,1}^d ordered by plane (any
+    order inside a plane), optionally scaled once; constant boundaries (int or float literal), now and then an
+    operator with `shrink` or with its terms in random order in between (those end a fused pair): what the dense
+    kernel's fused streaming form takes two at a time (round 4: dense3d.h SF_DENSE_T2, plan option dense.t2)."""
+    rng = np.random.default_rng(91_000 + seed)
+    nd = 3 if rng.random() < 0.7 else 2
+    its = ["i", "j", "k"][3 - nd:]
+    if nd == 3:
+        dims = [int(rng.integers(4, 26)), int(rng.integers(3, 60)), 4 * int(rng.integers(2, 140))]
+    else:
+        dims = [int(rng.integers(5, 140)), 4 * int(rng.integers(2, 300))]
+    dtype = "float32" if rng.random() < 0.7 else "float64"
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": [],
+            "dimensions": dims, "program": {}}
+    if rng.random() < 0.4:
+        prog["inputs"]["s0"] = {"data": float(np.round(rng.uniform(-1, 1), 3)), "data_type": dtype, "input_dims": []}
+    stages = int(rng.integers(2, 7))
+    prev = "a"
+    for s in range(stages):
+        name = "b%d" % s
+        density = rng.choice([0.3, 0.7, 1.0])
+        offs = [tuple(int(x) - 1 for x in idx) for idx in np.ndindex(*([3] * nd))
+                if any(int(x) != 1 for x in idx) and rng.random() < density]
+        if not offs:
+            offs = [tuple([1] + [0] * (nd - 1))]
+        if rng.random() < 0.8:
+            offs.append((0, ) * nd)
+        offs = [offs[int(t)] for t in rng.permutation(len(offs))]
+        if rng.random() < 0.85:
+            offs.sort(key=lambda o: o[0])
+        terms = ["%s[%s]" % (prev, ",".join(it if o == 0 else "%s%+d" % (it, o) for it, o in zip(its, off))) for off in offs]
+        if len(terms) < 2:
+            terms.append("%s[%s]" % (prev, ",".join(its)))
+        expr = " + ".join(terms)
+        c = rng.random()
+        if c < 0.5:
+            expr = "%r * (%s)" % (float(np.round(rng.uniform(0.01, 0.3), 8)), expr)
+        elif c < 0.7 and "s0" in prog["inputs"]:
+            expr = "s0 * (%s)" % expr
+        kind = rng.random()
+        if kind < 0.08:
+            bc = {"type": "shrink"}
+        elif kind < 0.5:
+            bc = {"type": "constant", "value": int(rng.integers(-1, 3))}
+        else:
+            bc = {"type": "constant", "value": float(rng.choice(EXACT))}
+        prog["program"][name] = {"computation_string": "%s = %s" % (name, expr),
+                                 "boundary_conditions": {prev: bc}, "data_type": dtype}
+        prev = name
+    prog["outputs"].append(prev)
+    if rng.random() < 0.3 and stages >= 3:
+        prog["outputs"].append("b%d" % int(rng.integers(0, stages - 1)))  # an intermediate that is also an output
+    text = " ".join(k["computation_string"] for k in prog["program"].values())
+    if "s0" in prog["inputs"] and "s0 *" not in text:
+        del prog["inputs"]["s0"]
+    return prog
+
+
 # --- random chains of COMPACT operators (kernels/compact3d.h): any subset of the 27
 # offsets {-1,0,1}^3 of the previous stage, optionally a second full input field read
 # through such offsets, scalar / literal coefficients, int / float / shrink boundaries,

@@ -916,12 +916,13 @@ def test_generator_box_of_extent_two_in_the_plain_sum_form(tmp_path, dims, dtype
         assert np.array_equal(got, want, equal_nan=True)
 
 
-@pytest.mark.parametrize("args,kwargs,stages,kernel", [
-    ((2, 2, 2), {}, 4, "[wide star T=2"),
-    ((1, 1, 1), {"stencil_shape": "box"}, 4, "[compact"),
-    ((2, 2, 2), {"stencil_shape": "box"}, 2, "[dense"),
+@pytest.mark.parametrize("args,kwargs,stages,kernel,options", [
+    ((2, 2, 2), {}, 4, "[wide star T=2", None),
+    ((1, 1, 1), {"stencil_shape": "box"}, 4, "sf_dense3d_f32_t2_", None),         # round 4: two boxes per streaming dense launch
+    ((1, 1, 1), {"stencil_shape": "box"}, 4, "[compact", {"dense.t2": 0}),        # the compact kernel (rounds 2-3)
+    ((2, 2, 2), {"stencil_shape": "box"}, 2, "[dense", None),
 ])
-def test_full_size_generator_workloads_bit_exact(args, kwargs, stages, kernel):
+def test_full_size_generator_workloads_bit_exact(args, kwargs, stages, kernel, options):
     """The reference generator's radius-2 cross, 27-point box and 125-point box (bin/synthesize.py
     conventions; the first two are bench.py's `wide` and `box` workloads) at the benchmark's 512^3,
     random data: all 134 million results of a short chain against the C oracle -- the tile and
@@ -937,7 +938,7 @@ def test_full_size_generator_workloads_bit_exact(args, kwargs, stages, kernel):
         chain = sf.KernelChainGraph(programs.write_program(prog, os.path.join(tmp, "w.json")))
     out = prog["outputs"][0]
     got = np.zeros((n, n, n), np.float32)
-    with Plan(lower(chain)) as plan:
+    with Plan(lower(chain), options=options) as plan:
         assert kernel in plan.describe(), plan.describe()
         assert list(plan.output_names) == [out] and list(plan.input_names) == ["a"]
         plan.run([x], [got], 1)

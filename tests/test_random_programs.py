@@ -515,6 +515,54 @@ def test_hip_matches_oracle_on_random_compact_chains(seed, tmp_path):
             assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
 
 
+def _box_sum_case(seed, tmp_path):
+    import tests.random_programs as rp
+    prog = rp.box_sum_program(seed)
+    rng = np.random.default_rng(seed + 7)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    path = programs.write_program(prog, str(tmp_path / "p.json"))
+    return prog, ins, sf.KernelChainGraph(path)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 5])
+def test_radius_one_plain_sums_pair_up_in_the_dense_kernel(seed, tmp_path):
+    """Chains of plain sums over subsets of {-1,0,1}^d ordered by plane (tests/random_programs.py: box_sum_program): the
+    oracles agree, and with dense.t2=2 (any grid, not only those a tile shape fits well) consecutive pairs share one
+    streaming dense launch (CPU: hipRTC only); dense.t2=0 plans none."""
+    prog, ins, chain = _box_sum_case(seed, tmp_path)
+    a = npo.run_reference(prog, inputs=ins)
+    b = c_oracle.CompiledReference(prog).run(inputs=ins)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (seed, k)
+    with Plan(lower(chain), options={"dense.t2": 2}) as plan:
+        text = plan.describe()
+        pairs = [i for i, n in enumerate(plan.kernel_names()) if n.startswith("sf_dense") and "_t2_" in n and n in text]
+        assert pairs, text
+        assert all("#define SF_DENSE_T2 1" in plan.kernel_source(i) for i in pairs)
+        assert sorted(plan.output_names) == sorted(prog["outputs"])
+    with Plan(lower(chain), options={"dense.t2": 0}) as plan:
+        assert "_t2_" not in "".join(n for n in plan.kernel_names() if n.startswith("sf_dense"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(0, 10)))
+def test_hip_matches_oracle_on_fused_pairs_of_plain_sums(seed, tmp_path):
+    prog, ins, chain = _box_sum_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain), options={"dense.t2": 2}) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]]) for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [{"k1.ahead": 0}, {"k1.xbatch": 1}, {"k1.xlane": 1}])
 @pytest.mark.parametrize("seed", COMPACT_GPU_SEEDS[:4])

@@ -1,0 +1,41 @@
+import sys, os, tempfile, itertools
+sys.path.insert(0, '/root/repo')
+import numpy as np
+import stencilflow_amd as sf
+from stencilflow_amd import programs
+from stencilflow_amd.backend import Plan
+from stencilflow_amd.lowering import lower
+from oracle import numpy_oracle as npo
+bad = 0
+cases = []
+for dims in [(20, 37, 72), (9, 14, 24), (33, 50, 512), (7, 16, 516), (12, 70, 1028), (70, 136), (40, 512), (25, 1032)]:
+    for dtype in ("float32", "float64"):
+        for stages in (2, 3, 4):
+            for bc in (0, 0.5, -1):
+                cases.append((dims, dtype, stages, bc))
+rng = np.random.default_rng(5)
+for dims, dtype, stages, bc in cases:
+    if rng.random() < 0.5 and len(cases) > 60: continue
+    full = list(dims) + [0] * (3 - len(dims))
+    ext = [1 if d else 0 for d in full]
+    prog, _ = programs.synthesize(dtype, stages, 0.0, *full, *ext, stencil_shape="box")
+    for k in prog["program"].values():
+        for f in k["boundary_conditions"]:
+            k["boundary_conditions"][f] = {"type": "constant", "value": bc}
+    x = rng.uniform(-1, 1, dims).astype(dtype)
+    with tempfile.TemporaryDirectory() as tmp:
+        chain = sf.KernelChainGraph(programs.write_program(prog, os.path.join(tmp, "p.json")))
+    got = np.zeros(dims, dtype)
+    with Plan(lower(chain), options={"dense.t2": 2}) as plan:
+        d = plan.describe()
+        used = "_t2_" in d
+        plan.run([x], [got], 1)
+    want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
+    ok = np.array_equal(got, want, equal_nan=True)
+    if not ok:
+        bad += 1
+        diff = np.argwhere(got != want)
+        print("MISMATCH", dims, dtype, stages, bc, "t2" if used else "no-t2", len(diff), "points; first", diff[:3].tolist(), d.split("\n")[1][:160])
+    else:
+        print("ok", dims, dtype, stages, bc, "t2" if used else "no-t2")
+print("failures", bad)

@@ -109,6 +109,8 @@ def updates_per_iteration(name, mac):
         unroll = 5
     elif name.startswith("sf_dense"):
         unroll, t = (5 if mac.get("SF_DENSE_STREAM", 0) else 6), 1  # (the streaming form rotates five accumulator sets)
+        if mac.get("SF_DENSE_T2", 0):
+            unroll, t = 3, 2  # (two fused operators, three accumulator sets each)
         vk = mac.get("SF_VK", 4)
     else:
         return None
@@ -158,7 +160,8 @@ FAMILIES = {
     "star (C3 jacobi3d 512^3 f32)": (lambda: programs.jacobi3d((512, 512, 512), 8), None),
     "star 2-D (C2 jacobi2d 4096^2 f32)": (lambda: programs.jacobi2d((4096, 4096), 8), None),
     "star f64 (C5 chain 512^3)": (lambda: programs.diffusion_advection_laplacian((512, 512, 512)), None),
-    "compact (27-point box 512^3 f32)": (lambda: programs.synthesize("float32", 4, 0.0, 512, 512, 512, 1, 1, 1, stencil_shape="box")[0], None),
+    "dense, two fused (27-point box 512^3 f32)": (lambda: programs.synthesize("float32", 4, 0.0, 512, 512, 512, 1, 1, 1, stencil_shape="box")[0], None),
+    "compact (27-point box 512^3 f32, dense.t2=0)": (lambda: programs.synthesize("float32", 4, 0.0, 512, 512, 512, 1, 1, 1, stencil_shape="box")[0], "dense.t2=0"),
     "wide star (radius-2 cross 512^3 f32)": (lambda: programs.synthesize("float32", 4, 0.0, 512, 512, 512, 2, 2, 2)[0], None),
     "dense (125-point box 512^3 f32)": (lambda: programs.synthesize("float32", 2, 0.0, 512, 512, 512, 2, 2, 2, stencil_shape="box")[0], None),
 }

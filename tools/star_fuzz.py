@@ -7,6 +7,8 @@ must agree exactly.  Prints one JSON line per failing program.
 usage: star_fuzz.py [--seeds 300] [--first 0] [--options "k1.rev=1"] [--generator star|wide]
 (--generator wide: chains of radius-2 stars, kernels/wstar3d.h; fusion depth 1-3;
  --generator dense: operators with dense radius-2 neighbourhoods, kernels/dense3d.h;
+ --generator box_sum: chains of plain sums over subsets of {-1,0,1}^d ordered by plane (round 4: the dense kernel's fused
+   streaming form, two operators per launch, plan option dense.t2);
  --generator compact: the 27 offsets of radius 1, kernels/compact3d.h (tools/compact_fuzz.py is its own tool);
  --generator dag: forks, joins and intermediates with several readers, kernels/star3d.h's DAG groups (round 4;
    --options "dag.windows=4" lets 3-D programs form them too);
@@ -28,7 +30,7 @@ from stencilflow_amd.backend import Plan  # noqa: E402
 from stencilflow_amd.lowering import lower  # noqa: E402
 from oracle import numpy_oracle as npo  # noqa: E402
 
-from tests.random_programs import (compact_program, dag_program, dense_program, dense_sum_program, star_program,  # noqa: E402
+from tests.random_programs import (box_sum_program, compact_program, dag_program, dense_program, dense_sum_program, star_program,  # noqa: E402
                                    wide_program, with_copy_boundaries)
 
 
@@ -38,14 +40,14 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--options", default="")
     ap.add_argument("--dump", type=int, default=-1, help="print the program of one seed and exit")
-    ap.add_argument("--generator", choices=["star", "wide", "dense", "dense_sum", "compact", "copy", "dag"], default="star")
+    ap.add_argument("--generator", choices=["star", "wide", "dense", "dense_sum", "box_sum", "compact", "copy", "dag"], default="star")
     ap.add_argument("--seconds", type=float, default=0, help="stop after this many seconds (0: run all seeds)")
     ap.add_argument("--copy", action="store_true",
                     help="turn a share of the boundary conditions into `copy`; reference: the generic kernel")
     args = ap.parse_args()
     if args.generator == "copy":
         args.generator, args.copy = "star", True
-    plain = {"wide": wide_program, "dense": dense_program, "dense_sum": dense_sum_program, "compact": compact_program,
+    plain = {"wide": wide_program, "dense": dense_program, "dense_sum": dense_sum_program, "box_sum": box_sum_program, "compact": compact_program,
              "dag": dag_program}.get(args.generator, star_program)
     make = (lambda seed: with_copy_boundaries(plain(seed), seed)) if args.copy else plain
     if args.dump >= 0:
