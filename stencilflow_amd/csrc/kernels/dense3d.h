@@ -64,7 +64,11 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_DENSE_T2 0
 #endif
 #if SF_DENSE_STREAM
-#define SF_SLOTS (SF_DENSE_T2 ? 4 : 2)  // LDS: the plane being read and the one being written (T2: of either ring)
+#ifndef SF_T2_ONE_IN
+#define SF_T2_ONE_IN 0  // fused form: ONE slot for the input planes (a second barrier per step) instead of two
+#endif
+#define SF_MID0 (SF_T2_ONE_IN ? 1 : 2)  // first slot of the ring between the two operators
+#define SF_SLOTS (SF_DENSE_T2 ? SF_MID0 + 2 : 2)  // LDS: the plane being read and the one being written (T2: of either ring)
 #ifndef SF_ACCS
 #define SF_ACCS 5   // accumulator sets: output planes p - R .. p + R are open while plane p is read
 #endif
@@ -269,7 +273,8 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_pair (&regs)[SF_NLOADS]
                                            sf_dense2::acc_t (&acc2)[SF_ACCS][SF_RJ][SF_VK]) {
   // (requesting planes TWO steps ahead -- two register sets, the loop unrolled by six -- was measured: slower,
   //  profiles/r04_dense_t2.log)
-  sf_t* in_slot = lds + s0 * SF_SLOT_ELEMS;
+  sf_t* in_slot = lds + (SF_T2_ONE_IN ? 0 : s0) * SF_SLOT_ELEMS;
+  if constexpr (SF_T2_ONE_IN != 0) __syncthreads();  // every wave has read the plane the slot held
   if constexpr (!(SF_WHATIF & 2)) {
 #pragma unroll
     for (int n = 0; n < SF_NLOADS; ++n)  // (only the last round of pairs can run out of pairs)
@@ -290,7 +295,7 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_pair (&regs)[SF_NLOADS]
   sf_t mid[SF_RJ][SF_VK];
   sf_dense::finish(sc, acc1[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], mid);
   const int mid_par = (s0 + 2 - SFD_DLAST) & 1;
-  sf_t* mid_w = lds + (2 + mid_par) * SF_SLOT_ELEMS + cx.tb + SF_RJH * SF_LS + SF_R;
+  sf_t* mid_w = lds + (SF_MID0 + mid_par) * SF_SLOT_ELEMS + cx.tb + SF_RJH * SF_LS + SF_R;
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     // outside the global domain operator 2 reads ITS boundary constant
@@ -305,7 +310,7 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_pair (&regs)[SF_NLOADS]
   }
   // ---- operator 2 on the plane published a step ago
   constexpr int PH2 = (PH - SFD_DLAST - 1 + 2 * SF_ACCS) % SF_ACCS;
-  const sf_t* mid_r = lds + (2 + (mid_par ^ 1)) * SF_SLOT_ELEMS + cx.tb;
+  const sf_t* mid_r = lds + (SF_MID0 + (mid_par ^ 1)) * SF_SLOT_ELEMS + cx.tb;
   sf_dense2::template accumulate<PH2>(mid_r, acc2);
 #pragma unroll
   for (int a = 0; a < SF_ACCS; ++a)
@@ -412,7 +417,7 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
 #if SF_DENSE_T2
   // ring 1 starts out as the second operator's boundary constant: its halo rows and columns are never written again
   // (they are right where the tile touches the edge of the domain; elsewhere the results that read them are not stored)
-  for (int i = tid; i < 2 * SF_SLOT_ELEMS; i += SF_THREADS) lds[2 * SF_SLOT_ELEMS + i] = sf_dense2::bc();
+  for (int i = tid; i < 2 * SF_SLOT_ELEMS; i += SF_THREADS) lds[SF_MID0 * SF_SLOT_ELEMS + i] = sf_dense2::bc();
   sf_dense::acc_t acc1[SF_ACCS][SF_RJ][SF_VK];
   sf_dense2::acc_t acc2[SF_ACCS][SF_RJ][SF_VK];
 #pragma unroll

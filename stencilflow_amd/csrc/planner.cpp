@@ -604,7 +604,9 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
   // (27-point box 512^3 f32, profiles/r04_dense_t2.log: 128x8x2 9.3e5 Mcells/s, 128x4x4 8.7e5, 128x6x2 8.5-8.7e5,
   //  128x4x3 8.4e5, 64x8x2 7.7e5, 64x4x4 7.4e5 against 8.5e5 on the compact kernel; 9-point box 4096^2: 64 lanes 1.18e6,
   //  128 lanes 1.11e6, 256 lanes 0.97e6 against 1.0e6)
-  static const Shape shapes3d_f32[] = {{128, 8, 2}, {128, 4, 4}, {128, 6, 2}, {64, 8, 2}, {64, 4, 4}};
+  //  with ONE slot for the input planes (a second barrier per step, 124 KB) 18-row tiles fit: 128x6x3, 32 row tiles x 8
+  //  chunks = one block per unit: 9.7-9.8e5)
+  static const Shape shapes3d_f32[] = {{128, 6, 3}, {128, 8, 2}, {128, 4, 4}, {128, 6, 2}, {64, 8, 2}, {64, 4, 4}};
   static const Shape shapes3d_f64[] = {{256, 4, 2}, {128, 8, 2}, {128, 4, 4}, {64, 8, 2}};
   static const Shape shapes2d[] = {{64, 1, 1}, {128, 1, 1}, {256, 1, 1}};
   // dense.t2: 0 never, 1 (default) where a tile shape wastes at most a quarter of its lanes and rows on this grid,
@@ -647,7 +649,10 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     // what the tiles cover against what the grid holds (rows recomputed by the neighbouring tile, lanes beyond the row)
     const double used = ((double)P.n[2] / ((double)c.NKT * (double)tk)) * (noj ? 1.0 : (double)P.n[1] / ((double)c.NJT * (double)tj));
     if (!force && !pin_bx && used < 0.75) continue;
-    const size_t lds = 4 * (size_t)(tj + (noj ? 0 : 2)) * (size_t)(tk + 4) * size_of(dt);
+    // four LDS slots; where they do not fit, three (one slot for the input planes, a second barrier per step)
+    const size_t slot = (size_t)(tj + (noj ? 0 : 2)) * (size_t)(tk + 4) * size_of(dt);
+    c.dense_one_in = (int)pl.opt.get("dense.onein", 4 * slot > 160 * 1024 ? 1 : 0);
+    const size_t lds = (c.dense_one_in ? 3 : 4) * slot;
     if (lds > 160 * 1024) continue;
     c.lds_bytes = lds;
     const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] * (double)P.n[2] *
