@@ -306,7 +306,22 @@ static std::atomic<long> g_cache_hits{0}, g_cache_misses{0}, g_cache_recompiles{
 
 // Code object for `source` (+ flags) through the process level and the disk level of the
 // cache, compiled when neither has it.  The kernel belongs to no plan yet.
-CompiledKernel compile_cached(const std::string& prefix, const std::string& source, const std::string& flags) {
+// An operator with hundreds of terms (the generator's 343-point box) is one left-associated sum, 342 parentheses deep,
+// where the text is evaluated as it stands (generic kernel, self-check references): clang stops at 256 unless told
+// otherwise.  Only sources that need it get the flag (the others keep their names and cache keys).
+std::string with_bracket_depth(const std::string& source, const std::string& flags) {
+  if (flags.find("-fbracket-depth") != std::string::npos) return flags;
+  int depth = 0, deepest = 0;
+  for (const char ch : source) {
+    if (ch == '(') deepest = std::max(deepest, ++depth);
+    else if (ch == ')') --depth;
+    else if (ch == '\n') depth = 0;
+  }
+  return deepest > 200 ? flags + (flags.empty() ? "" : " ") + "-fbracket-depth=4096" : flags;
+}
+
+CompiledKernel compile_cached(const std::string& prefix, const std::string& source, const std::string& flags_in) {
+  const std::string flags = with_bracket_depth(source, flags_in);
   const std::string keyed = flags.empty() ? source : flags + "\n" + source;
   CompiledKernel k;
   k.name = prefix + "_" + hex8(fnv1a(keyed));
@@ -365,6 +380,7 @@ int intern_kernel(sf_plan& pl, const std::string& prefix, const std::string& sou
       flags += (flags.empty() ? "" : " ") + std::string(extra);
       env_flags = true;
     }
+  flags = with_bracket_depth(source, flags);
   // (kernels without extra flags keep the names and cache keys they always had)
   const std::string keyed = flags.empty() ? source : flags + "\n" + source;
   auto it = pl.kernel_by_source.find(keyed);

@@ -45,7 +45,10 @@ typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 typedef sf_t sf_pair __attribute__((ext_vector_type(2)));
 #define SF_CE (16 / (int)sizeof(sf_t))  // elements of a 16-byte chunk
 typedef sf_t sf_chunk __attribute__((ext_vector_type(16 / sizeof(sf_t))));
-#define SF_SEG (SF_VK + 2 * SF_R)  // a row segment: the thread's VK columns and R more on either side
+#ifndef SF_RC
+#define SF_RC SF_R  // halo COLUMNS of an LDS row: R, rounded up to an even number (radius 3: four) -- pairs and chunks stay aligned
+#endif
+#define SF_SEG (SF_VK + 2 * SF_RC)  // a row segment: the thread's VK columns and RC more on either side
 typedef unsigned sf_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 
@@ -70,7 +73,7 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_MID0 (SF_T2_ONE_IN ? 1 : 2)  // first slot of the ring between the two operators
 #define SF_SLOTS (SF_DENSE_T2 ? SF_MID0 + 2 : 2)  // LDS: the plane being read and the one being written (T2: of either ring)
 #ifndef SF_ACCS
-#define SF_ACCS 5   // accumulator sets: output planes p - R .. p + R are open while plane p is read
+#define SF_ACCS (2 * SF_R + 1)  // accumulator sets: output planes p - R .. p + R are open while plane p is read
 #endif
 #else
 #define SF_SLOTS 6
@@ -96,7 +99,7 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #endif
 #define SF_TK (SF_BX * SF_VK)
 #define SF_LROWS (SF_TJ + 2 * SF_RJH)
-#define SF_LS (SF_TK + 2 * SF_R)  // row stride of a slot (elements); TK is a multiple of 4, R <= 2: pairs stay 8-byte aligned
+#define SF_LS (SF_TK + 2 * SF_RC)  // row stride of a slot (elements); TK is a multiple of 4, RC even: pairs stay 8-byte aligned
 #define SF_SLOT_ELEMS (SF_LROWS * SF_LS)
 #define SF_PAIRS_PER_ROW (SF_LS / 2)
 #define SF_PAIRS (SF_LROWS * SF_PAIRS_PER_ROW)
@@ -295,7 +298,7 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_pair (&regs)[SF_NLOADS]
   sf_t mid[SF_RJ][SF_VK];
   sf_dense::finish(sc, acc1[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], mid);
   const int mid_par = (s0 + 2 - SFD_DLAST) & 1;
-  sf_t* mid_w = lds + (SF_MID0 + mid_par) * SF_SLOT_ELEMS + cx.tb + SF_RJH * SF_LS + SF_R;
+  sf_t* mid_w = lds + (SF_MID0 + mid_par) * SF_SLOT_ELEMS + cx.tb + SF_RJH * SF_LS + SF_RC;
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     // outside the global domain operator 2 reads ITS boundary constant
@@ -376,7 +379,7 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   for (int n = 0; n < SF_NLOADS; ++n) {
     const int pair = tid + n * SF_THREADS;
     const int row = pair / SF_PAIRS_PER_ROW, col = (pair - row * SF_PAIRS_PER_ROW) * 2;
-    const int j = tj0 - SF_RJH + row, k = tk0 - SF_R + col;
+    const int j = tj0 - SF_RJH + row, k = tk0 - SF_RC + col;
     const bool mine = pair < SF_PAIRS;
     // (N2 is a multiple of 4 and R even or the tile origin a multiple of 4: a pair is inside or outside as a whole
     //  for R = 2; for R = 1 the pair straddles the edge -- R is always 2 here, codegen enforces it)
@@ -448,12 +451,16 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
 #pragma unroll
       for (int v = 0; v < SF_VK; ++v) acc[a][r][v] = (sf_dense::acc_t)0;
   for (int p = p_begin; p < p_end; p += SF_ACCS) {
-    const int s0 = (p - p_begin) & 1;  // five steps per trip: the slot parity alternates from trip to trip
+    const int s0 = (p - p_begin) & 1;  // an odd number of steps per trip: the slot parity alternates from trip to trip
     sf_step_stream<0>(lds, regs, out, sc, cx, p, p_end, s0, acc);
     sf_step_stream<1>(lds, regs, out, sc, cx, p + 1, p_end, s0 ^ 1, acc);
     sf_step_stream<2>(lds, regs, out, sc, cx, p + 2, p_end, s0, acc);
     sf_step_stream<3>(lds, regs, out, sc, cx, p + 3, p_end, s0 ^ 1, acc);
     sf_step_stream<4>(lds, regs, out, sc, cx, p + 4, p_end, s0, acc);
+#if SF_ACCS == 7
+    sf_step_stream<5>(lds, regs, out, sc, cx, p + 5, p_end, s0 ^ 1, acc);
+    sf_step_stream<6>(lds, regs, out, sc, cx, p + 6, p_end, s0, acc);
+#endif
   }
 #else
   for (int p = p_begin; p < p_end; p += SF_SLOTS) {

@@ -478,7 +478,7 @@ static StarChoice select_wide(sf_plan& pl, std::map<std::string, StarChoice>& me
 
 // A dense-neighbourhood operator (kernels/dense3d.h): a few block shapes in order of preference -- the
 // tile is staged in LDS, so what matters is the halo it re-reads and two blocks per unit (LDS, waves).
-static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& memo, int kidx, DT dt) {
+static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& memo, int kidx, DT dt, int radius = 2) {
   const Program& P = pl.P;
   const bool noj = P.n[1] == 1;
   struct Shape {
@@ -513,7 +513,9 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
   // there, the accumulators of five open output planes being the only state
   // (125-point box 512^3, profiles/r04_dense_stream.log: 64x2x4 0.397 ms per operator, 32x4x4 0.39, 64x2x2 0.41,
   //  64x4x2 0.43, 64x4x4 0.47, against 0.44 for the form that reads every plane five times)
-  static const Shape streams3d[] = {{64, 2, 4}, {32, 4, 4}, {64, 2, 2}, {64, 4, 2}};
+  // (one row per thread last: operators whose sums are typed double -- a float boundary literal -- hold two registers per
+  //  accumulator, seven sets of them at radius 3)
+  static const Shape streams3d[] = {{64, 2, 4}, {32, 4, 4}, {64, 2, 2}, {64, 4, 2}, {64, 4, 1}, {64, 8, 1}};
   if (pl.opt.get("dense.sum", 1) != 0 && pl.opt.get("dense.stream", 1) != 0 && dense_sum_form(P, P.kernels[kidx], nullptr)) {
     if (pin_bx && (noj || (pin_by && pin_rj))) variants.push_back({todo[0], false, true, true});
     else if (noj) for (const Shape& sh : shapes2d) variants.push_back({sh, false, true, true});
@@ -526,11 +528,14 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
   }
   for (const Shape& sh : todo) variants.push_back({sh, false, false});
   for (size_t i = 0; i < todo.size() && i < 2; ++i) variants.push_back({todo[i], true, false});
+  // radius 3 (the generator's extent 3): the streaming form or nothing
+  if (radius == 3)
+    variants.erase(std::remove_if(variants.begin(), variants.end(), [](const Variant& v) { return !v.stream; }), variants.end());
   for (const auto& variant : variants) {
     const Shape& sh = variant.first;
     StarCfg c;
     c.T = 1;
-    c.R = 2;
+    c.R = radius;
     c.dense = true;
     c.dense_scalar = variant.second;
     c.dense_sum = variant.sum;
@@ -552,7 +557,8 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     c.HK = 0;
     c.NKT = (int)((P.n[2] + tk - 1) / tk);
     c.NJT = noj ? 1 : (int)((P.n[1] + tj - 1) / tj);
-    const size_t lds = (variant.stream ? 2 : 6) * (size_t)(tj + (noj ? 0 : 4)) * (size_t)(tk + 4) * size_of(dt);
+    const int rc = (radius + 1) / 2 * 2;  // halo columns of an LDS row (dense3d.h: SF_RC)
+    const size_t lds = (variant.stream ? 2 : 6) * (size_t)(tj + (noj ? 0 : 2 * radius)) * (size_t)(tk + 2 * rc) * size_of(dt);
     if (lds > 160 * 1024) continue;
     c.lds_bytes = lds;
     const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] * (double)P.n[2] *
@@ -1415,9 +1421,10 @@ void build_plan(sf_plan& pl) {
         st.kernels.push_back(k);
       }
       // dense neighbourhoods of radius 2 (the generator's box of extent 2): one operator per launch, LDS tiles
+      const bool dense_r3 = pl.opt.get("dense.r3", 1) != 0 && dense_r3_eligible(P, P.kernels[k]);
       if (!st.star && st.kernels.size() == 1 && !generic_only && star_ok_dims && pl.opt.get("dense", 1) != 0 &&
-          dense_eligible(P, P.kernels[k])) {
-        StarChoice choice = select_dense(pl, star_memo, k, P.kernels[k].dt);
+          (dense_eligible(P, P.kernels[k]) || dense_r3)) {
+        StarChoice choice = select_dense(pl, star_memo, k, P.kernels[k].dt, dense_r3 ? 3 : 2);
         if (choice.ok) {
           st.star = true;
           st.dense = true;

@@ -570,6 +570,14 @@ def dense_sum_program(seed):
         offs = [tuple(int(x) - 2 for x in idx) for idx in np.ndindex(*([5] * nd))
                 if any(int(x) != 2 for x in idx) and rng.random() < density]
         far = tuple(int(rng.choice([-2, 2])) if d < 2 else int(rng.choice([-2, -1, 1, 2])) for d in range(nd))
+        # (round 4; its own generator again) one operator in four reaches THREE points: subsets of {-3..3}^d -- ordered
+        # by plane the dense kernel's streaming form with seven open planes, otherwise the generic kernel
+        r3 = np.random.default_rng(78_000 + 11 * seed + s)
+        if r3.random() < 0.25:
+            dens3 = float(r3.choice([0.03, 0.15, 0.5]))
+            offs = [tuple(int(x) - 3 for x in idx) for idx in np.ndindex(*([7] * nd))
+                    if any(int(x) != 3 for x in idx) and r3.random() < dens3]
+            far = tuple(int(r3.choice([-3, 3])) for _ in range(nd))
         if far not in offs:
             offs.append(far)
         if rng.random() < 0.7:

@@ -394,3 +394,21 @@ def test_a_short_star_chain_joins_the_compact_group_that_follows(tmp_path):
     with backend.Plan(sfir, options={"compact.prefer": 0}) as plan:
         text = plan.describe()
         assert text.count("\n  launch ") == 5 and "[star T=1" in text, text
+
+
+def test_radius_three_boxes_take_the_streaming_dense_kernel(tmp_path):
+    """The generator's box of extent 3 (343 points): a plain sum ordered by plane -- the dense kernel's streaming form with
+    seven open output planes (round 4); before, the operator did not even compile on the generic kernel (342 nested
+    parentheses; sources that deep now get -fbracket-depth).  A radius-3 cross lists its planes out of order and stays on
+    the generic kernel."""
+    box, _ = programs.synthesize("float32", 2, 0.0, 48, 48, 64, 3, 3, 3, stencil_shape="box")
+    sfir = lower(sf.KernelChainGraph(programs.write_program(box, str(tmp_path / "box.json"))))
+    with backend.Plan(sfir) as plan:
+        assert "[dense" in plan.describe() and "#define SF_ACCS 7" in plan.kernel_source(0), plan.describe()
+    with backend.Plan(sfir, options={"dense.r3": 0}) as plan:
+        assert "[point]" in plan.describe()
+        assert "-fbracket-depth" in plan.kernel_object(0)[1]
+    cross, _ = programs.synthesize("float32", 2, 0.0, 48, 48, 64, 3, 3, 3)
+    sfir = lower(sf.KernelChainGraph(programs.write_program(cross, str(tmp_path / "cross.json"))))
+    with backend.Plan(sfir) as plan:
+        assert "[point]" in plan.describe()
