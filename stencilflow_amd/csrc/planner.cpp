@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <set>
 
 namespace sf {
@@ -27,8 +28,12 @@ static void report_rejected_candidate(const sf_plan& pl, const char* family, con
   if (pl.opt.get("debug", 0) != 0)
     std::fprintf(stderr, "[sf_hip] %s candidate %s rejected by the compiler: %.400s\n", family, what.c_str(), msg.c_str());
   if (resources) return;
+  static std::mutex told_mutex;  // (plans are created from several threads)
   static std::set<std::string> told;
-  if (!told.insert(family).second) return;
+  {
+    std::lock_guard<std::mutex> lock(told_mutex);
+    if (!told.insert(family).second) return;
+  }
   const size_t at = msg.find("error:");
   std::fprintf(stderr, "[sf_hip] warning: a %s kernel failed to COMPILE and the planner falls back to other kernels: %.300s\n",
                family, at == std::string::npos ? msg.c_str() : msg.c_str() + at);
