@@ -1,5 +1,14 @@
-import sys, os, tempfile, itertools
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""GPU: the dense kernel's fused form (two radius-1 plain sums per launch, dense3d.h SF_DENSE_T2) on the generator's boxes
+of extent 1 -- 27 points, 9 in 2-D -- over grids that fit a tile, need several, cut rows into k-tiles or leave most of a
+tile empty, float32 / float64, 2-4 operators (an odd one out stays on the compact kernel), int and float boundary
+literals; every result against the NumPy oracle.  dense.t2=2 forces the form onto grids it would not choose.
+usage (from the repository root, on a GPU box): python tools/dense_t2_check.py"""
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import stencilflow_amd as sf
 from stencilflow_amd import programs
