@@ -859,7 +859,7 @@ def main():
             # applications of the fused chain back to back -- a lone 0.4-ms launch between two
             # synchronisations runs 20 % slower than the same launch in a stream of launches)
             # ... and two workloads of the reference's generator (bin/synthesize.py) that exercise the other
-            # fused kernel families: the 27-point box chain (compact3d.h) and the radius-2 cross chain
+            # fused kernel families: the 27-point box chain (dense3d.h, two per launch since round 4; compact3d.h before) and the radius-2 cross chain
             # (wstar3d.h), 16 operators each
             others = []
             # (>= 10 timed steps each and the median beside the mean: SURVEY.md 8d; the whole set costs about
