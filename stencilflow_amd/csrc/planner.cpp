@@ -618,7 +618,9 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
   //  with ONE slot for the input planes (a second barrier per step, 124 KB) 18-row tiles fit: 128x6x3, 32 row tiles x 8
   //  chunks = one block per unit: 9.7-9.8e5)
   static const Shape shapes3d_f32[] = {{128, 6, 3}, {128, 8, 2}, {128, 4, 4}, {128, 6, 2}, {64, 8, 2}, {64, 4, 4}};
-  static const Shape shapes3d_f64[] = {{256, 4, 2}, {128, 8, 2}, {128, 4, 4}, {64, 8, 2}};
+  // (float64, 27-point box 512^3, profiles/r04_box_f64.log: 256x3x3 4.0e5 Mcells/s, 256x4x2 3.8e5, against 3.2e5 on the compact
+  //  kernel two deep and 1.6e5 three deep)
+  static const Shape shapes3d_f64[] = {{256, 3, 3}, {256, 4, 2}, {128, 8, 2}, {128, 4, 4}, {64, 8, 2}};
   static const Shape shapes2d[] = {{64, 1, 1}, {128, 1, 1}, {256, 1, 1}};
   // dense.t2: 0 never, 1 (default) where a tile shape wastes at most a quarter of its lanes and rows on this grid,
   // 2 wherever a shape compiles (tests, fuzz campaigns on small grids)
@@ -1159,7 +1161,8 @@ void build_plan(sf_plan& pl) {
     std::set<std::string> extras;
     if (!cs.extra.empty()) extras.insert(cs.extra);
     int len = 1;
-    while (len < fuse && k + len < K) {
+    const int cfuse = (P.kernels[k].dt == DT::F64 && P.nd == 3 && !pl.opt.kv.count("fuse")) ? std::min(fuse, 2) : fuse;
+    while (len < cfuse && k + len < K) {
       const Kernel& kc = P.kernels[k + len - 1];
       CompactShape ns;
       if (!compact_eligible(P, P.kernels[k + len], &ns, kc.name)) break;
@@ -1382,7 +1385,10 @@ void build_plan(sf_plan& pl) {
                  compact_lateral(sh.xneed, 2);
         };
         bool group_diagonal = diagonal(cshape);
-        while ((int)group.size() < fuse && k + (int)group.size() < K) {
+        // (float64 groups two deep unless fuse= says otherwise: the 27-point box 512^3 runs 3.2e5 Mcells/s two deep and
+        //  1.6e5 three deep -- 247 registers and 9-row tiles --, profiles/r04_box_f64.log; the default of 3 is the star kernel's)
+        const int cfuse = (P.kernels[k].dt == DT::F64 && P.nd == 3 && !pl.opt.kv.count("fuse")) ? std::min(fuse, 2) : fuse;
+        while ((int)group.size() < cfuse && k + (int)group.size() < K) {
           const int cur = group.back(), nxt = cur + 1;
           const Kernel& kc = P.kernels[cur];
           CompactShape nshape;

@@ -412,3 +412,15 @@ def test_radius_three_boxes_take_the_streaming_dense_kernel(tmp_path):
     sfir = lower(sf.KernelChainGraph(programs.write_program(cross, str(tmp_path / "cross.json"))))
     with backend.Plan(sfir) as plan:
         assert "[point]" in plan.describe()
+
+
+def test_float64_boxes_take_the_fused_dense_form_or_compact_groups_two_deep(tmp_path):
+    """The 27-point box in float64 at 512^3 (profiles/r04_box_f64.log): the dense kernel's fused form (256x3 threads x 3
+    rows) -- 4.1e5 Mcells/s against 3.2e5 on the compact kernel two deep and 1.6e5 three deep, which the float64 default
+    of fuse = 3 (the star kernel's) used to pick."""
+    box, _ = programs.synthesize("float64", 4, 0.0, 512, 512, 512, 1, 1, 1, stencil_shape="box")
+    sfir = lower(sf.KernelChainGraph(programs.write_program(box, str(tmp_path / "box.json"))))
+    with backend.Plan(sfir) as plan:
+        assert "sf_dense3d_f64_t2_" in plan.describe() and "block 256x3 rows/thread 3" in plan.describe(), plan.describe()
+    with backend.Plan(sfir, options={"dense.t2": 0}) as plan:
+        assert "[compact windows 2 T=2" in plan.describe(), plan.describe()
