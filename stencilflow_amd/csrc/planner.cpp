@@ -1417,6 +1417,26 @@ void build_plan(sf_plan& pl) {
           if (choice.ok) break;
           group.pop_back();
         }
+        // A group whose only clean tile recomputes more than it keeps is worse than its operators one by one: boxes
+        // with a second spatial field two deep fit 64x4 threads x 3 rows only -- 8 of 12 rows and 512 of 768 columns
+        // useful; the next shape 5 of 9 rows -- and run 2.2-2.8e5 Mcells/s where one operator per launch runs 4.3e5
+        // (profiles/r04_box_extra.log).
+        if (choice.ok && group.size() > 1 && !pl.opt.kv.count("fuse")) {
+          auto kept = [&](const StarCfg& c) {  // share of a tile's rows and lanes whose results are stored
+            const double rows = c.noj ? 1.0 : (double)(c.BY * c.RJ - 2 * c.T) / (double)(c.BY * c.RJ);
+            const double cols = (double)P.n[2] / ((double)std::max(1, c.NKT) * (double)c.BX * (double)c.VK);
+            return rows * cols;
+          };
+          if (kept(choice.cfg) < 0.6) {
+            // (against what ONE operator's tile keeps on this grid: a small grid wastes lanes at any depth)
+            std::vector<int> one{k};
+            StarChoice single = select_compact(pl, star_memo, one, P.kernels[k].dt);
+            if (single.ok && kept(choice.cfg) < 0.65 * kept(single.cfg)) {
+              group = one;
+              choice = single;
+            }
+          }
+        }
         if (choice.ok) {
           st.star = true;
           st.compact = true;

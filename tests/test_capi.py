@@ -424,3 +424,17 @@ def test_float64_boxes_take_the_fused_dense_form_or_compact_groups_two_deep(tmp_
         assert "sf_dense3d_f64_t2_" in plan.describe() and "block 256x3 rows/thread 3" in plan.describe(), plan.describe()
     with backend.Plan(sfir, options={"dense.t2": 0}) as plan:
         assert "[compact windows 2 T=2" in plan.describe(), plan.describe()
+
+
+def test_a_compact_group_that_mostly_recomputes_is_planned_one_operator_at_a_time(tmp_path):
+    """27-point boxes with a second spatial field in every other operator: two deep the only clean tiles keep 5 of 9 or 8 of
+    12 rows (and two thirds of the columns) -- 2.2-2.8e5 Mcells/s against 4.3e5 with one operator per launch
+    (profiles/r04_box_extra.log).  The planner drops a group whose tile keeps less than 0.6 of what it computes and less than 0.65 of what one operator's tile keeps; an
+    explicit fuse= is followed as given."""
+    prog, _ = programs.synthesize("float32", 4, 0.5, 512, 512, 512, 1, 1, 1, stencil_shape="box")
+    sfir = lower(sf.KernelChainGraph(programs.write_program(prog, str(tmp_path / "p.json"))))
+    with backend.Plan(sfir) as plan:
+        text = plan.describe()
+        assert text.count("\n  launch ") == 4 and "T=2" not in text, text
+    with backend.Plan(sfir, options={"fuse": 2}) as plan:
+        assert "[compact windows 3 T=2" in plan.describe(), plan.describe()
