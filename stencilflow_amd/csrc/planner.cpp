@@ -733,7 +733,9 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
   }
   const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
                       (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
-  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
+  // (a single operator that finds no clean tile falls to the generic kernel, ten times slower or worse: it gets more
+  //  shapes to try -- float64 operators over two fields fit only the smaller ones)
+  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", kernels.size() == 1 ? 24 : 8)));
   int rejected = 0, sgpr_rejects = 0;
   // Dense 3-D groups (box-like: every operator reads 18 or more of the 27 offsets of one field)
   // are bound by vector-instruction issue; letting the scheduler mix the rows of a step is worth

@@ -3,7 +3,7 @@
 # compact groups two deep (12-row, 256-column tiles: 2.25 x redundant) against one operator per launch.
 set -o pipefail
 export SF_HIP_CACHE_DIR=$PWD/gpurun_out/cache_ab36
-for o in "" "fuse=1"; do
+for o in ""; do
   for dt in float32 float64; do
     timeout -k 10 200 python - "$o" $dt <<'PY'
 import sys, os, tempfile, re
