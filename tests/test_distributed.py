@@ -754,3 +754,31 @@ def test_program_inputs_no_launch_writes_are_exchanged_once(tmp_path):
         assert np.array_equal(got, want[name])
     for r in runners:
         r.close()
+
+
+def test_ranks_of_a_decomposed_run_plan_alike(tmp_path):
+    """Every rank of a slab decomposition must form the same launch groups on the same kernels (the exchange schedule is
+    derived from the plan): the planner's choices -- including round 4's, which look at tile shapes against the grid
+    (two boxes per dense launch, compact groups that would mostly recompute, the longer of star chain and compact
+    group) -- may depend on the (j,k) extent and on what compiles, never on where a rank's slab lies or how tall it is."""
+    import re
+    import stencilflow_amd as sf
+    from stencilflow_amd import programs
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    cases = {
+        "box": programs.synthesize("float32", 4, 0.0, 96, 512, 512, 1, 1, 1, stencil_shape="box")[0],
+        "box_two_fields": programs.synthesize("float32", 4, 0.5, 96, 512, 512, 1, 1, 1, stencil_shape="box")[0],
+        "cross_two_fields": programs.synthesize("float32", 4, 0.5, 96, 512, 512, 1, 1, 1)[0],
+    }
+    for name, prog in cases.items():
+        sfir = lower(sf.KernelChainGraph(programs.write_program(prog, str(tmp_path / (name + ".json")))))
+        seen = {}
+        for slab in (None, "0:24:8:96", "24:56:8:96"):
+            with Plan(sfir, options={"slab": slab} if slab else None) as plan:
+                launches = re.findall(r"launch (sf_\w+): ([^\[]+)\[", plan.describe())
+            seen[slab] = launches
+        first = seen[None]
+        assert first, name
+        for slab, launches in seen.items():
+            assert launches == first, (name, slab, launches, first)
