@@ -31,6 +31,21 @@ def test_instruction_budget_of_the_star_kernel(tmp_path):
     assert pu["all_valu"] < 18 and pu["vmem"] < 0.8, pu  # (both arms of the wave-uniform load-policy branch are counted)
     assert isa.classify("v_pk_add_f32") == "arith" and isa.classify("v_mov_b32_dpp") == "dpp+mov"
     assert isa.classify("s_nop") == "wait" and isa.classify("ds_read_b128") == "lds"
+    # the loop is a LOOP: shorter than the kernel (round 4 found the finder counting the whole kernel)
+    assert rec["loop_instructions"] < rec["instructions"] - 200, (rec["loop_instructions"], rec["instructions"])
+
+
+def test_loop_finder_reads_backward_branches_as_llvm_objdump_prints_them():
+    """llvm-objdump prints the 16-bit offset of a SOPP branch unsigned: a backward branch over 650 instructions reads
+    `s_cbranch_scc0 64886`, not `-650`.  The loop is the backward branch spanning the most instructions."""
+    isa = _load("isa_stats")
+    insts = [(0x1000 + 4 * i, "v_add_f32_e32", "v1, v2, v1") for i in range(700)]
+    insts[10] = (0x1000 + 40, "s_cbranch_execz", "5")                      # forward, short
+    insts[690] = (0x1000 + 4 * 690, "s_cbranch_scc0", str(65536 - 651))    # back to instruction 40
+    insts[300] = (0x1000 + 1200, "s_cbranch_vccnz", str(65536 - 21))       # a short inner loop
+    assert isa.main_loop(insts) == (40, 690)
+    assert isa.main_loop(insts[:600]) == (280, 300)
+    assert isa.main_loop(insts[:100]) is None
 
 
 def test_measured_table_is_generated_from_the_committed_profiles():
