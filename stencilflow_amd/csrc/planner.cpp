@@ -733,9 +733,15 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
   }
   const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
                       (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
-  // (a single operator that finds no clean tile falls to the generic kernel, ten times slower or worse: it gets more
-  //  shapes to try -- float64 operators over two fields fit only the smaller ones)
-  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", kernels.size() == 1 ? 24 : 8)));
+  // (a single operator that finds no clean tile falls to the generic kernel, ten times slower or worse: where registers
+  //  are scarce -- float64, or a second field's window -- it gets more shapes to try; only the failures cost compile time)
+  bool second_field = false;
+  for (int kk : kernels) {
+    CompactShape sh;
+    if (compact_eligible(P, P.kernels[kk], &sh) && !sh.extra.empty()) second_field = true;
+  }
+  const bool more = kernels.size() == 1 && (dt == DT::F64 || second_field);
+  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", more ? 24 : 8)));
   int rejected = 0, sgpr_rejects = 0;
   // Dense 3-D groups (box-like: every operator reads 18 or more of the 27 offsets of one field)
   // are bound by vector-instruction issue; letting the scheduler mix the rows of a step is worth
@@ -1429,7 +1435,9 @@ void build_plan(sf_plan& pl) {
             const double cols = (double)P.n[2] / ((double)std::max(1, c.NKT) * (double)c.BX * (double)c.VK);
             return rows * cols;
           };
-          if (kept(choice.cfg) < 0.6) {
+          // (grids narrower than a tile waste lanes at any depth and are no benchmark: the comparison -- one more
+          //  group to compile -- is for rows at least a tile wide)
+          if (P.n[2] >= (long long)choice.cfg.BX * choice.cfg.VK && kept(choice.cfg) < 0.6) {
             // (against what ONE operator's tile keeps on this grid: a small grid wastes lanes at any depth)
             std::vector<int> one{k};
             StarChoice single = select_compact(pl, star_memo, one, P.kernels[k].dt);
