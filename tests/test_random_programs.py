@@ -550,7 +550,7 @@ def test_radius_one_plain_sums_pair_up_in_the_dense_kernel(seed, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(0, 10)))
+@pytest.mark.parametrize("seed", list(range(0, 6)))
 def test_hip_matches_oracle_on_fused_pairs_of_plain_sums(seed, tmp_path):
     prog, ins, chain = _box_sum_case(seed, tmp_path)
     want = npo.run_reference(prog, inputs=ins)
@@ -565,7 +565,7 @@ def test_hip_matches_oracle_on_fused_pairs_of_plain_sums(seed, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [{"k1.ahead": 0}, {"k1.xbatch": 1}, {"k1.xlane": 1}])
-@pytest.mark.parametrize("seed", COMPACT_GPU_SEEDS[:4])
+@pytest.mark.parametrize("seed", COMPACT_GPU_SEEDS[:2])
 def test_compact_lane_exchange_variants_match_the_oracle(seed, extra, tmp_path):
     """The measured alternatives of compact3d.h's neighbour exchange (round 4: LDS reads not issued a row ahead; the DPP
     moves of a stage step in one burst; no DPP at all -- ds_swizzle and shifted reads of the row images) compute what
