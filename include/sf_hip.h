@@ -163,10 +163,10 @@ int sf_plan_kernel_planes(sf_plan* plan, int index, double* planes);
 int sf_plan_kernel_resources(const sf_plan* plan, int index, int* vgprs,
                              int* agprs, int* vgpr_spills, int* scratch_bytes,
                              int* lds_bytes);
-/* Diagnostic builds only (option "stamp=1"): read and clear the in-kernel cycle
- * counters of the star kernel (publish+barrier, stage 1, load issue, later
- * stages, wave count; summed over waves and launches). */
-int sf_plan_debug_counters(sf_plan* plan, unsigned long long* out, int count);
+/* The plan options this library accepts, one `key=<value>  meaning` line each (static text).  sf_plan_create refuses
+ * a key that is not listed (SF_ERR_INVALID) -- the reference's run_program has no such knobs (run_program.py:19-34);
+ * they pin what the planner would choose (tile shapes, fusion depth, kernel families) for tests and measurements. */
+const char* sf_describe_options(void);
 /* Human-readable description of the schedule (groups, tiles, buffers). */
 const char* sf_plan_describe(const sf_plan* plan);
 

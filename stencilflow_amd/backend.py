@@ -72,7 +72,7 @@ API = [
     ("sf_plan_kernel_object", _I, [_P, _I, _PP, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_char_p)]),
     ("sf_plan_kernel_planes", _I, [_P, _I, _DP]),
     ("sf_plan_kernel_resources", _I, [_P, _I, _IP, _IP, _IP, _IP, _IP]),
-    ("sf_plan_debug_counters", _I, [_P, ctypes.POINTER(ctypes.c_ulonglong), _I]),
+    ("sf_describe_options", _S, []),
     ("sf_plan_describe", _S, [_P]),
     ("sf_plan_num_steps", _I, [_P]),
     ("sf_plan_step_halo", _I, [_P, _I, _IP, _IP]),
@@ -116,6 +116,11 @@ HALO_RCCL_ID_BYTES = 128
 
 def library_path():
     return _LIB_PATH
+
+
+def describe_options():
+    """The plan options the library accepts (``key=<value>  meaning`` per line); any other key is refused."""
+    return load_library().sf_describe_options().decode()
 
 
 def load_library():
@@ -301,11 +306,6 @@ class Plan:
             out[name] = dict(zip(("vgprs", "agprs", "spills", "scratch", "lds"),
                                  [x.value for x in v]))
         return out
-
-    def debug_counters(self, count=5):
-        buf = (ctypes.c_ulonglong * 8)()
-        _check(self._lib.sf_plan_debug_counters(self._h, buf, count))
-        return [buf[i] for i in range(count)]
 
     def input_bytes(self, i):
         return self._lib.sf_plan_input_bytes(self._h, i)

@@ -54,7 +54,6 @@ int sf_plan_destroy(sf_plan* plan) {
     collect_profile(*plan);
     for (auto& b : plan->buffers)
       if (b.d) (void)hipFree(b.d);
-    if (plan->debug_buffer) (void)hipFree(plan->debug_buffer);
     for (auto& k : plan->kernels)
       if (k.mod) (void)hipModuleUnload(k.mod);
     for (auto& k : plan->check_kernels)
@@ -269,15 +268,9 @@ int sf_plan_kernel_resources(const sf_plan* p, int i, int* vgprs, int* agprs, in
   if (scratch && std::getenv("SF_HIP_REPORT_SGPR_SPILLS")) *scratch = k.sgpr_spills + 1000 * k.late_exec_restores;
   return SF_OK;
 }
-int sf_plan_debug_counters(sf_plan* plan, unsigned long long* out, int count) {
-  SF_API_BEGIN
-  if (!plan || !out || count < 0 || count > 8) throw Error(SF_ERR_INVALID, "bad argument");
-  ensure_device(*plan);
-  SF_HIP_CHECK(hipStreamSynchronize(plan->stream));
-  SF_HIP_CHECK(hipMemcpy(out, plan->debug_buffer, sizeof(unsigned long long) * count, hipMemcpyDeviceToHost));
-  SF_HIP_CHECK(hipMemset(plan->debug_buffer, 0, 64));
-  return SF_OK;
-  SF_API_END
+const char* sf_describe_options(void) {
+  static const std::string text = describe_options();
+  return text.c_str();
 }
 const char* sf_plan_describe(const sf_plan* p) { return p ? p->description.c_str() : nullptr; }
 

@@ -65,8 +65,6 @@ void ensure_device(sf_plan& pl) {
     SF_HIP_CHECK(hipMalloc(&b.d, b.bytes()));
     SF_HIP_CHECK(hipMemsetAsync(b.d, 0, b.bytes(), pl.stream));
   }
-  SF_HIP_CHECK(hipMalloc(&pl.debug_buffer, 64));
-  SF_HIP_CHECK(hipMemsetAsync(pl.debug_buffer, 0, 64, pl.stream));
   SF_HIP_CHECK(hipStreamSynchronize(pl.stream));
   pl.device_ready = true;
   self_check(pl);
@@ -164,7 +162,6 @@ void launch_ranges(sf_plan& pl, const Step& st, int i_begin, int i_end, int i_be
       for (size_t o = 1; o < st.out_bufs.size(); ++o) more_outs[o - 1] = pl.buffers[st.out_bufs[o]].d;
       args.push_back(more_outs);
     }
-    if (c.stamp) args.push_back(&pl.debug_buffer);
     SF_HIP_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(tiles * (nch1 + nch2)), 1, 1, c.BX, c.BY, 1, 0,
                                        stream, args.data(), nullptr));
   } else {
@@ -349,9 +346,7 @@ void execute(sf_plan& pl, int repetitions) {
   // graph=0|1 forces the choice.
   const bool small = pl.max_updates_per_launch > 0 && pl.max_updates_per_launch < 8.0e6;
   const bool want_graph = pl.opt.get("graph", (small && pl.steps.size() >= 4) ? 1 : 0) != 0;
-  bool stamp = false;
-  for (auto& st : pl.steps) stamp = stamp || (st.star && st.cfg.stamp);
-  if (want_graph && !pl.profile && !stamp && repetitions > 0) {
+  if (want_graph && !pl.profile && repetitions > 0) {
     if (!pl.chain_graph || pl.chain_graph_scalars != pl.scalar_values) {
       if (pl.chain_graph) {
         (void)hipGraphExecDestroy(pl.chain_graph);

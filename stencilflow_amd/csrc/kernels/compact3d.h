@@ -64,43 +64,16 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_PLANE_BYTES ((unsigned)(SF_PLANE_ELEMS * (long long)sizeof(sf_t)))
 #define SF_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format (gfx9 / CDNA) */
 
-#ifndef SF_SKIP_ROWS
-#define SF_SKIP_ROWS 0
-#endif
-#ifndef SF_LDS_AHEAD
-#define SF_LDS_AHEAD 1
-#endif
-// Timing diagnostics (plan option debug.whatif; the results are WRONG): 1 no barrier, 2 no LDS reads (the
-// registers keep what they hold), 4 no lane exchange, 8 no loads of the streamed planes, 16 no stores,
-// 32 nothing published to LDS.
-#ifndef SF_WHATIF
-#define SF_WHATIF 0
-#endif
 #define SF_SLOTS 4
 #define SF_NWIN (SF_T + SF_NX)
 #define SF_TJH (SF_BY * SF_RJ)
 #define SF_TKH (SF_BX * SF_VK)
-// Lane neighbours (k-1 of a thread's first element, k+1 of its last).  SF_XLANE 0 (default): DPP wave_shr / wave_shl
-// with the wave-edge words from LDS.  SF_XLANE 1 (plan option k1.xlane=1): NO cross-lane vector instruction -- on
-// gfx950 a single DPP move (v_readlane, v_permlane alike) switches off, for ~2000 cycles, the overlap of two waves' f32
-// instructions on a SIMD (tools/micro/valu_rate.hip: 7 v_add_f32 + 1 DPP: 0.97 quad-cycles per instruction against
-// 0.53 for the adds alone, profiles/r04_valu_rate.log).  Rows that are published in full anyway (a thread row's first
-// and last row) are read back from the row image one element to the left and to the right (the images carry a pad on
-// either side holding the boundary constant); the rows in between go through ds_swizzle_b32 (rotation within 32
-// lanes, an LDS-pipe instruction) and the lanes at a 32-lane edge take the word their neighbour segment published.
-// Bit-exact (compact fuzz), and SLOWER than DPP on the 27-point box at every tile shape (profiles/r04_box_xlane.log:
-// the shifted reads have a stride of four words, an 8-way bank conflict, and the staging costs ~25 registers):
-// kept as a measured alternative, not chosen.
-#ifndef SF_XLANE
-#define SF_XLANE 0
-#endif
-#ifndef SF_XBATCH
-#define SF_XBATCH 0
-#endif
-#define SF_SEG (SF_XLANE ? 32 : 64)
-#define SF_WPR (SF_BX / SF_SEG) /* segments (waves or half-waves) per row */
-#define SF_ROW_PAD ((SF_XLANE && !SF_NOJ) ? 4 : 0)
-#define SF_ROW_STRIDE (SF_TKH + 2 * SF_ROW_PAD)
+// Lane neighbours (k-1 of a thread's first element, k+1 of its last): DPP wave_shr / wave_shl with the wave-edge words
+// from LDS.  (Round 4 built two alternatives -- no cross-lane vector instruction at all, the rows going through
+// ds_swizzle / shifted reads of the row images; all the moves of a stage step in one burst -- bit-exact and slower on
+// the 27-point box at every tile shape, profiles/r04_box_xlane.log; removed in round 5, NOTES.md.)
+#define SF_WPR (SF_BX / 64) /* waves per row */
+#define SF_ROW_STRIDE SF_TKH
 #if SF_NOJ
 #define SF_TJI 1  // 2-D programs: the stream axis is j, there is no tiled row axis (one row per thread)
 #else
@@ -202,12 +175,9 @@ struct sf_ctx {
   bool kvec_in, tile_inside;
   int goff, halo, cb, ce, j0, k0;
   unsigned ld_off[SF_RJ], st_off[SF_RJ];
-#if SF_SKIP_ROWS
-  unsigned need_rows[SF_T];  // wave-uniform: bit r set = stage s + 1 evaluates row r of this thread row
-#endif
 };
 
-__host__ __device__ constexpr int sf_rows_at(int ty, int which) { return (ty * 2 + which) * SF_ROW_STRIDE + SF_ROW_PAD; }
+__host__ __device__ constexpr int sf_rows_at(int ty, int which) { return (ty * 2 + which) * SF_ROW_STRIDE + 0; }
 // (ty in -1 .. SF_BY, w in -1 .. SF_WPR)
 __host__ __device__ constexpr int sf_edge_at(int ty, int r, int w, int side) {
   return ((((ty + 1) * SF_RJ + r) * SF_EDGE_WAVES + (w + 1)) * 2 + side);
@@ -312,9 +282,6 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const sf_t* fiel
 struct sf_nbr {
   sf_vec lo[3], hi[3];
   sf_t km[3][SF_RJ + 2], kp[3][SF_RJ + 2];
-#if SF_XLANE
-  sf_t ekm[3], ekp[3];  // segment-edge words of the one row whose rotated values are in flight
-#endif
 };
 
 __host__ __device__ constexpr unsigned sf_plane_bits(unsigned m, int d) { return (m >> (d * 9)) & 0x1ffu; }
@@ -343,8 +310,6 @@ struct sf_row_plan {
   // thread row that owns the row (relative to ty), and its index there
   static constexpr int dty = below ? -1 : (above ? 1 : 0);
   static constexpr int orow = below ? SF_RJ - 1 : (above ? 0 : RR);
-  // the row is in the row image in full (first / last row of a thread row): SF_XLANE reads its neighbours there
-  static constexpr bool published = !SF_NOJ && (RR <= 0 || RR >= SF_RJ - 1);
   // cx.edge0 addresses (ty - 1, row 0, wave - 1, side 0): the rest is compile-time
   static constexpr int e_lo = sf_edge_at(dty, orow, -1, 1) - sf_edge_at(-1, 0, -1, 0);
   static constexpr int e_hi = sf_edge_at(dty, orow, 1, 0) - sf_edge_at(-1, 0, -1, 0);
@@ -352,49 +317,15 @@ struct sf_row_plan {
 
 template <int WIN, unsigned NEED, int PH, int RR>
 __device__ __forceinline__ void sf_fetch_row(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx) {
-  if constexpr (RR >= -1 && RR <= SF_RJ && (SF_WHATIF & 2) != 0) {  // diagnostics: opaque values instead of LDS reads
-    sf_static_for<0, 3>([&](auto D) {
-      using plan = sf_row_plan<WIN, NEED, PH, RR, decltype(D)::value>;
-      constexpr int d = decltype(D)::value;
-      if constexpr (plan::want_row) {
-        sf_t z = (sf_t)cx.tx;
-        asm volatile("" : "+v"(z));
-        if constexpr (plan::below) nb.lo[d] = (sf_vec)z;
-        if constexpr (plan::above) nb.hi[d] = (sf_vec)z;
-        if constexpr (plan::want_km) nb.km[d][RR + 1] = z;
-        if constexpr (plan::want_kp) nb.kp[d][RR + 1] = z;
-      }
-    });
-  }
-  if constexpr (RR >= -1 && RR <= SF_RJ && !(SF_WHATIF & 2)) {
+  if constexpr (RR >= -1 && RR <= SF_RJ) {
     sf_static_for<0, 3>([&](auto D) {
       using plan = sf_row_plan<WIN, NEED, PH, RR, decltype(D)::value>;
       constexpr int d = decltype(D)::value;
       if constexpr (plan::want_row) {
         if constexpr (plan::below) nb.lo[d] = *reinterpret_cast<const sf_vec*>(&lds_all[SF_ROWS_IMAGE(plan::g) + cx.row_lo]);
         if constexpr (plan::above) nb.hi[d] = *reinterpret_cast<const sf_vec*>(&lds_all[SF_ROWS_IMAGE(plan::g) + cx.row_hi]);
-#if SF_XLANE
-        if constexpr (plan::published) {
-          // this thread's vector in the row image, one element to the left / right of it
-          const int at = plan::below ? cx.row_lo : (plan::above ? cx.row_hi : (RR == 0 ? cx.row_own : cx.row_own + SF_ROW_STRIDE));
-          if constexpr (plan::want_km) nb.km[d][RR + 1] = lds_all[SF_ROWS_IMAGE(plan::g) + at - 1];
-          if constexpr (plan::want_kp) nb.kp[d][RR + 1] = lds_all[SF_ROWS_IMAGE(plan::g) + at + SF_VK];
-        } else {
-          constexpr int slot[3] = {PH % SF_SLOTS, (PH + 1) % SF_SLOTS, (PH + 2) % SF_SLOTS};
-          const sf_vec row = st.w[WIN][slot[d]][RR < 0 ? 0 : (RR >= SF_RJ ? SF_RJ - 1 : RR)];
-          if constexpr (plan::want_km) {
-            nb.ekm[d] = lds_all[SF_EDGE_IMAGE(plan::g) + cx.edge0 + plan::e_lo];
-            nb.km[d][RR + 1] = sf_rotate_lane<true>(row[SF_VK - 1]);
-          }
-          if constexpr (plan::want_kp) {
-            nb.ekp[d] = lds_all[SF_EDGE_IMAGE(plan::g) + cx.edge0 + plan::e_hi];
-            nb.kp[d][RR + 1] = sf_rotate_lane<false>(row[0]);
-          }
-        }
-#else
         if constexpr (plan::want_km) nb.km[d][RR + 1] = lds_all[SF_EDGE_IMAGE(plan::g) + cx.edge0 + plan::e_lo];
         if constexpr (plan::want_kp) nb.kp[d][RR + 1] = lds_all[SF_EDGE_IMAGE(plan::g) + cx.edge0 + plan::e_hi];
-#endif
       }
     });
   }
@@ -411,22 +342,10 @@ __device__ __forceinline__ void sf_merge_row(sf_nbr& nb, const sf_state& st, con
       if constexpr (plan::below) row = nb.lo[d];
       else if constexpr (plan::above) row = nb.hi[d];
       else row = st.w[WIN][slot[d]][RR < 0 ? 0 : (RR >= SF_RJ ? SF_RJ - 1 : RR)];
-      if constexpr ((SF_WHATIF & 4) != 0) {
-        if constexpr (plan::want_km) nb.km[d][RR + 1] = row[SF_VK - 1];
-        if constexpr (plan::want_kp) nb.kp[d][RR + 1] = row[0];
-      } else {
-#if SF_XLANE
-        if constexpr (!plan::published) {  // (a published row's neighbours came from the row image as they are)
-          if constexpr (plan::want_km) nb.km[d][RR + 1] = cx.seg_first ? nb.ekm[d] : nb.km[d][RR + 1];
-          if constexpr (plan::want_kp) nb.kp[d][RR + 1] = cx.seg_last ? nb.ekp[d] : nb.kp[d][RR + 1];
-        }
-#else
-        if constexpr (plan::want_km)  // k-1: the lane below, or the lower wave's last element
-          nb.km[d][RR + 1] = sf_neighbour_lane_or<true>(row[SF_VK - 1], nb.km[d][RR + 1]);
-        if constexpr (plan::want_kp)  // k+1
-          nb.kp[d][RR + 1] = sf_neighbour_lane_or<false>(row[0], nb.kp[d][RR + 1]);
-#endif
-      }
+      if constexpr (plan::want_km)  // k-1: the lane below, or the lower wave's last element
+        nb.km[d][RR + 1] = sf_neighbour_lane_or<true>(row[SF_VK - 1], nb.km[d][RR + 1]);
+      if constexpr (plan::want_kp)  // k+1
+        nb.kp[d][RR + 1] = sf_neighbour_lane_or<false>(row[0], nb.kp[d][RR + 1]);
     }
   });
 }
@@ -435,9 +354,6 @@ __device__ __forceinline__ void sf_merge_row(sf_nbr& nb, const sf_state& st, con
 // for the first stage of a step, right behind the barrier.
 template <int WIN, unsigned NEED, int PH>
 __device__ __forceinline__ void sf_gather_begin(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx) {
-#if SF_XBATCH
-  return;  // (all source rows are prepared at the start of the stage step: sf_gather_prepare)
-#endif
   sf_fetch_row<WIN, NEED, PH, -1>(nb, st, lds_all, cx);
   sf_fetch_row<WIN, NEED, PH, 0>(nb, st, lds_all, cx);
   sf_fetch_row<WIN, NEED, PH, 1>(nb, st, lds_all, cx);
@@ -448,16 +364,6 @@ __device__ __forceinline__ void sf_gather_begin(sf_nbr& nb, const sf_state& st, 
 // the LDS reads of the row after that are issued for the next output row to find.
 template <int WIN, unsigned NEED, int PH, int R>
 __device__ __forceinline__ void sf_gather_prepare(sf_nbr& nb, const sf_state& st, const sf_t* lds_all, const sf_ctx& cx) {
-#if SF_XBATCH
-  // All source rows of the stage step at once, before its first output row: the DPP moves of a stage step come in ONE
-  // burst.  On gfx950 a DPP move switches off the overlap of two waves' f32 instructions on the SIMD for ~2000 cycles
-  // (tools/micro/valu_rate.hip); spread over the rows, as they are otherwise, the moves keep it off for good.
-  if constexpr (R == 0) {
-    sf_static_for<0, SF_RJ + 2>([&](auto RR) { sf_fetch_row<WIN, NEED, PH, decltype(RR)::value - 1>(nb, st, lds_all, cx); });
-    sf_static_for<0, SF_RJ + 2>([&](auto RR) { sf_merge_row<WIN, NEED, PH, decltype(RR)::value - 1>(nb, st, cx); });
-  }
-  return;
-#endif
   if constexpr (R == 0) {
     sf_merge_row<WIN, NEED, PH, -1>(nb, st, cx);
     sf_merge_row<WIN, NEED, PH, 0>(nb, st, cx);
@@ -503,7 +409,7 @@ __device__ __forceinline__ void sf_refill(sf_state& st, const sf_ctx& cx, const 
   if constexpr (S == 1) {
     // input window: prev (plane p-2) is dead, plane p+1 is in flight in the fourth
     // slot, so prev's row receives plane p+2 (two steps to land, no copy)
-    if constexpr (!(SF_WHATIF & 8)) st.w[0][iprev][R] = sf_load_row<stage::bc_zero>(cx, cx.in, p + 2, R, p + 2 < p_end, stage::bc());
+    st.w[0][iprev][R] = sf_load_row<stage::bc_zero>(cx, cx.in, p + 2, R, p + 2 < p_end, stage::bc());
   }
   if constexpr (stage::xneed != 0) {
     // extra field: this stage consumed planes q-1..q+1, q+2 is in flight: request q+3,
@@ -543,18 +449,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all,
       sf_gather_begin<(S > 1 ? S - 2 : 0), below::need, PH>(nbn_next, st, lds_all, cx);
       if constexpr (below::xneed != 0) sf_gather_begin<(below::xneed != 0 ? below::xwin : 0), below::xneed, PH>(nbx_next, st, lds_all, cx);
     }
-#if SF_LDS_AHEAD
     __builtin_amdgcn_sched_barrier(0);  // the reads above are issued before the row is evaluated, not behind it
-#endif
-#if SF_SKIP_ROWS
-    // a halo row of the tile no later stage reads (star3d.h: SF_SKIP_ROWS; wave-uniform test): the windows
-    // move on, the neighbour rows are prepared for the rows that follow, nothing is evaluated
-    if (!((cx.need_rows[S - 1] >> r) & 1u)) {
-      if constexpr (r > 0) sf_refill<S, PH, r - 1>(st, cx, p, p_end);
-      if constexpr (r == SF_RJ - 1) sf_refill<S, PH, r>(st, cx, p, p_end);
-      return;
-    }
-#endif
     sf_t n[SF_VK][27], x[SF_VK][27];
 #pragma unroll
     for (int v = 0; v < SF_VK; ++v)
@@ -577,11 +472,7 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds_all,
       char* base = reinterpret_cast<char*>(out) + (long long)(q + cx.halo) * (long long)SF_PLANE_BYTES;
       const __amdgpu_buffer_rsrc_t rs =
           __builtin_amdgcn_make_buffer_rsrc(base, 0, store_plane ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
-      if constexpr ((SF_WHATIF & 16) != 0) {
-        asm volatile("" : : "v"(o), "s"(rs));  // evaluated, not stored
-      } else {
-        sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
-      }
+      sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
     } else {
       // outside the global domain the next stage must read ITS constant
       if (!(cx.tile_inside && plane_in)) {
@@ -644,19 +535,6 @@ __device__ __forceinline__ void sf_edge_prefill(sf_t* lds_all, const sf_ctx& cx)
     if constexpr (sf_win<W>::lateral) {
       constexpr int consumer = sf_win_info<W>::consumer;
       const sf_t bc = (W < SF_T) ? sf_stage<(consumer > 0 ? consumer : 1)>::bc() : sf_stage<(consumer > 0 ? consumer : 1)>::xbc();
-#if SF_ROW_PAD
-      // the element left of a row's first and right of its last column in the row images
-      if (cx.tx == 0) {
-#pragma unroll
-        for (int image = 0; image < sf_win<W>::ring; ++image)
-#pragma unroll
-          for (int which = 0; which < 2; ++which) {
-            sf_t* row = lds_all + SF_ROWS_IMAGE(sf_win_base<W>::value + image) + (cx.ty * 2 + which) * SF_ROW_STRIDE;
-            row[SF_ROW_PAD - 1] = bc;
-            row[SF_ROW_PAD + SF_TKH] = bc;
-          }
-      }
-#endif
       if (cx.seg_first && (cx.wave == 0 || cx.wave == SF_WPR - 1)) {
 #pragma unroll
         for (int image = 0; image < sf_win<W>::ring; ++image)
@@ -690,8 +568,8 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds_all, sf_t* __res
         else asm volatile("" : "+v"(st.w[w][s][r]));
       }
 #endif
-  if constexpr (!(SF_WHATIF & 32)) sf_publish<0, PH>(st, lds_all, cx);
-  if constexpr (!(SF_WHATIF & 1)) __syncthreads();
+  sf_publish<0, PH>(st, lds_all, cx);
+  __syncthreads();
   sf_nbr nbn, nbx;
   sf_gather_begin<SF_T - 1, sf_stage<SF_T>::need, PH>(nbn, st, lds_all, cx);
   if constexpr (sf_stage<SF_T>::xneed != 0)
@@ -732,10 +610,10 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   const int sf_tid_x = (int)threadIdx.x, sf_tid_y = (int)threadIdx.y;
   cx.tx = sf_tid_x;
   cx.ty = sf_tid_y;
-  cx.wave = cx.tx / SF_SEG;
-  cx.lane = cx.tx % SF_SEG;
+  cx.wave = cx.tx / 64;
+  cx.lane = cx.tx % 64;
   cx.seg_first = cx.lane == 0;
-  cx.seg_last = cx.lane == SF_SEG - 1;
+  cx.seg_last = cx.lane == 64 - 1;
   cx.goff = goff;
   cx.halo = halo;
   cx.row_own = sf_rows_at(cx.ty, 0) + cx.tx * SF_VK;
@@ -790,18 +668,6 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     cx.st_off[r] = ((store_mask >> r) & 1u) ? off : SF_OOB;
   }
 
-#if SF_SKIP_ROWS
-#pragma unroll
-  for (int s = 0; s < SF_T; ++s) {
-    unsigned need = 0;
-#pragma unroll
-    for (int r = 0; r < SF_RJ; ++r) {
-      const int tr = sf_tid_y * SF_RJ + r;
-      need |= ((SF_NOJ || (tr >= s + 1 && tr < SF_TJH - (s + 1))) ? 1u : 0u) << r;
-    }
-    cx.need_rows[s] = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
-  }
-#endif
   sf_state st;
 #pragma unroll
   for (int w = 0; w < SF_NWIN; ++w)

@@ -9,69 +9,70 @@
 // LDS once and every thread reads its (RJ + 2R) x (VK + 2R) patch from there -- the "2.5-D
 // LDS plane tiling" of the literature.  Semantics per point as ExpandStencilCPU
 // (stencilflow/stencil/cpu.py:58-115): out-of-domain reads yield the boundary constant --
-// the tile is padded with it at GLOBAL coordinates when it is written to LDS; the sum is
-// evaluated in the order of the program text (the functor is the text).
+// the tile is padded with it at GLOBAL coordinates in LDS; the sum is evaluated in the order
+// of the program text (the functor is the text).
 //
 // Decomposition
 //   block  = tile of TJ x TK output points of the (j,k) plane (TJ = BY * RJ rows, TK = BX * VK
 //            columns), marching along i over one chunk of planes;
-//   LDS    = ring of SIX plane slots of (TJ + 2R) x (TK + 2R) elements: step p writes plane p
-//            into slot p mod 6 (its loads were issued a step earlier), ONE barrier, then output
-//            plane q = p - R is evaluated from the five slots q-R .. q+R; the slot written at
-//            step p + 1 holds plane p - 5, which nobody reads any more;
-//   thread = RJ rows x VK columns of outputs; the step loop is unrolled by six, so a slot
-//            index is a compile-time constant and every LDS address is one per-thread base
-//            plus an immediate offset.
+//   thread = RJ rows x VK columns of outputs; the step loop is unrolled, so every LDS address is one
+//            per-thread base plus an immediate offset.
+// Three forms (macros from codegen):
+//   * general (any expression over the neighbourhood; SF_DENSE_ROWS 1: one plain sum, rows in step): a ring of SIX
+//     plane slots of (TJ + 2R) x (TK + 2R) elements: step p writes plane p -- loaded a step earlier into registers --
+//     into slot p mod 6, ONE barrier, then output plane q = p - R is evaluated from the five slots q-R .. q+R.
+//   * SF_DENSE_STREAM 1 (a plain sum whose terms come plane by plane, lowest plane first -- the generator's order, so the
+//     partial sum of output plane q meets its terms in the order of the text while the planes q-R .. q+R stream past):
+//     accumulate<PH>(tb, acc[ACCS][RJ][VK]) adds the plane that has just arrived to the accumulators of the output
+//     planes it belongs to, finish(sc, acc[s], out) scales the finished one.  A plane is read from LDS ONCE instead of
+//     five times; SFD_DLAST (the highest plane offset of the text) says which output plane a step completes.
+//   * SF_DENSE_T2 1 (round 4): TWO such operators with offsets in {-1,0,1}^3 in one launch -- `sf_dense` over the input
+//     ring, its finished planes (padded with the second operator's boundary constant outside the global domain) go into
+//     a second LDS ring, `sf_dense2` streams over that one a step later; three accumulator sets per operator.  The block
+//     evaluates both operators on its whole thread tile and stores the second one's interior (one row -- and, when a row
+//     is cut into tiles, four columns -- on either side are recomputed by the neighbouring tile); no register windows
+//     and no lane exchange, so the f32 adds of co-resident waves overlap.
+// Round 5: the streaming forms take their planes by LDS-DMA (`buffer_load_dwordx4 ... lds`: memory -> LDS, no staging
+// registers, no ds_write).  The input planes go through a ring of SF_IN_SLOTS slots, requested SF_IN_SLOTS - 1 planes
+// ahead (one slot: requested in mid-step, fused form only).  One wave-instruction writes 64 x 16 bytes of LDS in a row
+// (M0 + 16 x lane) while the SOURCE address is per lane: a slot is filled in image order, chunk c of the slot by lane
+// c mod 64 of piece c / 64, and a lane whose chunk lies outside the (j,k) domain -- or every lane, for a plane outside
+// the global domain: a resource of zero records -- reads out of range, which WRITES ZERO and touches no memory
+// (measured, tools/micro/lds_dma_probe.hip, profiles/r05_lds_dma_probe.log).  So an LDS row starts SF_RCL columns left
+// of the tile, RCL a whole number of chunks (a chunk is in or out as a whole: N2 is a multiple of 4), a slot is padded
+// to a whole number of 1-KiB pieces, and a boundary constant other than zero is written over the zeros by the tiles
+// that reach beyond the domain (sf_fix_boundary).  A row segment then starts RCL - RC elements past a 16-byte boundary
+// and is read in aligned pieces (float, RC = 2: 8 + 16 + 8 bytes).
 //
-// Macros from codegen: SF_R SF_VK SF_RJ SF_BX SF_BY SF_NOJ SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_NT
-//   SF_NLOADS SF_KERNEL_NAME; typedef sf_t; struct sf_scalars; struct sf_auxptrs;
-//   struct sf_dense {bc(), bc_zero, template<int PH> apply_row(tb, r, sc, o, gi, gj, gk0)}: the VK outputs of one row,
-//   every row segment (VK + 2R elements of one (di, dj)) read from LDS as aligned 16-byte chunks;
-//   SF_DENSE_ROWS 1 (the operator is one plain sum): apply_rows(tb, sc, out[RJ][VK]) instead, all rows in step.
-//   SF_DENSE_STREAM 1 (a plain sum whose terms come plane by plane, lowest plane first -- the generator's order, so the
-//   partial sum of output plane q meets its terms in the order of the text while the planes q-R .. q+R stream past):
-//   accumulate<PH>(tb, acc[5][RJ][VK]) adds the plane that has just arrived to the accumulators of the output planes
-//   it belongs to, finish(sc, acc[s], out) scales the finished one.  A plane is read from LDS ONCE instead of five
-//   times (1.5 instead of 7.6 ds_read_b128 per point of the 125-point box), the LDS ring shrinks to two slots, and
-//   SFD_DLAST (the highest plane offset of the text) says which output plane a step completes.
-//   SF_DENSE_T2 1 (round 4): TWO such operators with offsets in {-1,0,1}^3 in one launch -- `sf_dense` over the input
-//   ring, its finished planes (padded with the second operator's boundary constant outside the global domain) go into a
-//   second LDS ring, `sf_dense2` streams over that one a step later; three accumulator sets per operator, one barrier
-//   per step.  The block evaluates both operators on its whole thread tile and stores the second one's interior (one row
-//   -- and, when a row is cut into tiles, four columns -- on either side are recomputed by the neighbouring tile); no
-//   register windows and no lane exchange, so the f32 adds of co-resident waves overlap.
+// Macros from codegen: SF_R SF_VK SF_RJ SF_BX SF_BY SF_NOJ SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_NT SF_KERNEL_NAME,
+//   general forms SF_NLOADS, streaming forms SF_IN_SLOTS SF_RCL [SF_RC SF_ACCS SF_RJH SF_KTILED]; typedef sf_t; struct
+//   sf_scalars; struct sf_auxptrs; struct sf_dense (and sf_dense2) {bc(), bc_zero, apply_row / apply_rows / accumulate + finish}.
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
 typedef sf_t sf_pair __attribute__((ext_vector_type(2)));
 #define SF_CE (16 / (int)sizeof(sf_t))  // elements of a 16-byte chunk
 typedef sf_t sf_chunk __attribute__((ext_vector_type(16 / sizeof(sf_t))));
-#ifndef SF_RC
-#define SF_RC SF_R  // halo COLUMNS of an LDS row: R, rounded up to an even number (radius 3: four) -- pairs and chunks stay aligned
-#endif
-#define SF_SEG (SF_VK + 2 * SF_RC)  // a row segment: the thread's VK columns and RC more on either side
 typedef unsigned sf_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
-
+#ifndef SF_RC
+#define SF_RC SF_R  // halo COLUMNS of a row segment: R, rounded up to an even number (radius 3: four)
+#endif
+#ifndef SF_IN_SLOTS
+#define SF_IN_SLOTS 0
+#endif
+#define SF_DMA (SF_IN_SLOTS > 0)
+#ifndef SF_RCL
+#define SF_RCL SF_RC  // halo columns of an LDS ROW (>= RC; LDS-DMA: a whole number of chunks)
+#endif
 #ifndef SF_DENSE_STREAM
 #define SF_DENSE_STREAM 0
-#endif
-// Timing diagnostics of the streaming form (plan option debug.whatif; the results are WRONG): 1 no barrier, 2 the plane
-// is not written to LDS, 8 no loads of the streamed planes, 16 results evaluated but not stored.
-#ifndef SF_WHATIF
-#define SF_WHATIF 0
-#endif
-#ifndef SF_DENSE_LOAD_EARLY
-#define SF_DENSE_LOAD_EARLY 0
 #endif
 #ifndef SF_DENSE_T2
 #define SF_DENSE_T2 0
 #endif
 #if SF_DENSE_STREAM
-#ifndef SF_T2_ONE_IN
-#define SF_T2_ONE_IN 0  // fused form: ONE slot for the input planes (a second barrier per step) instead of two
-#endif
-#define SF_MID0 (SF_T2_ONE_IN ? 1 : 2)  // first slot of the ring between the two operators
-#define SF_SLOTS (SF_DENSE_T2 ? SF_MID0 + 2 : 2)  // LDS: the plane being read and the one being written (T2: of either ring)
+#define SF_MID0 SF_IN_SLOTS  // first slot of the ring between the two operators
+#define SF_SLOTS (SF_DENSE_T2 ? SF_IN_SLOTS + 2 : SF_IN_SLOTS)
 #ifndef SF_ACCS
 #define SF_ACCS (2 * SF_R + 1)  // accumulator sets: output planes p - R .. p + R are open while plane p is read
 #endif
@@ -98,12 +99,26 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_KTILED 1
 #endif
 #define SF_TK (SF_BX * SF_VK)
+#define SF_THREADS (SF_BX * SF_BY)
 #define SF_LROWS (SF_TJ + 2 * SF_RJH)
-#define SF_LS (SF_TK + 2 * SF_RC)  // row stride of a slot (elements); TK is a multiple of 4, RC even: pairs stay 8-byte aligned
+#define SF_LS (SF_TK + 2 * SF_RCL)  // row stride of a slot (elements); TK is a multiple of 4, RCL even: pairs stay 8-byte aligned
 #define SF_SLOT_ELEMS (SF_LROWS * SF_LS)
+#if SF_DMA
+#define SF_NCH (SF_SLOT_ELEMS / SF_CE)       // 16-byte chunks of a slot
+#define SF_NI ((SF_NCH + 63) / 64)           // pieces (wave-instructions, 1 KiB each) that fill one
+#define SF_SLOT_STRIDE (SF_NI * 64 * SF_CE)  // elements from slot to slot: the last piece ends inside the slot's padding
+#define SF_NW (SF_THREADS / 64)
+#define SF_ND ((SF_NI + SF_NW - 1) / SF_NW)  // pieces a wave issues per plane, at most / at least
+#define SF_NDMIN (SF_NI / SF_NW)
+#ifndef SF_LAG
+#define SF_LAG 0  // planes the ring keeps behind the one that has just arrived (terms that join their output plane late)
+#endif
+#define SF_AHEAD (SF_IN_SLOTS - SF_LAG > 1 ? SF_IN_SLOTS - SF_LAG - 1 : 1)  // planes requested ahead of the one being read
+#else
+#define SF_SLOT_STRIDE SF_SLOT_ELEMS
 #define SF_PAIRS_PER_ROW (SF_LS / 2)
 #define SF_PAIRS (SF_LROWS * SF_PAIRS_PER_ROW)
-#define SF_THREADS (SF_BX * SF_BY)
+#endif
 
 // slot of plane q + di when the plane written this step (p = q + R) sits in slot PH
 #define SF_SLOT_OF(PH, di) (((PH) + (di) - SF_R + 2 * SF_SLOTS) % SF_SLOTS)
@@ -138,18 +153,88 @@ struct sf_ctx {
   const sf_t* in;
   int goff, halo, cb, ce;
   int j0, k0;  // global (j, k) of the thread's first output point (`copy` boundaries)
+#if SF_DMA
+  // what this thread requests of every plane: chunk (n * NW + wave) * 64 + lane of the slot, n < ND -- its byte offset
+  // inside the plane (SF_OOB: outside the (j,k) domain or beyond the slot: reads as zero)
+  unsigned ld_off[SF_ND];
+  unsigned wave;      // (scalar) wave of the block
+  unsigned lds_base;  // (scalar) LDS byte address of slot 0
+  bool edge_tile;     // (scalar) the tile reaches beyond the (j,k) domain: non-zero boundary constants are written in
+#else
   // what this thread moves of every plane: SF_NLOADS pairs of elements (8 bytes for float, 16 for
   // double) -- byte offset inside the plane (SF_OOB: outside the (j,k) domain, or no pair at
   // all) and element index inside an LDS slot (-1: no pair)
   unsigned ld_off[SF_NLOADS];
   int ld_lds[SF_NLOADS];
+#endif
   unsigned st_off[SF_RJ];  // byte offset of the thread's output vector in row r, or SF_OOB
-  int tb;                  // LDS element index of the thread's patch origin (row -RJH, column -R of its outputs)
+  int tb;                  // LDS element index of the thread's patch origin (row -RJH, column -RC of its outputs)
 #if SF_DENSE_T2
   unsigned jmask, kmask;   // rows / columns of the thread's points that lie inside the global domain
 #endif
 };
 
+#if SF_DMA
+// One piece: 64 lanes x 16 bytes from `voff` (per lane, bytes inside the resource) to LDS [lds_byte + 16 * lane].  M0 holds
+// the destination and belongs to the compiler: saved and restored inside the statement.  The compiler does not count
+// this load: the waits below are ours (sf_wait_plane).
+__device__ __forceinline__ void sf_dma16(const __amdgpu_buffer_rsrc_t rs, const unsigned voff, const unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rs), "s"(lds_byte)
+      : "memory");
+}
+
+// Requests input plane p into slot `slot`.  A plane outside the global domain, or one the chunk does not need
+// (`enabled` false), is requested from a resource of zero records: every lane reads zero, nothing touches memory, and
+// EVERY wave issues the same number of pieces in every step -- which is what the counted waits rely on.
+__device__ __forceinline__ void sf_dma_plane(const sf_ctx& cx, const int p, const bool enabled, const int slot) {
+  const bool plane_ok = enabled && (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
+  const char* base = reinterpret_cast<const char*>(cx.in) + (long long)(p + cx.halo) * (long long)SF_PLANE_BYTES;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0,
+                                                                     plane_ok ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
+  const unsigned dst = cx.lds_base + (unsigned)slot * (unsigned)(SF_SLOT_STRIDE * sizeof(sf_t));
+#pragma unroll
+  for (int n = 0; n < SF_ND; ++n) {
+    const unsigned piece = (unsigned)n * SF_NW + cx.wave;
+    if (n < SF_NDMIN || piece < (unsigned)SF_NI) sf_dma16(rs, cx.ld_off[n], dst + piece * 1024u);
+  }
+}
+
+// Waits until the wave's requests of the plane that is read next have landed (all but the YOUNGER vector-memory
+// operations: the pieces of the planes requested since -- at least NDMIN each -- and the stores of the steps since),
+// and for its own LDS accesses; then the block's barrier.  `drain`: the first steps of a chunk, where fewer
+// operations are in flight than the count assumes.
+template <int YOUNGER>
+__device__ __forceinline__ void sf_wait_plane(const bool drain) {
+  constexpr int N = YOUNGER > 63 ? 63 : YOUNGER;
+  if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// A boundary constant other than zero: the tiles that reach beyond the (j,k) domain, and every tile for a plane outside
+// the global domain, write it over the zeros the requests left (each thread over the chunks it requested), then a
+// second barrier.  The condition is the same for the whole block.
+template <typename F>
+__device__ __forceinline__ void sf_fix_boundary(const sf_ctx& cx, const int p, const bool enabled, sf_t* sl) {
+  if constexpr (!F::bc_zero) {
+    const bool plane_in = enabled && (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
+    if (cx.edge_tile || !plane_in) {
+      sf_chunk fill;
+#pragma unroll
+      for (int e = 0; e < SF_CE; ++e) fill[e] = F::bc();
+#pragma unroll
+      for (int n = 0; n < SF_ND; ++n) {
+        const unsigned c = ((unsigned)n * SF_NW + cx.wave) * 64u + (threadIdx.x + threadIdx.y * SF_BX) % 64u;
+        if (c < (unsigned)SF_NCH && (!plane_in || cx.ld_off[n] == SF_OOB)) *reinterpret_cast<sf_chunk*>(&sl[c * SF_CE]) = fill;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  }
+}
+#else
 // the thread's pairs of input plane p, padded with the boundary constant outside the global domain
 __device__ __forceinline__ void sf_load_plane(const sf_ctx& cx, const int p, sf_pair (&dst)[SF_NLOADS], const bool enabled) {
   const bool plane_ok = enabled && (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
@@ -167,6 +252,7 @@ __device__ __forceinline__ void sf_load_plane(const sf_ctx& cx, const int p, sf_
     dst[n] = v;
   }
 }
+#endif
 
 #if !SF_DENSE_STREAM
 // One step: plane p (in `regs`) goes to slot PH, the loads of plane p + 1 are issued, output plane
@@ -210,132 +296,113 @@ __device__ __forceinline__ void sf_step(sf_t* lds, sf_pair (&regs)[SF_NLOADS], s
   }
 #endif
 }
-
 #endif  // !SF_DENSE_STREAM
 
 #if SF_DENSE_STREAM
-// One step of the streaming form: plane p (in `regs`) goes to LDS slot `slot`, the loads of plane p + 1 are issued,
-// the plane is added to the open output planes (set of output plane q: (q - p_begin) mod 5, so with
-// PH = (p - p_begin) mod 5 the plane at offset di belongs to set (PH - di) mod 5), output plane p - SFD_DLAST is
-// finished and stored.
-template <int PH>
-__device__ __forceinline__ void sf_step_stream(sf_t* lds, sf_pair (&regs)[SF_NLOADS], sf_t* __restrict__ out,
-                                               const sf_scalars& sc, const sf_ctx& cx, const int p, const int p_end,
-                                               const int slot, sf_dense::acc_t (&acc)[SF_ACCS][SF_RJ][SF_VK]) {
-  sf_t* sl = lds + slot * SF_SLOT_ELEMS;
-  if constexpr (!(SF_WHATIF & 2)) {
-#pragma unroll
-    for (int n = 0; n < SF_NLOADS; ++n)  // (only the last round of pairs can run out of pairs)
-      if (n < SF_NLOADS - 1 || cx.ld_lds[n] >= 0) *reinterpret_cast<sf_pair*>(&sl[cx.ld_lds[n]]) = regs[n];
-  }
-#if SF_DENSE_LOAD_EARLY
-  // requested before the barrier (the LDS writes above have taken their operands): the wait at the barrier is part of
-  // the time the loads have to land
-  if constexpr (!(SF_WHATIF & 8)) sf_load_plane(cx, p + 1, regs, p + 1 < p_end);
-  if constexpr (!(SF_WHATIF & 1)) __syncthreads();  // (two slots: the waves still reading the other slot are at most one step behind)
-#else
-  if constexpr (!(SF_WHATIF & 1)) __syncthreads();  // (two slots: the waves still reading the other slot are at most one step behind)
-  if constexpr (!(SF_WHATIF & 8)) sf_load_plane(cx, p + 1, regs, p + 1 < p_end);  // lands during the evaluation below
+#if !SF_DMA
+#error "the streaming forms take their planes by LDS-DMA (SF_IN_SLOTS >= 1)"
 #endif
-  sf_dense::template accumulate<PH>(sl + cx.tb, acc);
-  // the sums are complete HERE: left alone, the compiler sinks the adds of an output plane towards the step that
-  // finishes it and keeps the operands -- whole planes of the patch -- alive until then (244 registers instead of ~100)
+// the accumulators are complete HERE: left alone, the compiler sinks the adds of an output plane towards the step that
+// finishes it and keeps the operands -- whole planes of the patch -- alive until then (244 registers instead of ~100)
+template <typename A>
+__device__ __forceinline__ void sf_pin(A (&acc)[SF_ACCS][SF_RJ][SF_VK]) {
 #pragma unroll
   for (int a = 0; a < SF_ACCS; ++a)
 #pragma unroll
     for (int r = 0; r < SF_RJ; ++r)
 #pragma unroll
       for (int v = 0; v < SF_VK; ++v) asm volatile("" : "+v"(acc[a][r][v]));
-  const int q = p - SFD_DLAST;
+}
+
+__device__ __forceinline__ void sf_store_rows(const sf_t (&rows)[SF_RJ][SF_VK], sf_t* __restrict__ out, const sf_ctx& cx, const int q) {
   const bool store_plane = q >= cx.cb && q < cx.ce && (q + cx.goff >= 0) && (q + cx.goff < SF_N0G);
   char* base = reinterpret_cast<char*>(out) + (long long)(q + cx.halo) * (long long)SF_PLANE_BYTES;
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(base, 0, store_plane ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
-  sf_t rows[SF_RJ][SF_VK];
-  sf_dense::finish(sc, acc[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
 #pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) {
+  for (int r = 0; r < SF_RJ; ++r) {  // (always SF_RJ store instructions per step: the counted waits rely on it)
     sf_vec o;
 #pragma unroll
     for (int v = 0; v < SF_VK; ++v) o[v] = rows[r][v];
-    if constexpr ((SF_WHATIF & 16) != 0) asm volatile("" : : "v"(o), "s"(rs));
-    else sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
+    sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
   }
+}
+
+#endif  // SF_DENSE_STREAM
+
+#if SF_DENSE_STREAM && !SF_DENSE_T2
+// One step of the streaming form.  Input plane p has been requested SF_AHEAD steps ago into slot `slot`; when it has
+// landed everywhere (wait, barrier) the slot that held plane p - 1 is free and plane p + SF_AHEAD is requested into it;
+// plane p is added to the open output planes (set of output plane q: (q - p_begin) mod ACCS, so with
+// PH = (p - p_begin) mod ACCS the plane at offset di belongs to set (PH - di) mod ACCS), output plane p - SFD_DLAST is
+// finished and stored.
+template <int PH>
+__device__ __forceinline__ void sf_step_stream(sf_t* lds, sf_t* __restrict__ out, const sf_scalars& sc, const sf_ctx& cx,
+                                               const int p, const int p_begin, const int p_end, const int slot,
+                                               sf_dense::acc_t (&acc)[SF_ACCS][SF_RJ][SF_VK]) {
+  // younger than plane p's pieces: the stores of the AHEAD steps since, the pieces of the AHEAD - 1 planes since
+  sf_wait_plane<(SF_AHEAD - 1) * SF_NDMIN + SF_AHEAD * SF_RJ>(p - p_begin < SF_AHEAD);
+  sf_t* sl = lds + slot * SF_SLOT_STRIDE;
+  sf_fix_boundary<sf_dense>(cx, p, p < p_end, sl);
+  sf_dma_plane(cx, p + SF_AHEAD, p + SF_AHEAD < p_end, (slot + SF_AHEAD) % SF_IN_SLOTS);
+  const sf_t* tb[SF_LAG + 1];  // the thread's patch of planes p, p - 1, .. p - LAG
+#pragma unroll
+  for (int l = 0; l <= SF_LAG; ++l) tb[l] = lds + ((slot + SF_IN_SLOTS - l) % SF_IN_SLOTS) * SF_SLOT_STRIDE + cx.tb;
+  sf_dense::template accumulate<PH>(tb, acc);
+  sf_pin(acc);
+  sf_t rows[SF_RJ][SF_VK];
+  sf_dense::finish(sc, acc[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
+  sf_store_rows(rows, out, cx, p - SFD_DLAST);
 }
 #endif
 
 #if SF_DENSE_T2
 // One step of the fused form.  PH = (p - p_begin) mod 3 names the accumulator sets as in sf_step_stream.  Operator 1
-// reads input plane p from slot `s0` of ring 0 and finishes its plane q1 = p - SFD_DLAST, which goes to ring 1 (slot
-// parity of q1); operator 2 reads the plane that went there in the PREVIOUS step (q1 - 1: this step's barrier has
-// made it visible) and finishes output plane q1 - 1 - SFD2_DLAST.
+// reads input plane p from slot `slot` of the input ring and finishes its plane q1 = p - SFD_DLAST, which goes to the
+// ring between the operators (slot parity of q1); operator 2 reads the plane that went there in the PREVIOUS step
+// (q1 - 1: this step's barrier has made it visible) and finishes output plane q1 - 1 - SFD2_DLAST.
+// Input ring of one slot (SF_IN_SLOTS 1): the next plane is requested in mid-step, behind a second barrier -- when
+// every wave has read the slot -- and lands while the second operator runs.
 template <int PH>
-__device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_pair (&regs)[SF_NLOADS], sf_t* __restrict__ out,
-                                           const sf_scalars& sc, const sf_ctx& cx, const int p, const int p_load_end,
-                                           const int s0, sf_dense::acc_t (&acc1)[SF_ACCS][SF_RJ][SF_VK],
+__device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, const sf_scalars& sc, const sf_ctx& cx,
+                                           const int p, const int p_begin, const int p_end, const int slot, const int s0,
+                                           sf_dense::acc_t (&acc1)[SF_ACCS][SF_RJ][SF_VK],
                                            sf_dense2::acc_t (&acc2)[SF_ACCS][SF_RJ][SF_VK]) {
-  // (requesting planes TWO steps ahead -- two register sets, the loop unrolled by six -- was measured: slower,
-  //  profiles/r04_dense_t2.log)
-  sf_t* in_slot = lds + (SF_T2_ONE_IN ? 0 : s0) * SF_SLOT_ELEMS;
-  if constexpr (SF_T2_ONE_IN != 0) __syncthreads();  // every wave has read the plane the slot held
-  if constexpr (!(SF_WHATIF & 2)) {
-#pragma unroll
-    for (int n = 0; n < SF_NLOADS; ++n)  // (only the last round of pairs can run out of pairs)
-      if (n < SF_NLOADS - 1 || cx.ld_lds[n] >= 0) *reinterpret_cast<sf_pair*>(&in_slot[cx.ld_lds[n]]) = regs[n];
-  }
-  if constexpr (!(SF_WHATIF & 1)) __syncthreads();
-  if constexpr (!(SF_WHATIF & 8)) sf_load_plane(cx, p + 1, regs, p + 1 < p_load_end);
+  if constexpr (SF_IN_SLOTS == 1) sf_wait_plane<SF_RJ>(p == p_begin);
+  else sf_wait_plane<(SF_AHEAD - 1) * SF_NDMIN + SF_AHEAD * SF_RJ>(p - p_begin < SF_AHEAD);
+  sf_t* in_slot = lds + slot * SF_SLOT_STRIDE;
+  sf_fix_boundary<sf_dense>(cx, p, p < p_end, in_slot);
+  if constexpr (SF_IN_SLOTS > 1) sf_dma_plane(cx, p + SF_AHEAD, p + SF_AHEAD < p_end, (slot + SF_AHEAD) % SF_IN_SLOTS);
   // ---- operator 1: plane p joins the open planes, plane q1 is finished and published
   sf_dense::template accumulate<PH>(in_slot + cx.tb, acc1);
-#pragma unroll
-  for (int a = 0; a < SF_ACCS; ++a)
-#pragma unroll
-    for (int r = 0; r < SF_RJ; ++r)
-#pragma unroll
-      for (int v = 0; v < SF_VK; ++v) asm volatile("" : "+v"(acc1[a][r][v]));
+  sf_pin(acc1);
+  if constexpr (SF_IN_SLOTS == 1) {
+    asm volatile("s_barrier" ::: "memory");  // every wave has read the slot
+    sf_dma_plane(cx, p + 1, p + 1 < p_end, 0);
+  }
   const int q1 = p - SFD_DLAST;
   const bool plane1_in = (q1 + cx.goff >= 0) && (q1 + cx.goff < SF_N0G);
   sf_t mid[SF_RJ][SF_VK];
   sf_dense::finish(sc, acc1[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], mid);
   const int mid_par = (s0 + 2 - SFD_DLAST) & 1;
-  sf_t* mid_w = lds + (SF_MID0 + mid_par) * SF_SLOT_ELEMS + cx.tb + SF_RJH * SF_LS + SF_RC;
+  sf_t* mid_w = lds + (SF_MID0 + mid_par) * SF_SLOT_STRIDE + cx.tb + SF_RJH * SF_LS + SF_RC;
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     // outside the global domain operator 2 reads ITS boundary constant
     const bool row_in = plane1_in && ((cx.jmask >> r) & 1u);
+    sf_vec w;
 #pragma unroll
-    for (int v = 0; v < SF_VK; v += 2) {
-      sf_pair w;
-      w[0] = (row_in && ((cx.kmask >> v) & 1u)) ? mid[r][v] : sf_dense2::bc();
-      w[1] = (row_in && ((cx.kmask >> (v + 1)) & 1u)) ? mid[r][v + 1] : sf_dense2::bc();
-      *reinterpret_cast<sf_pair*>(&mid_w[r * SF_LS + v]) = w;
-    }
+    for (int v = 0; v < SF_VK; ++v) w[v] = (row_in && ((cx.kmask >> v) & 1u)) ? mid[r][v] : sf_dense2::bc();
+    *reinterpret_cast<sf_vec*>(&mid_w[r * SF_LS]) = w;  // (the thread's own columns: 16-byte aligned)
   }
   // ---- operator 2 on the plane published a step ago
   constexpr int PH2 = (PH - SFD_DLAST - 1 + 2 * SF_ACCS) % SF_ACCS;
-  const sf_t* mid_r = lds + (SF_MID0 + (mid_par ^ 1)) * SF_SLOT_ELEMS + cx.tb;
+  const sf_t* mid_r = lds + (SF_MID0 + (mid_par ^ 1)) * SF_SLOT_STRIDE + cx.tb;
   sf_dense2::template accumulate<PH2>(mid_r, acc2);
-#pragma unroll
-  for (int a = 0; a < SF_ACCS; ++a)
-#pragma unroll
-    for (int r = 0; r < SF_RJ; ++r)
-#pragma unroll
-      for (int v = 0; v < SF_VK; ++v) asm volatile("" : "+v"(acc2[a][r][v]));
-  const int q2 = q1 - 1 - SFD2_DLAST;
-  const bool store_plane = q2 >= cx.cb && q2 < cx.ce && (q2 + cx.goff >= 0) && (q2 + cx.goff < SF_N0G);
-  char* base = reinterpret_cast<char*>(out) + (long long)(q2 + cx.halo) * (long long)SF_PLANE_BYTES;
-  const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(base, 0, store_plane ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
+  sf_pin(acc2);
   sf_t rows[SF_RJ][SF_VK];
   sf_dense2::finish(sc, acc2[(PH2 - SFD2_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
-#pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) {
-    sf_vec o;
-#pragma unroll
-    for (int v = 0; v < SF_VK; ++v) o[v] = rows[r][v];
-    if constexpr ((SF_WHATIF & 16) != 0) asm volatile("" : : "v"(o), "s"(rs));
-    else sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
-  }
+  sf_store_rows(rows, out, cx, q1 - 1 - SFD2_DLAST);
 }
 #endif
 
@@ -343,7 +410,7 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, sf_auxptrs aux, int halo,
                    int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2) {
   (void)aux;
-  __shared__ sf_t lds[SF_SLOTS * SF_SLOT_ELEMS];
+  __shared__ __attribute__((aligned(1024))) sf_t lds[SF_SLOTS * SF_SLOT_STRIDE];
 
   sf_ctx cx;
   cx.in = in;
@@ -374,6 +441,21 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
 #else
   const int tj0 = SF_NOJ ? 0 : jt * SF_TJ, tk0 = kt * SF_TK;  // first output point of the tile
 #endif
+#if SF_DMA
+  // the chunks this thread requests of every plane (image order over the slot)
+  cx.wave = __builtin_amdgcn_readfirstlane((unsigned)tid >> 6);
+  cx.lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
+  cx.edge_tile = (tj0 - SF_RJH < 0) || (tj0 - SF_RJH + SF_LROWS > SF_N1) || (tk0 - SF_RCL < 0) || (tk0 - SF_RCL + SF_LS > SF_N2);
+#pragma unroll
+  for (int n = 0; n < SF_ND; ++n) {
+    const int c = (n * SF_NW + (tid >> 6)) * 64 + (tid & 63);
+    const int row = c / (SF_LS / SF_CE), col = (c - row * (SF_LS / SF_CE)) * SF_CE;
+    const int j = tj0 - SF_RJH + row, k = tk0 - SF_RCL + col;
+    // (N2 and the tile origin are multiples of the chunk: a chunk is inside or outside as a whole)
+    const bool inside = c < SF_NCH && j >= 0 && j < SF_N1 && k >= 0 && k + SF_CE <= SF_N2;
+    cx.ld_off[n] = inside ? (unsigned)((j * SF_N2 + k) * (int)sizeof(sf_t)) : SF_OOB;
+  }
+#else
   // the pairs this thread loads of every plane (row-major over the slot, pairs of columns)
 #pragma unroll
   for (int n = 0; n < SF_NLOADS; ++n) {
@@ -381,12 +463,12 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     const int row = pair / SF_PAIRS_PER_ROW, col = (pair - row * SF_PAIRS_PER_ROW) * 2;
     const int j = tj0 - SF_RJH + row, k = tk0 - SF_RC + col;
     const bool mine = pair < SF_PAIRS;
-    // (N2 is a multiple of 4 and R even or the tile origin a multiple of 4: a pair is inside or outside as a whole
-    //  for R = 2; for R = 1 the pair straddles the edge -- R is always 2 here, codegen enforces it)
+    // (N2 is a multiple of 4 and R even or the tile origin a multiple of 4: a pair is inside or outside as a whole)
     const bool inside = mine && j >= 0 && j < SF_N1 && k >= 0 && k + 1 < SF_N2;
     cx.ld_off[n] = inside ? (unsigned)((j * SF_N2 + k) * (int)sizeof(sf_t)) : SF_OOB;
     cx.ld_lds[n] = mine ? row * SF_LS + col : -1;
   }
+#endif
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     const int j = tj0 + (SF_NOJ ? 0 : ty * SF_RJ + r), k = tk0 + tx * SF_VK;
@@ -399,7 +481,7 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
 #endif
     cx.st_off[r] = inside ? (unsigned)((j * SF_N2 + k) * (int)sizeof(sf_t)) : SF_OOB;
   }
-  cx.tb = (SF_NOJ ? 0 : ty * SF_RJ) * SF_LS + tx * SF_VK;
+  cx.tb = (SF_NOJ ? 0 : ty * SF_RJ) * SF_LS + tx * SF_VK + (SF_RCL - SF_RC);
   cx.j0 = tj0 + (SF_NOJ ? 0 : ty * SF_RJ);
   cx.k0 = tk0 + tx * SF_VK;
 #if SF_DENSE_T2
@@ -411,16 +493,15 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   for (int v = 0; v < SF_VK; ++v) cx.kmask |= ((cx.k0 + v >= 0 && cx.k0 + v < SF_N2) ? 1u : 0u) << v;
 #endif
 
-  // input planes [p_begin, p_end) are read; step p writes plane p into slot (p - p_begin) mod 6
+  // input planes [p_begin, p_end) are read
   const int p_begin = cx.cb - SF_R, p_end = cx.ce + SF_R;
-  sf_pair regs[SF_NLOADS];
-  sf_load_plane(cx, p_begin, regs, true);
   // the slots of planes before p_begin are never read for a stored plane: the first stored plane is
   // cb = p_begin + R, whose oldest operand plane is p_begin
 #if SF_DENSE_T2
-  // ring 1 starts out as the second operator's boundary constant: its halo rows and columns are never written again
-  // (they are right where the tile touches the edge of the domain; elsewhere the results that read them are not stored)
-  for (int i = tid; i < 2 * SF_SLOT_ELEMS; i += SF_THREADS) lds[SF_MID0 * SF_SLOT_ELEMS + i] = sf_dense2::bc();
+  // the ring between the operators starts out as the second operator's boundary constant: its halo rows and columns
+  // are never written again (they are right where the tile touches the edge of the domain; elsewhere the results
+  // that read them are not stored)
+  for (int i = tid; i < 2 * SF_SLOT_STRIDE; i += SF_THREADS) lds[SF_MID0 * SF_SLOT_STRIDE + i] = sf_dense2::bc();
   sf_dense::acc_t acc1[SF_ACCS][SF_RJ][SF_VK];
   sf_dense2::acc_t acc2[SF_ACCS][SF_RJ][SF_VK];
 #pragma unroll
@@ -432,14 +513,19 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
         acc1[a][r][v] = (sf_dense::acc_t)0;
         acc2[a][r][v] = (sf_dense2::acc_t)0;
       }
+#pragma unroll
+  for (int a = 0; a < SF_AHEAD; ++a) sf_dma_plane(cx, p_begin + a, p_begin + a < p_end, a % SF_IN_SLOTS);
   // output plane q2 leaves at step q2 + SFD_DLAST + 1 + SFD2_DLAST; input planes up to ce + R - 1 are read
   const int p_stop = cx.ce + SFD_DLAST + 1 + SFD2_DLAST;
+  int slot = 0;
   for (int p = p_begin; p < p_stop; p += SF_ACCS) {
     const int s0 = (p - p_begin) & 1;  // three steps per trip: the slot parity alternates from trip to trip
-    sf_step_t2<0>(lds, regs, out, sc, cx, p, p_end, s0, acc1, acc2);
-    sf_step_t2<1>(lds, regs, out, sc, cx, p + 1, p_end, s0 ^ 1, acc1, acc2);
-    sf_step_t2<2>(lds, regs, out, sc, cx, p + 2, p_end, s0, acc1, acc2);
+    sf_step_t2<0>(lds, out, sc, cx, p, p_begin, p_end, slot, s0, acc1, acc2);
+    sf_step_t2<1>(lds, out, sc, cx, p + 1, p_begin, p_end, (slot + 1) % SF_IN_SLOTS, s0 ^ 1, acc1, acc2);
+    sf_step_t2<2>(lds, out, sc, cx, p + 2, p_begin, p_end, (slot + 2) % SF_IN_SLOTS, s0, acc1, acc2);
+    slot = (slot + 3) % SF_IN_SLOTS;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (requests of planes nobody reads: landed before the LDS is given back)
 #elif SF_DENSE_STREAM
   // (an output plane before cb collects planes that were never added to it: it is not stored; the first stored plane
   //  cb = p_begin + R opens at step p_begin + R + d0 >= p_begin, with the first term of the text -- an assignment)
@@ -450,19 +536,25 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     for (int r = 0; r < SF_RJ; ++r)
 #pragma unroll
       for (int v = 0; v < SF_VK; ++v) acc[a][r][v] = (sf_dense::acc_t)0;
+#pragma unroll
+  for (int a = 0; a < SF_AHEAD; ++a) sf_dma_plane(cx, p_begin + a, p_begin + a < p_end, a % SF_IN_SLOTS);
+  int slot = 0;
   for (int p = p_begin; p < p_end; p += SF_ACCS) {
-    const int s0 = (p - p_begin) & 1;  // an odd number of steps per trip: the slot parity alternates from trip to trip
-    sf_step_stream<0>(lds, regs, out, sc, cx, p, p_end, s0, acc);
-    sf_step_stream<1>(lds, regs, out, sc, cx, p + 1, p_end, s0 ^ 1, acc);
-    sf_step_stream<2>(lds, regs, out, sc, cx, p + 2, p_end, s0, acc);
-    sf_step_stream<3>(lds, regs, out, sc, cx, p + 3, p_end, s0 ^ 1, acc);
-    sf_step_stream<4>(lds, regs, out, sc, cx, p + 4, p_end, s0, acc);
+    sf_step_stream<0>(lds, out, sc, cx, p, p_begin, p_end, slot, acc);
+    sf_step_stream<1>(lds, out, sc, cx, p + 1, p_begin, p_end, (slot + 1) % SF_IN_SLOTS, acc);
+    sf_step_stream<2>(lds, out, sc, cx, p + 2, p_begin, p_end, (slot + 2) % SF_IN_SLOTS, acc);
+    sf_step_stream<3>(lds, out, sc, cx, p + 3, p_begin, p_end, (slot + 3) % SF_IN_SLOTS, acc);
+    sf_step_stream<4>(lds, out, sc, cx, p + 4, p_begin, p_end, (slot + 4) % SF_IN_SLOTS, acc);
 #if SF_ACCS == 7
-    sf_step_stream<5>(lds, regs, out, sc, cx, p + 5, p_end, s0 ^ 1, acc);
-    sf_step_stream<6>(lds, regs, out, sc, cx, p + 6, p_end, s0, acc);
+    sf_step_stream<5>(lds, out, sc, cx, p + 5, p_begin, p_end, (slot + 5) % SF_IN_SLOTS, acc);
+    sf_step_stream<6>(lds, out, sc, cx, p + 6, p_begin, p_end, (slot + 6) % SF_IN_SLOTS, acc);
 #endif
+    slot = (slot + SF_ACCS) % SF_IN_SLOTS;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (requests of planes nobody reads: landed before the LDS is given back)
 #else
+  sf_pair regs[SF_NLOADS];
+  sf_load_plane(cx, p_begin, regs, true);
   for (int p = p_begin; p < p_end; p += SF_SLOTS) {
     sf_step<0>(lds, regs, out, sc, cx, p, p_end);
     sf_step<1>(lds, regs, out, sc, cx, p + 1, p_end);

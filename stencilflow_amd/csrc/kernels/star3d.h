@@ -67,27 +67,6 @@
 #define SF_DAG 0
 #endif
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
-// SF_WIDE (2-D, one wave per block, float fields whose operators are typed double): the register windows hold the
-// values ALREADY CONVERTED to double.  A value is read by up to three steps and four neighbours; kept as float it is
-// converted at every use (4.0 v_cvt_f64_f32 per update in the C2 loop), kept as double once when it enters the
-// window (a float widens exactly: the results are the same bits).  Twice the window registers -- which the 2-D
-// kernels have -- and two DPP moves per lane-edge value instead of one.
-#ifndef SF_WIDE
-#define SF_WIDE 0
-#endif
-#if SF_WIDE
-typedef double sf_wt;
-#else
-typedef sf_t sf_wt;
-#endif
-typedef sf_wt sf_wvec __attribute__((ext_vector_type(SF_VK)));
-__device__ __forceinline__ sf_wvec sf_widen(const sf_vec v) {
-#if SF_WIDE
-  return __builtin_convertvector(v, sf_wvec);
-#else
-  return v;
-#endif
-}
 // the fields a launch materialises (argument `out` is p[0]; further outputs of a DAG group follow in `more`)
 struct sf_outptrs {
   sf_t* p[SF_NOUT > 0 ? SF_NOUT : 1];
@@ -96,23 +75,8 @@ struct sf_more_outs {
   void* p[SF_NOUT > 1 ? SF_NOUT - 1 : 1];
 };
 
-#ifndef SF_REVERSE
-#define SF_REVERSE 0
-#endif
-#ifndef SF_PFD
-#define SF_PFD 1
-#endif
-#ifndef SF_UNIFORM
-#define SF_UNIFORM 0
-#endif
 #ifndef SF_AUX_AHEAD
 #define SF_AUX_AHEAD 0
-#endif
-#ifndef SF_UNIFORM_LOADS
-#define SF_UNIFORM_LOADS 0
-#endif
-#ifndef SF_BUFFER_IO
-#define SF_BUFFER_IO 0
 #endif
 // SF_SKIP_ROWS: a stage does not evaluate the rows of the tile's halo that no later stage reads.  Stage S of T
 // is read back through S' > S stages of reach one row each, so of the SF_TJH rows of a tile only rows
@@ -120,12 +84,7 @@ struct sf_more_outs {
 // the thread row, which is the same for all lanes of a wave: a scalar branch around the row's arithmetic.  Only the
 // first and last thread rows of a block skip anything -- with 2 waves per thread row and 4 thread rows each SIMD holds
 // one such wave, so every SIMD issues (RJ - S) instead of RJ rows per stage for one of its two waves.
-#ifndef SF_SKIP_ROWS
-#define SF_SKIP_ROWS 0
-#endif
 // (diagnostic values: 2 = buffer loads only, 3 = buffer stores only)
-#define SF_BIO_LOADS (SF_BUFFER_IO == 1 || SF_BUFFER_IO == 2)
-#define SF_BIO_STORES (SF_BUFFER_IO == 1 || SF_BUFFER_IO == 3)
 
 // SF_BUFFER_IO: planes are read and written with buffer instructions whose
 // resource describes exactly one plane.  A lane (or a whole row, or -- with zero
@@ -142,18 +101,11 @@ typedef unsigned sf_u4 __attribute__((ext_vector_type(4)));
 #define SF_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format (gfx9 / CDNA) */
 typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 
-#if SF_REVERSE  // loads are issued at the end of the step: no staging registers
-#undef SF_PREFETCH2
-#define SF_PREFETCH2 0
-#undef SF_SPREAD_LOADS
-#define SF_SPREAD_LOADS 0
-#endif
 
 // window slots per stage and period of the phase rotation
 // (SF_PREFETCH2 3: a FIVE-slot input ring, two planes in flight -- a load has three steps to land; the step
 // loop is unrolled by five.  SF_RING4 names the ring forms, SF_INFLIGHT the planes in flight beside the window.)
-#define SF_RING4 (SF_PREFETCH2 >= 2)
-#define SF_INFLIGHT (SF_PREFETCH2 == 3 ? 2 : (SF_PREFETCH2 == 2 ? 1 : 0))
+#define SF_INFLIGHT (SF_RING4 ? 1 : 0)
 #define SF_SLOTS (3 + SF_INFLIGHT)
 
 #define SF_TJH (SF_BY * SF_RJ)
@@ -177,7 +129,7 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 // (SF_DPP 4: one virtual wave below and one above every row hold the boundary
 // constant, so a wave reads its neighbours' edge columns without testing whether
 // they exist)
-#define SF_VWAVES (SF_DPP == 4 && SF_WPR > 1)
+#define SF_VWAVES (4 == 4 && SF_WPR > 1)
 #define SF_EDGE_WAVES (SF_VWAVES ? SF_WPR + 2 : SF_WPR)
 #define SF_EDGE_ELEMS (SF_NW * SF_BY * SF_RJ * SF_EDGE_WAVES * 2)
 #define SF_IMAGE_ELEMS (SF_ROWS_ELEMS + SF_EDGE_ELEMS)
@@ -205,12 +157,7 @@ struct sf_state
     : sf_auxslots<SF_NS>
 #endif
 {
-  sf_wvec w[SF_NW][SF_SLOTS][SF_RJ];
-#if SF_REVERSE == 2 || SF_PREFETCH2 == 1
-  // input planes in flight: a ring of SF_PFD (1 or 3) planes, so a load has
-  // SF_PFD full steps to land (slot = phase % SF_PFD)
-  sf_vec pf[SF_PFD][SF_RJ];
-#endif
+  sf_vec w[SF_NW][SF_SLOTS][SF_RJ];
 };
 
 #ifndef SF_AUX_PASS
@@ -232,14 +179,9 @@ struct sf_ctx {
   bool kvec_in;
   bool tile_inside;  // block-uniform: every point of the tile lies in the (j,k) domain
   int goff, halo, cb, ce, j0, k0;
-#if SF_SKIP_ROWS
-  unsigned need_rows[SF_NS];  // wave-uniform: bit r set = stage s + 1 evaluates row r of this thread row
-#endif
-#if SF_BUFFER_IO
   // byte offset of this lane's vector in row r of a plane, or SF_OOB where the
   // lane must not load (outside the (j,k) domain) / store (halo rows and columns)
   unsigned ld_off[SF_RJ], st_off[SF_RJ];
-#endif
 #if SF_NT & 4
   unsigned nt_rows;  // wave-uniform: bit r set = row r of this thread row is read by this block only
 #endif
@@ -258,11 +200,9 @@ __device__ __forceinline__ int sf_edge_at(int s, int ty, int r, int w, int side)
 // no trip through the LDS crossbar that __shfl_up/__shfl_down (ds_bpermute) take.
 template <bool FROM_LOWER, typename T>
 __device__ __forceinline__ T sf_neighbour_lane(T x) {
-#if SF_DPP
   constexpr int ctrl = FROM_LOWER ? 0x138 /* wave_shr:1 */ : 0x130 /* wave_shl:1 */;
   if constexpr (sizeof(T) == 4) {
     const int v = __builtin_bit_cast(int, x);
-#if SF_DPP >= 2
     // bound_ctrl: lanes without a source read 0 and nothing of the old value is
     // kept, so no copy precedes the DPP move (the caller replaces lane 0 / 63)
     // (the result is made opaque: LLVM's DPP combiner otherwise folds the move into
@@ -270,25 +210,14 @@ __device__ __forceinline__ T sf_neighbour_lane(T x) {
     int moved = __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
     asm volatile("" : "+v"(moved));
     return __builtin_bit_cast(T, moved);
-#else
-    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false));
-#endif
   } else {
     const long long v = __builtin_bit_cast(long long, x);
     const int lo = (int)(v & 0xffffffffll), hi = (int)(v >> 32);
-#if SF_DPP >= 2
     int rlo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, true);
     int rhi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, true);
     asm volatile("" : "+v"(rlo), "+v"(rhi));
-#else
-    const int rlo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false);
-    const int rhi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);
-#endif
     return __builtin_bit_cast(T, ((long long)rhi << 32) | (unsigned int)rlo);
   }
-#else
-  return FROM_LOWER ? __shfl_up(x, 1) : __shfl_down(x, 1);
-#endif
 }
 
 // As above, but lanes without a source (lane 0 when taking from the lower lane,
@@ -350,18 +279,17 @@ __device__ __forceinline__ void sf_buf_store(const V v, const __amdgpu_buffer_rs
 __device__ __forceinline__ bool sf_row_ok(const sf_ctx& cx, const int p, const int r) {
   const bool plane_in = (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
   // SF_EXPERIMENT 5: timing-only build without the input loads (invalid results)
-  return SF_EXPERIMENT != 5 && plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in;
+  return plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in;
 }
 
 // Row r of input plane p (padded with stage 1's boundary constant outside the
 // global domain).
 __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, const int r,
                                               const bool enabled = true) {
-#if SF_BIO_LOADS
   // wave-uniform: a plane outside the global domain (or a load the caller has
   // switched off) gets a resource of zero records
   const bool plane_ok =
-      enabled && SF_EXPERIMENT != 5 && (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
+      enabled && (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
   const char* base = reinterpret_cast<const char*>(cx.in) + (long long)(p + cx.halo) * (long long)SF_PLANE_BYTES;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(base), 0, plane_ok ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
@@ -381,47 +309,11 @@ __device__ __forceinline__ sf_vec sf_load_row(const sf_ctx& cx, const int p, con
     for (int e = 0; e < SF_VK; ++e) v[e] = ok ? v[e] : sf_win<0>::bc();
   }
   return v;
-#else
-  (void)enabled;
-  const sf_t* plane = cx.in + (size_t)(p + cx.halo) * ((size_t)SF_N1 * SF_N2);
-  const sf_vec* src = reinterpret_cast<const sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0));
-#if SF_UNIFORM_LOADS
-  // Tiles strictly inside the (j,k) domain (block-uniform) have no lane to pad:
-  // the test left is the plane's, which is wave-uniform, so the load needs no
-  // execution mask and its destination no fill beforehand.
-  if (cx.tile_inside && SF_EXPERIMENT != 5) {
-    if ((p + cx.goff >= 0) && (p + cx.goff < SF_N0G)) {
-#if SF_NT & 2
-      return __builtin_nontemporal_load(src);
-#else
-      return *src;
-#endif
-    }
-    return (sf_vec)sf_win<0>::bc();
-  }
-#endif
-  sf_vec v = (sf_vec)sf_win<0>::bc();
-  if (sf_row_ok(cx, p, r)) {
-#if SF_NT & 2
-    v = __builtin_nontemporal_load(src);
-#else
-    v = *src;
-#endif
-  }
-  return v;
-#endif  // SF_BUFFER_IO
 }
 
 // `dst = row r of plane p` if `cond` (wave-uniform).  SF_BUFFER_IO: always issued,
 // with a resource of zero records when `cond` is false (dst then holds the padding).
-#if SF_BIO_LOADS
 #define SF_LOAD_ROW_IF(cond, dst, p, r) dst = sf_load_row(cx, p, r, cond)
-#else
-#define SF_LOAD_ROW_IF(cond, dst, p, r) \
-  do {                                  \
-    if (cond) dst = sf_load_row(cx, p, r); \
-  } while (0)
-#endif
 
 // Auxiliary values of stage S for row r of plane q: only planes this chunk's
 // stage S really evaluates are touched (the surplus steps of the last trip and
@@ -431,15 +323,10 @@ __device__ __forceinline__ typename sf_stage<S>::aux_row sf_aux_row(const sf_ctx
   const bool plane_ok = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G) && (q + cx.halo >= 0) &&
                         q >= cx.cb - (SF_T - sf_stage<S>::depth) && q < cx.ce + (SF_T - sf_stage<S>::depth);
   const bool row_ok = ((cx.jmask >> r) & 1u) != 0;
-#if SF_BIO_LOADS
   // never under a branch: a plane this stage does not evaluate has zero records
   // (fields lacking dimensions are indexed by the dimensions they have, under a guard)
   return sf_stage<S>::load_aux_bio(cx.aux, (long long)(q + cx.halo), plane_ok, cx.ld_off[r], SF_PLANE_BYTES,
                                    cx.j0 + r, cx.k0, row_ok, cx.kvec_in);
-#endif
-  return sf_stage<S>::load_aux(
-      cx.aux, (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2) + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0),
-      plane_ok && row_ok && cx.kvec_in, (long long)(q + cx.halo), cx.j0 + r, cx.k0, plane_ok, row_ok, cx.kvec_in);
 }
 
 #if SF_AUX_PASS
@@ -459,20 +346,10 @@ __device__ __forceinline__ sf_aux_passed sf_aux_take(const sf_ctx& cx, const int
 #endif
 
 __device__ __forceinline__ void sf_load_plane(const sf_t* __restrict__ in, const sf_ctx& cx,
-                                              const int p, sf_wvec (&dst)[SF_RJ], const bool enabled = true) {
+                                              const int p, sf_vec (&dst)[SF_RJ], const bool enabled = true) {
   (void)in;
-#if SF_WIDE
-  // (prologue only: the step loop loads into the float staging registers and widens on the copy)
-#pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) {
-    sf_vec v = (sf_vec)sf_win<0>::bc();
-    SF_LOAD_ROW_IF(enabled, v, p, r);
-    dst[r] = sf_widen(v);
-  }
-#else
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) SF_LOAD_ROW_IF(enabled, dst[r], p, r);
-#endif
 }
 
 // Stage 1 is done with row r of the input window's "prev" slot: the row takes its next plane.
@@ -485,12 +362,7 @@ __device__ __forceinline__ void sf_refill_row(sf_state& st, const sf_ctx& cx, co
   // it receives row r of the plane after the ones in flight (the next plane is already in flight in the fourth
   // slot -- the next two in the fourth and fifth), which has two (three) steps to land -- and nothing is copied
   SF_LOAD_ROW_IF(load_next, st.w[0][iprev][r], p + 1 + SF_INFLIGHT, r);
-#elif SF_PREFETCH2
-  // it takes row r of plane p+1 from the staging registers (loaded during the previous step),
-  // which then receive row r of plane p+2
-  st.w[0][iprev][r] = sf_widen(st.pf[PH % SF_PFD][r]);
-  SF_LOAD_ROW_IF(load_next, st.pf[PH % SF_PFD][r], p + 1 + SF_PFD, r);
-#elif SF_SPREAD_LOADS
+#else
   // it receives row r of input plane p+1 -- loads are spread over stage 1 instead of issued in a burst
   SF_LOAD_ROW_IF(load_next, st.w[0][iprev][r], p + 1, r);
 #endif
@@ -501,20 +373,19 @@ __device__ __forceinline__ void sf_refill_row(sf_state& st, const sf_ctx& cx, co
 template <int W, int PH>
 struct sf_rowsrc {
   static constexpr int iprev = PH % SF_SLOTS, icur = (PH + 1) % SF_SLOTS, inext = (PH + 2) % SF_SLOTS;
-  sf_wvec jm, jpl;  // the row above the one being evaluated; the first row of the thread row below
-#if SF_DPP == 4 && SF_WPR > 1
+  sf_vec jm, jpl;  // the row above the one being evaluated; the first row of the thread row below
+#if SF_WPR > 1
   sf_t e_lo[SF_RJ], e_hi[SF_RJ];
 #endif
-  sf_wvec c, im, ip, jp;  // of the current row
-  sf_wt km_e, kp_e;       // k-1 of the vector's first element, k+1 of its last
+  sf_vec c, im, ip, jp;  // of the current row
+  sf_t km_e, kp_e;       // k-1 of the vector's first element, k+1 of its last
 
   __device__ __forceinline__ void begin(const sf_state& st, const sf_t* lds, const sf_ctx& cx) {
     const int tx = cx.tx, ty = cx.ty;
     // first / last row of the neighbouring thread rows (LDS)
     jm = st.w[W][icur][0];
     jpl = st.w[W][icur][SF_RJ - 1];
-#if !SF_WIDE
-    if constexpr (!SF_NOJ && SF_EXPERIMENT != 4) {
+    if constexpr (!SF_NOJ) {
       // No test of the thread row: the first / last thread row of the tile reads an image that
       // exists (its own) -- rows 0 and SF_RJ-1 there are halo rows, whatever they take as their
       // outer neighbour never reaches a stored value.  A divergent `if` here was the construct on
@@ -522,8 +393,7 @@ struct sf_rowsrc {
       jm = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(W, ty > 0 ? ty - 1 : 0, 1) + tx * SF_VK]);
       jpl = *reinterpret_cast<const sf_vec*>(&lds[sf_rows_at(W, ty < SF_BY - 1 ? ty + 1 : ty, 0) + tx * SF_VK]);
     }
-#endif
-#if SF_DPP == 4 && SF_WPR > 1
+#if SF_WPR > 1
 #pragma unroll
     for (int r = 0; r < SF_RJ; ++r) {
       e_lo[r] = lds[sf_edge_at(W, ty, r, cx.wave - 1, 1)];
@@ -541,48 +411,29 @@ struct sf_rowsrc {
     ip = st.w[W][inext][r];
     jp = (r < SF_RJ - 1) ? st.w[W][icur][r < SF_RJ - 1 ? r + 1 : r] : jpl;
     // innermost-dimension halo: adjacent lanes hold the adjacent vectors
-    // SF_EXPERIMENT 3: timing-only build without the lane exchange (invalid results)
-#if SF_DPP == 4 && SF_WPR > 1
+#if SF_WPR > 1
     // Lanes 0 / 63 take the neighbouring wave's edge column -- or, from the
     // virtual waves beside the row, the boundary constant -- as the DPP move's
     // starting destination: no test, no select (the words were read before the
     // first row, see e_lo / e_hi).
     km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], e_lo[r]);
     kp_e = sf_neighbour_lane_or<false>(c[0], e_hi[r]);
-#elif SF_DPP >= 3
-    // Lanes 0 / 63 have no source lane.  Their value is the neighbouring wave's
-    // edge column (LDS, every lane reads the same word) or the boundary constant the
-    // window's readers declare; it is handed to the DPP move as the starting destination, so no
-    // select follows -- and a boundary constant of +0 is what bound_ctrl writes.
-    const int ty = cx.ty;
-    if (SF_WPR > 1 && cx.wave > 0)
-      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], (sf_wt)lds[sf_edge_at(W, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]);
-    else if (sf_win<W>::bc_zero)
-      km_e = sf_neighbour_lane<true>(c[SF_VK - 1]);
-    else
-      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], (sf_wt)sf_win<W>::bc());
-    if (SF_WPR > 1 && cx.wave < SF_WPR - 1)
-      kp_e = sf_neighbour_lane_or<false>(c[0], (sf_wt)lds[sf_edge_at(W, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]);
-    else if (sf_win<W>::bc_zero)
-      kp_e = sf_neighbour_lane<false>(c[0]);
-    else
-      kp_e = sf_neighbour_lane_or<false>(c[0], (sf_wt)sf_win<W>::bc());
 #else
-    const int ty = cx.ty;
-    km_e = (SF_EXPERIMENT == 3) ? c[SF_VK - 1] : sf_neighbour_lane<true>(c[SF_VK - 1]);
-    kp_e = (SF_EXPERIMENT == 3) ? c[0] : sf_neighbour_lane<false>(c[0]);
-    if (SF_EXPERIMENT != 3 && cx.lane == 0)
-      km_e = (SF_WPR > 1 && cx.wave > 0)
-                 ? (sf_wt)lds[sf_edge_at(W, ty, r, cx.wave > 0 ? cx.wave - 1 : 0, 1)]
-                 : (sf_wt)sf_win<W>::bc();
-    if (SF_EXPERIMENT != 3 && cx.lane == 63)
-      kp_e = (SF_WPR > 1 && cx.wave < SF_WPR - 1)
-                 ? (sf_wt)lds[sf_edge_at(W, ty, r, cx.wave < SF_WPR - 1 ? cx.wave + 1 : cx.wave, 0)]
-                 : (sf_wt)sf_win<W>::bc();
+    // One wave per row: lanes 0 / 63 have no source lane.  Their value is the boundary constant the window's
+    // readers declare; it is handed to the DPP move as the starting destination, so no select follows -- and a
+    // boundary constant of +0 is what bound_ctrl writes.
+    (void)lds;
+    if (sf_win<W>::bc_zero) {
+      km_e = sf_neighbour_lane<true>(c[SF_VK - 1]);
+      kp_e = sf_neighbour_lane<false>(c[0]);
+    } else {
+      km_e = sf_neighbour_lane_or<true>(c[SF_VK - 1], (sf_t)sf_win<W>::bc());
+      kp_e = sf_neighbour_lane_or<false>(c[0], (sf_t)sf_win<W>::bc());
+    }
 #endif
   }
-  __device__ __forceinline__ sf_wt km(const int v) const { return (v > 0) ? c[v > 0 ? v - 1 : 0] : km_e; }
-  __device__ __forceinline__ sf_wt kp(const int v) const { return (v < SF_VK - 1) ? c[v < SF_VK - 1 ? v + 1 : v] : kp_e; }
+  __device__ __forceinline__ sf_t km(const int v) const { return (v > 0) ? c[v > 0 ? v - 1 : 0] : km_e; }
+  __device__ __forceinline__ sf_t kp(const int v) const { return (v < SF_VK - 1) ? c[v < SF_VK - 1 ? v + 1 : v] : kp_e; }
   // a row that is not evaluated still is the next row's j-neighbour
   __device__ __forceinline__ void skip(const sf_state& st, const int r) { jm = st.w[W][icur][r]; }
   __device__ __forceinline__ void next() { jm = c; }
@@ -606,9 +457,8 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
   A.begin(st, lds, cx);
   sf_rowsrc<(joins ? src2 : src), PH> B;
   if constexpr (joins) B.begin(st, lds, cx);
-  // plane this stage produces (local owned coords).  SF_REVERSE: every stage
-  // reads only planes finished in earlier steps, so a stage of depth d lags 2d-1 steps.
-  const int q = SF_REVERSE ? p - (2 * depth - 1) : p - depth;
+  // plane this stage produces (local owned coords)
+  const int q = p - depth;
   const bool plane_in = (q + cx.goff >= 0) && (q + cx.goff < SF_N0G);
   const bool store_plane = (stage::out >= 0) && q >= cx.cb && q < cx.ce && plane_in;
   sf_t pad = (sf_t)0;
@@ -645,16 +495,6 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
 #endif
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
-#if SF_SKIP_ROWS
-    // a halo row no later stage reads (wave-uniform test: a scalar branch); the row above still is this
-    // row's j-neighbour, and the input window still moves on
-    if (!((cx.need_rows[S - 1] >> r) & 1u)) {
-      A.skip(st, r);
-      if constexpr (joins) B.skip(st, r);
-      if constexpr (stage::refill) sf_refill_row<PH>(st, cx, p, r, load_next);
-      continue;
-    }
-#endif
     A.row(st, lds, cx, r);
     if constexpr (joins) B.row(st, lds, cx, r);
     // centre-only auxiliary fields of this stage, row r of plane q
@@ -689,30 +529,13 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
     if constexpr (stage::refill) sf_refill_row<PH>(st, cx, p, r, load_next);
     if constexpr (stage::out >= 0) {
       // a materialised field: write interior, in-domain points
-      // SF_EXPERIMENT 1: timing-only build without the output stores (invalid results)
       sf_t* __restrict__ out = outs.p[stage::out >= 0 ? stage::out : 0];
-      if (SF_EXPERIMENT == 1) asm volatile("" ::"v"(o));
-#if SF_BIO_STORES
-      {
-        // always issued: a plane that is not stored has a resource of zero records,
-        // rows and lanes that are not stored an offset outside the plane
-        char* base = reinterpret_cast<char*>(out) + (long long)(q + cx.halo) * (long long)SF_PLANE_BYTES;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            base, 0, (SF_EXPERIMENT != 1 && store_plane) ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
-        sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
-      }
-      if (false) {
-#else
-      if (SF_EXPERIMENT != 1 && store_plane && ((cx.store_mask >> r) & 1u)) {
-#endif
-        // wave-uniform plane base (SGPR pair) + 32-bit in-plane offset
-        sf_t* plane = out + (size_t)(q + cx.halo) * ((size_t)SF_N1 * SF_N2);
-#if SF_NT & 1
-        __builtin_nontemporal_store(o, reinterpret_cast<sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)));
-#else
-        *reinterpret_cast<sf_vec*>(plane + (unsigned)((cx.j0 + r) * SF_N2 + cx.k0)) = o;
-#endif
-      }
+      // always issued: a plane that is not stored has a resource of zero records,
+      // rows and lanes that are not stored an offset outside the plane
+      char* base = reinterpret_cast<char*>(out) + (long long)(q + cx.halo) * (long long)SF_PLANE_BYTES;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          base, 0, store_plane ? SF_PLANE_BYTES : 0u, SF_RSRC_FLAGS);
+      sf_buf_store<sf_vec, (SF_NT & 1) ? 2 : 0>(o, rs, cx.st_off[r]);
     }
     if constexpr (dst >= 0) {
       // pad: outside the global domain the readers of this window must read THEIR constant
@@ -722,9 +545,8 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
 #pragma unroll
         for (int v = 0; v < SF_VK; ++v) o[v] = (row_in && ((cx.kmask >> v) & 1u)) ? o[v] : pad;
       }
-      // becomes plane "next" of the window.  SF_REVERSE: its reader ran earlier in
-      // this step and is done with the slot that held its plane "prev".
-      st.w[dst >= 0 ? dst : 0][SF_REVERSE ? iprev : inext][r] = sf_widen(o);
+      // becomes plane "next" of the window
+      st.w[dst >= 0 ? dst : 0][inext][r] = o;
     }
 #if SF_ROW_FENCE
     __builtin_amdgcn_sched_barrier(0);  // rows in order: bounds the live f64 temporaries
@@ -732,46 +554,19 @@ __device__ __forceinline__ void sf_stage_step(sf_state& st, const sf_t* lds, con
   }
 }
 
-#if SF_STAMP
-// Diagnostic build only (option stamp=1): where a step spends its cycles.
-// acc[0] publish + barrier, [1] stage 1 (incl. wait for the input plane),
-// [2] issue of the next plane's loads, [3] later stages.
-#define SF_STAMP_AT(i)                                                              \
-  do {                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                              \
-    unsigned long long t_;                                                          \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
-    __builtin_amdgcn_sched_barrier(0);                                              \
-    acc[i] += t_ - t_prev;                                                          \
-    t_prev = t_;                                                                    \
-  } while (0)
-#define SF_STAMP_ARGS , unsigned long long (&acc)[4], unsigned long long& t_prev
-#define SF_STAMP_PASS , acc, t_prev
-#else
-#define SF_STAMP_AT(i)
-#define SF_STAMP_ARGS
-#define SF_STAMP_PASS
-#endif
-
 // stages S, S + 1, ..., SF_NS in order (every stage after the ones it reads); the stage that is the last reader of
 // the input window also moves that window on (codegen: sf_stage<S>::refill -- stage 1 of a chain)
 template <int S, int PH>
 __device__ __forceinline__ void sf_stages_from(sf_state& st, const sf_t* lds, const sf_t* __restrict__ in,
                                                const sf_scalars& sc, const sf_outptrs& outs, const sf_ctx& cx,
-                                               const int p, const int p_end, const bool load_next SF_STAMP_ARGS) {
+                                               const int p, const int p_end, const bool load_next) {
   if constexpr (S <= SF_NS) {
     sf_stage_step<S, PH>(st, lds, sc, outs, cx, p, sf_stage<S>::refill && load_next);
     if constexpr (sf_stage<S>::refill) {
-      SF_STAMP_AT(1);
-      if constexpr (!SF_RING4 && !SF_PREFETCH2 && !SF_SPREAD_LOADS) {
-        // (no ring, no staging registers, loads not spread over the rows: the freed slot takes the next plane now)
-        sf_load_plane(in, cx, p + 1, st.w[0][PH % 3], p + 1 < p_end);
-      }
-      SF_STAMP_AT(2);
     }
     (void)in;
     (void)p_end;
-    sf_stages_from<S + 1, PH>(st, lds, in, sc, outs, cx, p, p_end, load_next SF_STAMP_PASS);
+    sf_stages_from<S + 1, PH>(st, lds, in, sc, outs, cx, p, p_end, load_next);
   }
 }
 
@@ -786,13 +581,13 @@ __device__ __forceinline__ void sf_later_stages_desc(sf_state& st, const sf_t* l
   }
 }
 
-#if SF_DPP == 4 && SF_WPR > 1
+#if SF_WPR > 1
 template <int W>
 __device__ __forceinline__ void sf_edge_prefill(sf_t* lds_all, const sf_ctx& cx) {
   if constexpr (W < SF_NW) {
     if (cx.lane == 0 && (cx.wave == 0 || cx.wave == SF_WPR - 1)) {
 #pragma unroll
-      for (int image = 0; image < (SF_LDS_DB ? 2 : 1); ++image)
+      for (int image = 0; image < (1 ? 2 : 1); ++image)
 #pragma unroll
         for (int r = 0; r < SF_RJ; ++r) {
           sf_t* lds = lds_all + image * SF_IMAGE_ELEMS;
@@ -810,7 +605,7 @@ __device__ __forceinline__ void sf_edge_prefill(sf_t* lds_all, const sf_ctx& cx)
 template <int S>
 __device__ __forceinline__ void sf_aux_preload(sf_state& st, const sf_ctx& cx, const int p_first) {
   if constexpr (S <= SF_NS) {
-    const int q = SF_REVERSE ? p_first - (2 * sf_stage<S>::depth - 1) : p_first - sf_stage<S>::depth;
+    const int q = p_first - sf_stage<S>::depth;
 #pragma unroll
     for (int r = 0; r < SF_RJ; ++r) static_cast<sf_auxslots<S>&>(st).a[r] = sf_aux_row<S>(cx, q, r);
     sf_aux_preload<S + 1>(st, cx, p_first);
@@ -824,15 +619,8 @@ __device__ __forceinline__ void sf_aux_preload(sf_state& st, const sf_ctx& cx, c
 template <int PH>
 __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __restrict__ in,
                                         const sf_outptrs& outs, const sf_scalars& sc,
-                                        const sf_ctx& cx, const int p, const int p_end SF_STAMP_ARGS) {
+                                        const sf_ctx& cx, const int p, const int p_end) {
   constexpr int icur = (PH + 1) % SF_SLOTS;
-#if SF_REVERSE == 2
-  // the plane loaded during the previous step (between its last and its first
-  // stage) enters the window as plane "next"; this is the step's only wait on
-  // vector memory, and everything it waits for is at least a stage old
-#pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) st.w[0][(PH + 2) % 3][r] = st.pf[PH % SF_PFD][r];
-#endif
   // Make the window opaque at the step boundary: otherwise the compiler keeps
   // the f64 conversions of whole planes alive from one unrolled step to the
   // next (fewer v_cvt, but ~80 more VGPRs and spills).
@@ -843,20 +631,17 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
     for (int w = 0; w < SF_SLOTS; ++w)
 #pragma unroll
       for (int r = 0; r < SF_RJ; ++r) {
-        // (SF_REVERSE 1: the input plane still in flight must not be touched here)
-        if (SF_REVERSE == 1 && s == 0 && w == (PH + 2) % 3) continue;
         // (SF_RING4: nor the fourth slot -- in flight for the input, dead otherwise)
-        if (SF_RING4 && (w == (PH + 3) % SF_SLOTS || (SF_INFLIGHT == 2 && w == (PH + 4) % SF_SLOTS))) continue;
+        if (SF_RING4 && w == (PH + 3) % SF_SLOTS) continue;
         // (a one-element vector is not a register operand: name its element)
         if constexpr (SF_VK == 1) asm volatile("" : "+v"(st.w[s][w][r][0]));
         else asm volatile("" : "+v"(st.w[s][w][r]));
       }
 #endif
   // publish the rows / columns other threads need of every window's current plane
-#if !SF_WIDE  // (a lone wave per block publishes nothing)
 #pragma unroll
   for (int s = 0; s < SF_NW; ++s) {
-    if constexpr (!SF_NOJ && SF_EXPERIMENT != 4) {
+    if constexpr (!SF_NOJ) {
       *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(s, cx.ty, 0) + cx.tx * SF_VK]) = st.w[s][icur][0];
       *reinterpret_cast<sf_vec*>(&lds[sf_rows_at(s, cx.ty, 1) + cx.tx * SF_VK]) =
           st.w[s][icur][SF_RJ - 1];
@@ -873,66 +658,18 @@ __device__ __forceinline__ void sf_step(sf_state& st, sf_t* lds, const sf_t* __r
       }
     }
   }
-#else
-  static_assert(SF_NOJ && SF_WPR == 1 && !SF_OPAQUE && SF_PREFETCH2 == 1 && !SF_REVERSE, "SF_WIDE: 2-D, one wave per block, staging registers");
-  (void)icur;
-#endif
-  // SF_EXPERIMENT 2/4: timing-only builds without the barrier (invalid results)
-  if (SF_USE_LDS && SF_EXPERIMENT != 2 && SF_EXPERIMENT != 4) __syncthreads();
-  SF_STAMP_AT(0);
-#if SF_REVERSE
-  // Last stage first: its stores are issued at the start of the step and the
-  // input loads at its very end, so the one `s_waitcnt vmcnt(0)` per step (the
-  // compiler cannot count loads and stores apart) waits for loads a whole step
-  // old and for stores most of a step old -- not for stores just issued.
-  sf_later_stages_desc<SF_T, PH>(st, lds, sc, outs, cx, p);
-  SF_STAMP_AT(3);
-#if SF_REVERSE == 2
-#pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) SF_LOAD_ROW_IF(p + SF_PFD < p_end, st.pf[PH % SF_PFD][r], p + SF_PFD, r);
-  SF_STAMP_AT(2);
-  sf_stage_step<1, PH>(st, lds, sc, outs, cx, p);
-  SF_STAMP_AT(1);
-#else
-  sf_stage_step<1, PH>(st, lds, sc, outs, cx, p);
-  SF_STAMP_AT(1);
-  sf_load_plane(in, cx, p + 1, st.w[0][PH % 3], p + 1 < p_end);
-  SF_STAMP_AT(2);
-#endif
-  if (SF_USE_LDS && !SF_LDS_DB) __syncthreads();
-  return;
-#endif
+  if (SF_USE_LDS) __syncthreads();
   // the stages in order.  The last reader of the input window (stage 1 of a chain) consumes input plane p (slot
   // "next") and frees slot "prev", which receives the next plane the ring / staging / plain scheme asks for
 #if SF_RING4
   const bool load_next = p + 1 + SF_INFLIGHT < p_end;
-#elif SF_PREFETCH2
-  const bool load_next = p + 1 + SF_PFD < p_end;
 #else
   const bool load_next = p + 1 < p_end;
 #endif
-  sf_stages_from<1, PH>(st, lds, in, sc, outs, cx, p, p_end, load_next SF_STAMP_PASS);
-  if (SF_USE_LDS && !SF_LDS_DB) __syncthreads();
-  SF_STAMP_AT(3);
+  sf_stages_from<1, PH>(st, lds, in, sc, outs, cx, p, p_end, load_next);
+  if (SF_USE_LDS && !1) __syncthreads();
 }
 
-#if SF_SKIP_ROWS
-// rows of the tile stage S evaluates: what later stages can still read of its output, [depth, SF_TJH - depth)
-template <int S>
-__device__ __forceinline__ void sf_need_rows(sf_ctx& cx, const int tid_y) {
-  if constexpr (S <= SF_NS) {
-    constexpr int d = sf_stage<S>::depth;
-    unsigned need = 0;
-#pragma unroll
-    for (int r = 0; r < SF_RJ; ++r) {
-      const int tr = tid_y * SF_RJ + r;
-      need |= ((SF_NOJ || (tr >= d && tr < SF_TJH - d)) ? 1u : 0u) << r;
-    }
-    cx.need_rows[S - 1] = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
-    sf_need_rows<S + 1>(cx, tid_y);
-  }
-}
-#endif
 
 extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc,
@@ -942,12 +679,8 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
                    ,
                    sf_more_outs more
 #endif
-#if SF_STAMP
-                   ,
-                   unsigned long long* dbg
-#endif
     ) {
-  static_assert(!(SF_DAG && SF_REVERSE), "DAG groups run the stages in order");
+  static_assert(!(SF_DAG && 0), "DAG groups run the stages in order");
   sf_outptrs outs;
   outs.p[0] = out;
 #if SF_NOUT > 1
@@ -955,18 +688,11 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   for (int i = 1; i < SF_NOUT; ++i) outs.p[i] = static_cast<sf_t*>(more.p[i - 1]);
 #endif
   // SF_LDS_DB: two exchange images used alternately -> one barrier per step
-  __shared__ sf_t lds_all[(SF_LDS_DB ? 2 : 1) * SF_IMAGE_ELEMS];
+  __shared__ sf_t lds_all[(1 ? 2 : 1) * SF_IMAGE_ELEMS];
 #if SF_AUX_PASS
   __shared__ sf_aux_passed lds_aux[2 * SF_RJ * SF_BX * SF_BY];
 #endif
 
-#if SF_PRIO
-  // The second-dispatched half of the block's waves (the younger wave of every SIMD's pair) loses the arbitration
-  // for vector issue whenever both are ready (MI355X_MICROARCH.md, two waves per SIMD, item 4): a static priority
-  // for that half evens the pair out.
-  if (__builtin_amdgcn_readfirstlane((((int)threadIdx.y * SF_BX + (int)threadIdx.x) >> 6)) >= (SF_BX * SF_BY) / 128)
-    __builtin_amdgcn_s_setprio(SF_PRIO);
-#endif
   sf_ctx cx;
   cx.in = in;
   cx.aux = aux;
@@ -977,13 +703,8 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   cx.tx = sf_tid_x;
   // thread row and wave-within-row are the same for all lanes of a wave (SF_BX is
   // a multiple of 64): telling the compiler so makes every test on them a scalar branch
-#if SF_UNIFORM
-  cx.ty = __builtin_amdgcn_readfirstlane(sf_tid_y);
-  cx.wave = __builtin_amdgcn_readfirstlane(cx.tx >> 6);
-#else
   cx.ty = sf_tid_y;
   cx.wave = cx.tx >> 6;
-#endif
   cx.lane = cx.tx & 63;
   cx.goff = goff;
   cx.halo = halo;
@@ -994,14 +715,9 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   const int nb = gridDim.x, b = blockIdx.x;
   const int xq = nb >> 3, xr = nb & 7, xcd = b & 7;
   const int L = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
-#if SF_TILE_ORDER == 1
   // k-tiles fastest: an XCD's share is a band of whole tile rows, every pair of k-neighbours in it
   const int kt = L % SF_NKT;
   const int jt = (L / SF_NKT) % SF_NJT;
-#else
-  const int jt = L % SF_NJT;
-  const int kt = (L / SF_NJT) % SF_NKT;
-#endif
   const int ch = L / (SF_NJT * SF_NKT);
 
   // chunks [0, nch1) cover planes [i_begin, i_end), later chunks a second range
@@ -1053,17 +769,12 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
     cx.nt_rows = (unsigned)__builtin_amdgcn_readfirstlane((int)excl);
   }
 #endif
-#if SF_SKIP_ROWS
-  sf_need_rows<1>(cx, sf_tid_y);
-#endif
-#if SF_BUFFER_IO
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     const unsigned off = (unsigned)(((cx.j0 + r) * SF_N2 + cx.k0) * (int)sizeof(sf_t));
     cx.ld_off[r] = (((cx.jmask >> r) & 1u) && cx.kvec_in) ? off : SF_OOB;
     cx.st_off[r] = ((cx.store_mask >> r) & 1u) ? off : SF_OOB;
   }
-#endif
 
   sf_state st;
 #pragma unroll
@@ -1071,38 +782,21 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 #pragma unroll
     for (int w = 0; w < SF_SLOTS; ++w)
 #pragma unroll
-      for (int r = 0; r < SF_RJ; ++r) st.w[s][w][r] = (sf_wvec)(sf_wt)0;
+      for (int r = 0; r < SF_RJ; ++r) st.w[s][w][r] = (sf_vec)(sf_t)0;
 
-  // p_end bounds the input planes read; p_last the steps (SF_REVERSE drains
-  // T-1 more steps because its stages lag further)
+  // p_end bounds the input planes read and the steps
   const int p_begin = cx.cb - SF_T, p_end = cx.ce + SF_T;
-  const int p_last = SF_REVERSE ? cx.ce + 2 * SF_T - 1 : p_end;
-#if SF_REVERSE != 2
+  const int p_last = p_end;
   sf_load_plane(in, cx, p_begin, st.w[0][2]);  // slot "next" of phase 0
-#endif
 #if SF_RING4
   // the plane(s) after the one stage 1 starts with are already in flight (fourth / fifth slot)
   sf_load_plane(in, cx, p_begin + 1, st.w[0][3], p_begin + 1 < p_end);
-#if SF_INFLIGHT == 2
-  sf_load_plane(in, cx, p_begin + 2, st.w[0][4], p_begin + 2 < p_end);
-#endif
-#elif SF_PREFETCH2 || SF_REVERSE == 2
-  // fill the prefetch ring: the planes after the one stage 1 starts with
-  // (SF_REVERSE 2: including that one)
-#pragma unroll
-  for (int d = 0; d < SF_PFD; ++d) {
-    const int pd = p_begin + d + (SF_REVERSE == 2 ? 0 : 1);
-#pragma unroll
-    for (int r = 0; r < SF_RJ; ++r) st.pf[d][r] = (sf_vec)(sf_t)0;
-#pragma unroll
-    for (int r = 0; r < SF_RJ; ++r) SF_LOAD_ROW_IF(pd < p_end, st.pf[d][r], pd, r);
-  }
 #endif
 
 #if SF_AUX_AHEAD == 2
   sf_aux_preload<1>(st, cx, p_begin);
 #endif
-#if SF_DPP == 4 && SF_WPR > 1
+#if SF_WPR > 1
   // the virtual waves' edge words: window s is read by stage s + 1, whose boundary
   // constant they hold (never overwritten; the first step's barrier orders them)
   sf_edge_prefill<0>(lds_all, cx);
@@ -1110,34 +804,20 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
   // Two exchange images alternate every step (run-time offset); the window
   // phase cycles with period 3 (compile-time slot indices).
   int image = 0;
-#if SF_STAMP
-  unsigned long long acc[4] = {0, 0, 0, 0}, t_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
-#endif
   // the trip always runs three steps: up to two surplus steps past p_end
   // compute planes nobody stores (loads and stores are range-guarded), which
   // keeps the loop body free of control flow between the phases
   // (SF_RING4: four steps, up to three surplus ones)
   for (int p = p_begin; p < p_last; p += SF_SLOTS) {
-    sf_step<0>(st, lds_all + image, in, outs, sc, cx, p, p_end SF_STAMP_PASS);
-    if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
-    sf_step<1>(st, lds_all + image, in, outs, sc, cx, p + 1, p_end SF_STAMP_PASS);
-    if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
-    sf_step<2>(st, lds_all + image, in, outs, sc, cx, p + 2, p_end SF_STAMP_PASS);
-    if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
+    sf_step<0>(st, lds_all + image, in, outs, sc, cx, p, p_end);
+    image = SF_IMAGE_ELEMS - image;
+    sf_step<1>(st, lds_all + image, in, outs, sc, cx, p + 1, p_end);
+    image = SF_IMAGE_ELEMS - image;
+    sf_step<2>(st, lds_all + image, in, outs, sc, cx, p + 2, p_end);
+    image = SF_IMAGE_ELEMS - image;
 #if SF_RING4
-    sf_step<3>(st, lds_all + image, in, outs, sc, cx, p + 3, p_end SF_STAMP_PASS);
-    if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
-#endif
-#if SF_INFLIGHT == 2
-    sf_step<4>(st, lds_all + image, in, outs, sc, cx, p + 4, p_end SF_STAMP_PASS);
-    if (SF_LDS_DB) image = SF_IMAGE_ELEMS - image;
+    sf_step<3>(st, lds_all + image, in, outs, sc, cx, p + 3, p_end);
+    image = SF_IMAGE_ELEMS - image;
 #endif
   }
-#if SF_STAMP
-  if (cx.lane == 0) {
-    for (int i = 0; i < 4; ++i) atomicAdd(&dbg[i], acc[i]);
-    atomicAdd(&dbg[4], 1ull);
-  }
-#endif
 }

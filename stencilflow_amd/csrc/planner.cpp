@@ -51,15 +51,13 @@ size_t star_lds_bytes(const StarCfg& c, DT dt) {
   if (c.compact) {
     // kernels/compact3d.h: per window a ring of images (first / last row of every
     // thread row + the wave-edge columns of every row incl. two virtual waves)
-    // (SF_XLANE: segments of 32 lanes, and four pad elements on either side of a row of the row images)
-    const size_t seg = c.xlane ? 32 : 64, pad = (c.xlane && !c.noj) ? 4 : 0;
-    const size_t win = (size_t)c.BY * 2 * (c.BX * c.VK + 2 * pad) + (size_t)(c.BY + 2) * c.RJ * (c.BX / seg + 2) * 2;
+    const size_t win = (size_t)c.BY * 2 * (c.BX * c.VK) + (size_t)(c.BY + 2) * c.RJ * (c.BX / 64 + 2) * 2;
     return std::max<size_t>(1, (size_t)c.lds_images * win) * size_of(dt);
   }
   const size_t windows = c.dag.on ? (size_t)c.dag.nwin : (size_t)c.T;  // (kernels/star3d.h: SF_NW)
   const size_t rows = c.noj ? 0 : windows * c.BY * 2 * c.BX * c.VK;
-  const size_t edge = windows * c.BY * c.RJ * (c.BX / 64 + ((c.dpp == 4 && c.BX > 64) ? 2 : 0)) * 2;
-  return (rows + edge) * size_of(dt) * (c.lds_db ? 2 : 1);
+  const size_t edge = windows * c.BY * c.RJ * (c.BX / 64 + (c.BX > 64 ? 2 : 0)) * 2;  // (two virtual waves beside a row)
+  return (rows + edge) * size_of(dt) * 2;  // (two images alternate from step to step)
 }
 
 // ---- launch-geometry model ------------------------------------------------------
@@ -85,8 +83,7 @@ static int star_regs_estimate(const StarCfg& c, DT dt) {
     return (3 * c.nwin + 1 + c.nwin - c.T) * P * words + 52 + P;
   // (a DAG group: one window per field held, and an evaluation's temporaries per stage beyond the chain's)
   const int windows = c.dag.on ? c.dag.nwin : c.T;
-  return 3 * windows * P * words + 20 + (33 * P) / 10 +
-         ((c.prefetch2 || c.reverse == 2) ? P * words * c.pfd : 0);
+  return 3 * windows * P * words + 20 + (33 * P) / 10 + (c.ring4 ? P * words : 0);
 }
 
 static int star_blocks_per_cu(const StarCfg& c, DT dt) {
@@ -143,7 +140,7 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
       // 92-row chunks).  Below that, time follows the chunk length; above it,
       // the warm-up redundancy.
       const double waves_per_simd = (double)blocks * (double)(c.BX / 64) / 1024.0;
-      const double warm = (double)(li + 2 * c.T * c.R + (c.reverse ? c.T - 1 : 0)) / (double)li;
+      const double warm = (double)(li + 2 * c.T * c.R + (c.compact ? c.T - 1 : 0)) / (double)li;
       const double cost = warm * std::max(1.0, 3.0 / waves_per_simd);
       if (cost < best - 1e-12) {
         best = cost;
@@ -154,7 +151,8 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
     }
     const long long rounds = (blocks + slots - 1) / slots;
     const double quant = (double)(rounds * slots) / (double)blocks;
-    const double warm = (double)(li + 2 * c.T * c.R + (c.reverse ? c.T - 1 : 0)) / (double)li;
+    // (the compact kernel's stages read planes finished in earlier steps only: T - 1 more steps to drain)
+    const double warm = (double)(li + 2 * c.T * c.R + (c.compact ? c.T - 1 : 0)) / (double)li;
     // more rounds amortise the tail when block times differ
     const double cost = warm * quant * (1.0 + 0.02 / (double)rounds);
     if (cost < best - 1e-12) {
@@ -167,13 +165,12 @@ static int star_chunk_planes(const StarCfg& c, DT dt, int range, double* cost_ou
   return best_li;
 }
 
-// Extra compiler flags of a kernel family: `<family>.slp=0|1` turns the SLP vectoriser off / on for it.  On gfx950 a
+// Extra compiler flags of a kernel family: the SLP vectoriser is off everywhere but for the 3-D wide stars.  On gfx950 a
 // v_pk_add_f32 holds the vector pipe as long as the two v_add_f32 it replaces, its operand pairs are assembled with
 // moves and two dependent ones need wait states between them (an `s_nop` each): measured slower wherever it was
-// tried -- 27-point box (round 2), 125-point box 505 -> 450 us per launch (round 4, profiles/r04_dense_slp.log).
-static std::string slp_flags(const sf_plan& pl, const char* family, int dflt) {
-  return pl.opt.get(std::string(family) + ".slp", dflt) != 0 ? "" : "-fno-slp-vectorize";
-}
+// tried -- 27-point box (round 2), 125-point box 505 -> 450 us per launch, stars with float-typed sums 0.5-8 %
+// (round 4, profiles/r04_dense_slp.log, r04_slp_families.log); 3-D wide stars 8.8e5 against 8.0e5 without it.
+static std::string slp_flags(bool slp) { return slp ? "" : "-fno-slp-vectorize"; }
 
 // chunk length used for a launch over `range` planes (options k1.li / k2.li pin it)
 long long star_chunk_length(const sf_plan& pl, const StarCfg& c, DT dt, int range, int ranges) {
@@ -202,91 +199,33 @@ static std::vector<StarCfg> rank_star_cfgs(const sf_plan& pl, int T, DT dt, cons
   base.n1 = P.n[1];
   base.n2 = P.n[2];
   base.noj = (P.n[1] == 1);
-  base.row_fence = (int)pl.opt.get("k1.fence", 1);
-  base.lds_db = (int)pl.opt.get("k1.db", 1);
-  base.opaque = (int)pl.opt.get("k1.opaque", base.noj ? 0 : 1);  // 2-D: registers are plentiful
-  base.stamp = (int)pl.opt.get("stamp", 0);
-  base.spread = (int)pl.opt.get("k1.spread", 1);
-  // step order: 3-D kernels run stage 1 first (k1.rev=0); 2-D kernels run the
-  // storing stage first, which makes the stages of one step independent of each
-  // other (more instruction-level parallelism for the lone wave) -- measured
-  // +30 % on C2, no change on C3 (profiles/r01_sweep_9_step_order.log)
-  // -- with branch-free buffer loads and stores (k1.bio, below) the compiler counts
-  // the memory operations in flight, a wave no longer drains them once per step,
-  // and stage-1-first with the four-slot input ring overtakes it: C2 +10 %
-  // (profiles/r01_sweep_17_buffer_io.log); k1.rev=1 remains available
-  base.reverse = base.compact ? 1 : base.R == 2 ? 0 : (int)pl.opt.get("k1.rev", 0);
-  // input planes: 0 = loaded into the window slot stage 1 has just freed, 1 = into
-  // staging registers a step earlier and copied, 2 = four-slot input ring (two
-  // steps to land, no copy; the step loop is unrolled by 4)
-  // (defaults: the ring for 2-D and f32 3-D -- C2 +10 %, C3 +1.7 %, hotspot chains
-  // +1 % with k1.bio; staging registers for f64, whose ring needs a smaller tile)
-  // (round 4: f64 3-D loads straight into the freed slot -- the staging registers cost 20-30 registers, which made
-  // C5's five-row tile spill under ROCm 7.2's hipRTC and fall back to four rows (433 us), and without them the
-  // five-row tile is as fast or faster under every compiler: 409.5-415 against 417 us with PyTorch's hipRTC,
-  // 410 against 412 us with ROCm's comgr, profiles/r04_compilers_c5_c3.log)
-  base.prefetch2 = base.reverse ? 0 : (int)pl.opt.get("k1.pf2", (base.noj || dt == DT::F32) ? 2 : 0);
-  // (3: a five-slot ring, two planes in flight beside the window -- 20 registers more at five rows per thread)
-  if (base.prefetch2 < 0 || base.prefetch2 > 3) throw Error(SF_ERR_INVALID, "k1.pf2 must be 0, 1, 2 or 3");
-  base.uniform_loads = (int)pl.opt.get("k1.ul", 0);
-  // planes through buffer instructions (out-of-range offsets instead of branches
-  // around loads and stores); a plane must stay well below the 2 GiB offset range
+  base.row_fence = 1;
+  base.opaque = base.noj ? 0 : 1;  // 2-D: registers are plentiful
+  // Input planes: the four-slot ring (two steps to land, no copy; the step loop is unrolled by 4) for 2-D and f32 3-D
+  // -- C2 +10 %, C3 +1.7 %, hotspot chains +1 % --; f64 3-D loads straight into the window slot stage 1 has just freed
+  // (the ring needs a smaller tile there; staging registers cost 20-30 registers and made C5's five-row tile spill
+  // under ROCm 7.2's hipRTC, profiles/r04_compilers_c5_c3.log).  The compact kernels have their own ring.
+  base.ring4 = !base.compact && (base.noj || dt == DT::F32);
+  // Planes go through buffer instructions (out-of-range offsets instead of branches around loads and stores: the
+  // compiler counts the memory operations in flight instead of draining them once per step; 2-D +10 %, f32 3-D chains
+  // with auxiliary fields +38 %, profiles/r01_sweep_17_buffer_io.log): a plane must stay below the 2 GiB offset range
   const double plane_bytes = (double)P.n[1] * (double)P.n[2] * (double)size_of(dt);
-  // Measured (profiles/r01_sweep_17_buffer_io.log): 2-D +10 % (with the step order
-  // and input ring above), f64 3-D +1..4 %, f32 3-D jacobi +1.7 % with the ring,
-  // f32 3-D chains with auxiliary fields (hotspot) +38 %
-  base.buffer_io = plane_bytes <= 1024.0 * 1024 * 1024 ? (int)pl.opt.get("k1.bio", 1) : 0;
-  base.pfd = (int)pl.opt.get("k1.pfd", 1);
-  if (base.pfd != 1 && base.pfd != 3) throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
-  if ((base.prefetch2 != 1 && base.reverse != 2) || base.prefetch2 >= 2) base.pfd = 1;
-  base.experiment = (int)pl.opt.get("experiment", 0);
-  // lane exchange: 0 = __shfl, 1 = DPP, 2 = DPP with bound_ctrl (no copy before the
-  // move), 3 = as 2 and the wave's edge lane gets its value (boundary constant or
-  // the neighbouring wave's edge column) from the move's starting destination
-  // instead of a select, 4 = as 3 with the neighbour test removed: virtual waves
-  // beside every row hold the boundary constant in LDS.  Measured: C3 2 -> 4 +1 %
-  // (3 costs 7 % there: scalar branches per row), C5 2 -> 3/4 +4.7 %, C2 +8 %.
-  const long long dpp_opt = pl.opt.get("k1.dpp", -1);
-  base.dpp = dpp_opt >= 0 ? (int)dpp_opt : 4;
-  base.uniform = (int)pl.opt.get("k1.uni", 0);
-  // halo rows of the tile no later stage reads are not evaluated (star3d.h: SF_SKIP_ROWS)
-  base.skip_rows = (int)pl.opt.get("k1.skip", 0);
-  base.whatif = (int)pl.opt.get("debug.whatif", 0);  // timing diagnostics, wrong results
-  base.lds_ahead = (int)pl.opt.get("k1.ahead", 1);
-  base.xlane = (int)pl.opt.get("k1.xlane", 0);
-  base.xbatch = (int)pl.opt.get("k1.xbatch", 0);
-  // s_setprio for the younger half of a block's waves (star3d.h: SF_PRIO; measured -0.7 % on C3, off)
-  base.prio = (int)pl.opt.get("k1.prio", 0);
-  if (base.prio < 0 || base.prio > 3) throw Error(SF_ERR_INVALID, "k1.prio must lie in [0, 3]");
-  // 2-D float programs with double-typed operators on one-wave blocks: windows of converted values (star3d.h:
-  // SF_WIDE); needs the staging registers (the copy into the window is where a plane is converted)
-  base.wide = (pl.opt.get("k2.wide", 0) != 0 && base.noj && dt == DT::F32 && !base.reverse && !base.compact && base.R == 1) ? 1 : 0;
-  if (base.wide) {
-    base.prefetch2 = 1;
-    base.pfd = (int)pl.opt.get("k1.pfd", 3);
-    base.opaque = 0;
-  }
-  // logical tile order inside an XCD's share of the grid: 1 = k-tiles fastest, so that the share is a band of whole
-  // tile rows and all its k-neighbours (which re-read each other's halo columns) meet in one L2.  C5 (16 x 5 tiles):
-  // FETCH 1.2445 -> 1.1922 GB per launch, 0.7 % faster (profiles/r03_c5_tile_order.log); no k-tiles: same order
-  base.order = (int)pl.opt.get("k1.order", 1);
-  // auxiliary (centre-only) fields: 1 = a stage requests all its rows before its
-  // first row is evaluated (3-D hotspot chains +21 %); 2 = rows are requested a
-  // whole step ahead into per-stage slots (2-D, where a thread has one row and
+  if (plane_bytes > 1024.0 * 1024 * 1024) throw Error(SF_ERR_INVALID, "planes of more than 1 GiB take the generic kernel");
+  // auxiliary (centre-only) fields: 1 = a stage requests all its rows before its first row is evaluated (3-D hotspot
+  // chains +21 %); 2 = rows are requested a whole step ahead into per-stage slots (2-D, where a thread has one row and
   // registers to spare, +11 %)
-  base.aux_ahead = (int)pl.opt.get("k1.auxpre", base.noj ? 2 : 1);
-  base.aux_pass = (int)pl.opt.get("k1.auxpass", 1);
-  // Non-temporal output stores when a field is larger than the 256 MiB Infinity
-  // Cache: nothing of it would survive until the next launch reads it, and not
-  // allocating the written lines leaves the cache to the input stream (C3 +3 %,
-  // C5 +1.4 %; the cache-resident 64 MiB field of C2 loses 13 % with them).
+  base.aux_ahead = base.noj ? 2 : 1;
+  base.aux_pass = 1;
+  // Non-temporal output stores when a field is larger than the 256 MiB Infinity Cache: nothing of it would survive
+  // until the next launch reads it, and not allocating the written lines leaves the cache to the input stream (C3 +3 %,
+  // C5 +1.4 %; the cache-resident 64 MiB field of C2 loses 13 % with them).  Bit 4 (round 4): the rows of a tile no other
+  // block reads -- neither a neighbouring tile's halo nor its source of halo rows -- are LOADED non-temporally as well,
+  // the shared rows keep the default policy and meet their second reader in the XCD's L2 (C3 199.9 -> 198.1-198.6 us,
+  // profiles/r04_c3_prio_nt_fork.log; all-rows non-temporal loads had lost 4-8 % in round 2)
   const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] *
                              (double)P.n[2] * (double)size_of(dt);
-  // (round 4, bit 2: the rows of a tile no other block reads -- neither a neighbouring tile's halo nor its source of
-  // halo rows -- are LOADED non-temporally as well, as a flat copy's loads would be; the shared rows keep the default
-  // policy and meet their second reader in the XCD's L2.  C3 199.9 -> 198.1-198.6 us on one box, 200.1 -> 198.1-198.2
-  // on another (profiles/r04_c3_prio_nt_fork.log); all-rows non-temporal loads, k1.nt=3, had lost 4-8 % in round 2)
   base.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 5 : 0);
+  if (base.nt & ~5) throw Error(SF_ERR_INVALID, "k1.nt: 1 (non-temporal stores), 4 (non-temporal loads of unshared rows) or 5");
   const std::string pfx = base.noj ? "k2." : "k1.";
   const long long pin_bx = pl.opt.get(pfx + "bx", 0);
   const long long pin_by = base.noj ? 1 : pl.opt.get("k1.by", 0);
@@ -384,7 +323,7 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
   }
   const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
                       (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
-  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
+  const size_t tries = std::min<size_t>(ranked.size(), (size_t)8);
   int rejected = 0, sgpr_rejects = 0;
   for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {  // compile errors rarely depend on the shape
     ranked[ci].lds_bytes = star_lds_bytes(ranked[ci], dt);
@@ -393,7 +332,7 @@ static StarChoice select_star(sf_plan& pl, std::map<std::string, StarChoice>& me
     try {
       // (off since round 4: float-typed sums -- integer boundary literals, the generator's programs -- gain 0.5-8 %
       // without the packed adds, nothing loses: profiles/r04_slp_families.log)
-      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "star", 0));
+      ck = intern_kernel(pl, prefix, g.source, slp_flags(false));
     } catch (const Error& e) {
       // a shape the compiler rejects is no candidate (a pinned shape reports it);
       // the group is shortened and in the end the generic kernel takes over
@@ -445,14 +384,14 @@ static StarChoice select_wide(sf_plan& pl, std::map<std::string, StarChoice>& me
   }
   const bool pinned = pl.opt.kv.count(P.n[1] == 1 ? "k2.bx" : "k1.bx") &&
                       (P.n[1] == 1 || (pl.opt.kv.count("k1.by") && pl.opt.kv.count("k1.rj")));
-  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", 8)));
+  const size_t tries = std::min<size_t>(ranked.size(), (size_t)8);
   int rejected = 0;
   for (size_t ci = 0; ci < tries && rejected < 2; ++ci) {
     StarKernelSource g = gen_wide(P, kernels, ranked[ci]);
     int ck = -1;
     try {
       // (3-D wide stars are the one family that gains from the packed adds: 8.8e5 against 8.0e5 without; 2-D: off, +2 %)
-      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "wide", P.n[1] == 1 ? 0 : 1));
+      ck = intern_kernel(pl, prefix, g.source, slp_flags(P.n[1] != 1));
     } catch (const Error& e) {
       if (pinned || e.status != SF_ERR_COMPILE) throw;
       report_rejected_candidate(pl, "wide-star", std::to_string(ci + 1) + "/" + std::to_string(ranked.size()), e);
@@ -499,43 +438,43 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
   std::vector<Shape> todo;
   if (pin_bx && (noj || (pin_by && pin_rj))) todo.push_back({(int)pin_bx, noj ? 1 : (int)pin_by, noj ? 1 : (int)pin_rj});
   else todo.assign(noj ? std::begin(shapes2d) : std::begin(shapes3d), noj ? std::end(shapes2d) : std::end(shapes3d));
-  // every shape with row segments held in registers first; then, for the first shapes, the form that reads
-  // each operand from LDS where the text uses it (operators whose typing doubles what a segment takes)
+  // a plain sum streams (the planes by LDS-DMA, every plane read from LDS once); anything else: every shape with row
+  // segments held in registers first, then, for the first shapes, the form that reads each operand from LDS where the
+  // text uses it (operators whose typing doubles what a segment takes)
   struct Variant {
     Shape first;
     bool second;  // operands read from LDS where the text uses them
-    bool sum;     // plain-sum form: the thread's rows accumulated in step, row segments shared between them
-    bool stream = false;  // plain sum, terms ordered by plane: every plane read from LDS once (SF_DENSE_STREAM)
+    bool stream;  // ONE left-associated sum: the streaming form (SF_DENSE_STREAM)
   };
   std::vector<Variant> variants;
-  // An operator that is one plain sum (the generator's boxes): several rows per thread, so that a row segment
-  // read from LDS serves them all -- LDS bytes per output fall from 200 to 120 (two rows) or 80 (four).
-  // (measured on the 125-point box 512^3, profiles/r03_dense_sum_probe.log: 0.595 / 0.600 / 0.609 ms per operator
-  //  against 0.666 row by row; four rows per thread 0.605-0.616: with 124 adds per point the kernel is bound by
-  //  vector issue -- 0.42 ms at full rate -- not by LDS bytes any more)
-  static const Shape sums3d[] = {{64, 4, 2}, {64, 8, 2}, {32, 8, 2}};
-  // The streaming form first (gen_dense refuses it when the terms are not ordered by plane): more rows per thread pay
-  // there, the accumulators of five open output planes being the only state
+  // Streaming form: more rows per thread pay, the accumulators of the open output planes being the only state
   // (125-point box 512^3, profiles/r04_dense_stream.log: 64x2x4 0.397 ms per operator, 32x4x4 0.39, 64x2x2 0.41,
-  //  64x4x2 0.43, 64x4x4 0.47, against 0.44 for the form that reads every plane five times)
+  //  64x4x2 0.43, 64x4x4 0.47)
   // (one row per thread last: operators whose sums are typed double -- a float boundary literal -- hold two registers per
   //  accumulator, seven sets of them at radius 3)
   static const Shape streams3d[] = {{64, 2, 4}, {32, 4, 4}, {64, 2, 2}, {64, 4, 2}, {64, 4, 1}, {64, 8, 1}};
-  if (pl.opt.get("dense.sum", 1) != 0 && pl.opt.get("dense.stream", 1) != 0 && dense_sum_form(P, P.kernels[kidx], nullptr)) {
-    if (pin_bx && (noj || (pin_by && pin_rj))) variants.push_back({todo[0], false, true, true});
-    else if (noj) for (const Shape& sh : shapes2d) variants.push_back({sh, false, true, true});
-    else for (const Shape& sh : streams3d) variants.push_back({sh, false, true, true});
-  }
-  if (pl.opt.get("dense.sum", 1) != 0 && dense_sum_form(P, P.kernels[kidx], nullptr)) {
+  // (a float32 sum typed double -- a float boundary literal -- at radius 3: seven sets of two-register accumulators fit one
+  //  row per thread only; the other shapes would each cost seconds of compilation to find that out)
+  static const Shape streams3d_wide_acc[] = {{64, 4, 1}, {64, 8, 1}};
+  // (few terms -- a radius-3 cross, 18 of them: the launch is paced by memory, two rows per thread leave room for twice
+  //  the waves; radius-3 cross 512^3: 64x4x2 200.7 us per operator, 64x2x4 213.5, 128x4x2 210.4, 64x4x4 219.0, 64x2x2 267.6,
+  //  against 392 on the generic kernel, profiles/r05_cross3.log)
+  static const Shape streams3d_sparse[] = {{64, 4, 2}, {64, 2, 4}, {128, 4, 2}, {64, 4, 4}, {64, 4, 1}};
+  DenseSum sum_form;
+  if (dense_sum_form(P, P.kernels[kidx], &sum_form)) {
+    const Kernel& K = P.kernels[kidx];
+    const bool wide_acc = dt == DT::F32 && radius == 3 &&
+                          (K.acc[sum_form.terms[0]].vtype == DT::F64 || K.acc[sum_form.terms[1]].vtype == DT::F64);
     if (pin_bx && (noj || (pin_by && pin_rj))) variants.push_back({todo[0], false, true});
     else if (noj) for (const Shape& sh : shapes2d) variants.push_back({sh, false, true});
-    else for (const Shape& sh : sums3d) variants.push_back({sh, false, true});
+    else if (wide_acc) for (const Shape& sh : streams3d_wide_acc) variants.push_back({sh, false, true});
+    else if (sum_form.terms.size() <= 32) for (const Shape& sh : streams3d_sparse) variants.push_back({sh, false, true});
+    else for (const Shape& sh : streams3d) variants.push_back({sh, false, true});
   }
-  for (const Shape& sh : todo) variants.push_back({sh, false, false});
-  for (size_t i = 0; i < todo.size() && i < 2; ++i) variants.push_back({todo[i], true, false});
-  // radius 3 (the generator's extent 3): the streaming form or nothing
-  if (radius == 3)
-    variants.erase(std::remove_if(variants.begin(), variants.end(), [](const Variant& v) { return !v.stream; }), variants.end());
+  if (radius != 3) {  // (radius 3: the streaming form or nothing)
+    for (const Shape& sh : todo) variants.push_back({sh, false, false});
+    for (size_t i = 0; i < todo.size() && i < 2; ++i) variants.push_back({todo[i], true, false});
+  }
   for (const auto& variant : variants) {
     const Shape& sh = variant.first;
     StarCfg c;
@@ -543,11 +482,7 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     c.R = radius;
     c.dense = true;
     c.dense_scalar = variant.second;
-    c.dense_sum = variant.sum;
     c.dense_stream = variant.stream ? 1 : 0;
-    c.whatif = (int)pl.opt.get("debug.whatif", 0);  // timing diagnostics, wrong results
-    c.dense_early = variant.stream ? (int)pl.opt.get("dense.early", 0) : 0;
-    c.dense_il = (int)pl.opt.get("dense.il", 0);
     c.VK = dt == DT::F64 ? 2 : 4;  // 16 bytes of output per lane and row
     c.BX = sh.bx;
     c.BY = sh.by;
@@ -562,26 +497,32 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     c.HK = 0;
     c.NKT = (int)((P.n[2] + tk - 1) / tk);
     c.NJT = noj ? 1 : (int)((P.n[1] + tj - 1) / tj);
-    const int rc = (radius + 1) / 2 * 2;  // halo columns of an LDS row (dense3d.h: SF_RC)
-    const size_t lds = (variant.stream ? 2 : 6) * (size_t)(tj + (noj ? 0 : 2 * radius)) * (size_t)(tk + 2 * rc) * size_of(dt);
+    const int rc = (radius + 1) / 2 * 2;  // halo columns of a row segment (dense3d.h: SF_RC)
+    size_t lds = 6 * (size_t)(tj + (noj ? 0 : 2 * radius)) * (size_t)(tk + 2 * rc) * size_of(dt);
+    if (variant.stream) {
+      // planes by LDS-DMA: rows start a whole 16-byte chunk left of the tile, slots are whole 1-KiB pieces (SF_RCL, SF_SLOT_STRIDE)
+      const int ce = (int)(16 / size_of(dt)), rcl = (rc + ce - 1) / ce * ce;
+      // (two slots = requested one plane ahead, measured equal to three on the 125-point box, 355.8 us sustained either
+      //  way -- the launch is paced by vector issue at the clock the chip holds, profiles/r05_dense_whatif.log)
+      c.dense_in_slots = 2;
+      // (a sum whose terms are not ordered by plane -- a cross -- keeps the planes its late terms read: stream_schedule)
+      c.dense_lag = stream_schedule(P.kernels[kidx], sum_form).max_lag;
+      const size_t slot = ((size_t)(tj + (noj ? 0 : 2 * radius)) * (size_t)(tk + 2 * rcl) * size_of(dt) + 1023) / 1024 * 1024;
+      lds = (size_t)(c.dense_in_slots + c.dense_lag) * slot;
+    }
     if (lds > 160 * 1024) continue;
     c.lds_bytes = lds;
     const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] * (double)P.n[2] *
                                (double)size_of(dt);
     c.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
     StarKernelSource g;
-    try {
-      g = gen_dense(P, kidx, c);
-    } catch (const Error&) {
-      if (!variant.stream) throw;
-      continue;  // (the terms are not ordered by plane)
-    }
+    g = gen_dense(P, kidx, c);
     const std::string sig = "dense" + std::to_string(fnv1a(g.source));
     auto it = memo.find(sig);
     if (it != memo.end()) return it->second;
     int ck = -1;
     try {
-      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "dense", 0));
+      ck = intern_kernel(pl, prefix, g.source, slp_flags(false));
     } catch (const Error& e) {
       if (e.status != SF_ERR_COMPILE) throw;
       report_rejected_candidate(pl, "dense", std::to_string(sh.bx) + "x" + std::to_string(sh.by) + "x" + std::to_string(sh.rj), e);
@@ -590,7 +531,7 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
     const CompiledKernel& k = pl.kernels[ck];
     if (pl.opt.get("debug", 0) != 0)
       std::fprintf(stderr, "[sf_hip] dense candidate block %dx%d rows/thread %d%s: vgpr %d agpr %d spill %d scratch %d lds %d\n", sh.bx,
-                   sh.by, sh.rj, variant.stream ? " (plain sum, planes streamed)" : variant.sum ? " (plain sum, rows in step)" : variant.second ? " (operands read where used)" : "", k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
+                   sh.by, sh.rj, variant.stream ? " (plain sum, planes streamed)" : variant.second ? " (operands read where used)" : "", k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
     if (!kernel_unsafe(k) && (!kernel_slow(k) || (pin_bx != 0 && pl.opt.get("allow_spills", 0) != 0))) {
       out.ok = true;
       out.cfg = c;
@@ -638,11 +579,9 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     c.T = 1;
     c.R = 2;  // (the group reaches two planes, one per operator: what the slab halo and the chunking see)
     c.dense = true;
-    c.dense_sum = true;
     c.dense_stream = 1;
     c.dense_t2 = 1;
     c.dense_k2 = k2;
-    c.whatif = (int)pl.opt.get("debug.whatif", 0);
     c.VK = dt == DT::F64 ? 2 : 4;
     c.BX = sh.bx;
     c.BY = sh.by;
@@ -662,11 +601,14 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     // what the tiles cover against what the grid holds (rows recomputed by the neighbouring tile, lanes beyond the row)
     const double used = ((double)P.n[2] / ((double)c.NKT * (double)tk)) * (noj ? 1.0 : (double)P.n[1] / ((double)c.NJT * (double)tj));
     if (!force && !pin_bx && used < 0.75) continue;
-    // four LDS slots; where they do not fit, three (one slot for the input planes, a second barrier per step)
-    const size_t slot = (size_t)(tj + (noj ? 0 : 2)) * (size_t)(tk + 4) * size_of(dt);
-    c.dense_one_in = (int)pl.opt.get("dense.onein", 4 * slot > 160 * 1024 ? 1 : 0);
-    const size_t lds = (c.dense_one_in ? 3 : 4) * slot;
-    if (lds > 160 * 1024) continue;
+    // the input ring (planes by LDS-DMA, requested `slots - 1` ahead) and the two slots between the operators: as many
+    // input slots, up to three, as fit; one = the next plane requested in mid-step, behind a second barrier
+    const size_t slot = ((size_t)(tj + (noj ? 0 : 2)) * (size_t)(tk + 2 * (16 / size_of(dt))) * size_of(dt) + 1023) / 1024 * 1024;
+    const long long fit = (long long)(160 * 1024 / slot) - 2;
+    if (fit < 1) continue;
+    // (two input slots against one, 16-row tiles: 286 against 294 us; a third buys nothing)
+    c.dense_in_slots = (int)std::min<long long>(2, fit);
+    const size_t lds = (size_t)(c.dense_in_slots + 2) * slot;
     c.lds_bytes = lds;
     const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] * (double)P.n[2] *
                                (double)size_of(dt);
@@ -682,7 +624,7 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     if (it != memo.end()) return it->second;
     int ck = -1;
     try {
-      ck = intern_kernel(pl, prefix, g.source, slp_flags(pl, "dense", 0));
+      ck = intern_kernel(pl, prefix, g.source, slp_flags(false));
     } catch (const Error& e) {
       if (e.status != SF_ERR_COMPILE) throw;
       report_rejected_candidate(pl, "dense (two fused)", std::to_string(sh.bx) + "x" + std::to_string(sh.by) + "x" + std::to_string(sh.rj), e);
@@ -709,7 +651,8 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
 // keeps the 26 adds of a box stencil scalar instead of pairing them into
 // v_pk_add_f32, whose operand pairs it has to assemble with moves (option compact.slp).
 static std::string compact_flags(const sf_plan& pl) {
-  return pl.opt.get("compact.slp", 0) != 0 ? "" : "-fno-slp-vectorize";
+  (void)pl;
+  return "-fno-slp-vectorize";
 }
 
 // The same for a group of compact operators (kernels/compact3d.h).
@@ -741,7 +684,7 @@ static StarChoice select_compact(sf_plan& pl, std::map<std::string, StarChoice>&
     if (compact_eligible(P, P.kernels[kk], &sh) && !sh.extra.empty()) second_field = true;
   }
   const bool more = kernels.size() == 1 && (dt == DT::F64 || second_field);
-  const size_t tries = std::min<size_t>(ranked.size(), (size_t)std::max<long long>(1, pl.opt.get("k1.tries", more ? 24 : 8)));
+  const size_t tries = std::min<size_t>(ranked.size(), (size_t)(more ? 24 : 8));
   int rejected = 0, sgpr_rejects = 0;
   // Dense 3-D groups (box-like: every operator reads 18 or more of the 27 offsets of one field)
   // are bound by vector-instruction issue; letting the scheduler mix the rows of a step is worth
@@ -838,28 +781,74 @@ std::string describe_plan(const sf_plan& pl) {
   return desc.str();
 }
 
-// Values outside an option's range are the caller's mistake and are reported;
-// (a shape no kernel can serve is not: that group falls back to the generic kernel)
+// THE plan options (sf_plan_create's `options`, $SF_HIP_OPTIONS): a key that is not in this table is refused, and so is
+// a value outside its range -- the caller's mistake, reported (a shape no kernel can serve is not: that group falls
+// back to the generic kernel).  `slab` is the one option with a text value.  Round 5 froze this list: the switches of
+// rounds 1-4's measurements (kernel variants that were never planned, timing-only builds with wrong results) are gone
+// from the library; what each measured is in NOTES.md, and timing-only code objects are built outside the library
+// (tools/whatif_objects.py).
+struct OptionSpec {
+  const char* key;
+  long long lo, hi;
+  const char* what;
+};
+static const OptionSpec kOptions[] = {
+    {"fuse", 1, 8, "operators per fused launch (default: 2 for 3-D float32, 3 for float64, 4 for 2-D)"},
+    {"reorder", 0, 1, "plan the operators depth first, the operators of one branch next to each other (default 1)"},
+    {"dag", 0, 1, "fuse forks and joins into DAG groups (default 1)"},
+    {"dag.windows", 1, 8, "register windows a DAG group may hold (default: 6 in 2-D, fuse + 1 in 3-D)"},
+    {"star", 0, 1, "kernel family switch: fused radius-1 star groups, kernels/star3d.h (default 1)"},
+    {"compact", 0, 1, "kernel family switch: fused groups over {-1,0,1}^3, kernels/compact3d.h (default 1)"},
+    {"wide", 0, 1, "kernel family switch: fused radius-2 star groups, kernels/wstar3d.h (default 1)"},
+    {"dense", 0, 1, "kernel family switch: dense neighbourhoods and plain sums, kernels/dense3d.h (default 1)"},
+    {"dense.t2", 0, 2, "two radius-1 plain sums per dense launch: 0 never, 1 where a tile fits the grid (default), 2 wherever one compiles"},
+    {"generic_only", 0, 1, "every operator on the generic kernel, one per launch"},
+    {"k1.bx", 0, 1024, "pin the tile shape, 3-D: lanes per row (with k1.by and k1.rj)"},
+    {"k1.by", 0, 64, "pin the tile shape, 3-D: thread rows"},
+    {"k1.rj", 0, 16, "pin the tile shape, 3-D: rows per thread"},
+    {"k2.bx", 0, 1024, "pin the tile shape, 2-D: lanes per block"},
+    {"k1.vk", 1, 4, "elements per lane and row: 1, 2 or 4 (default: 16 bytes, less where rows do not hold whole vectors)"},
+    {"k1.li", 0, 1 << 30, "planes per chunk of a 3-D launch (default: the launch-geometry model)"},
+    {"k2.li", 0, 1 << 30, "rows per chunk of a 2-D launch"},
+    {"k1.nt", 0, 5, "cache policy bits: 1 non-temporal stores, 4 non-temporal loads of unshared rows (default: 5 beyond 256 MiB)"},
+    {"allow_spills", 0, 1, "accept a PINNED tile shape whose code object spills (experiments)"},
+    {"autotune", 0, 8, "time the first k clean tile shapes on the device and keep the fastest"},
+    {"graph", 0, 1, "replay the chain as one hipGraph (default: launch-bound chains only)"},
+    {"profile", 0, 1, "HIP events around every launch (sf_plan_kernel_launch_times)"},
+    {"debug", 0, 1, "planner trace on stderr"},
+    {"slab", 0, 0, "<lo>:<hi>:<halo>[:<extent>] -- this plan computes planes [lo, hi) of a decomposed run"},
+};
+
+std::string describe_options() {
+  std::ostringstream o;
+  for (const OptionSpec& sp : kOptions) o << sp.key << (std::strcmp(sp.key, "slab") == 0 ? "=" : "=<int>  ") << sp.what << "\n";
+  return o.str();
+}
+
 static void validate_options(const sf_plan& pl) {
-  struct Range {
-    const char* key;
-    long long lo, hi;
-  };
-  static const Range ranges[] = {{"k1.pf2", 0, 3}, {"k1.rev", 0, 2},  {"k1.dpp", 0, 4},   {"k1.bio", 0, 3},
-                                 {"k1.ul", 0, 1},  {"k1.db", 0, 1},   {"k1.nt", 0, 7},    {"k1.auxpre", 0, 2},
-                                 {"graph", 0, 1},  {"autotune", 0, 8}, {"k1.order", 0, 1}};
-  for (const Range& r : ranges) {
-    if (!pl.opt.kv.count(r.key)) continue;
-    const long long v = pl.opt.get(r.key, r.lo);
-    if (v < r.lo || v > r.hi)
-      throw Error(SF_ERR_INVALID, std::string("option ") + r.key + " must lie in [" + std::to_string(r.lo) + ", " +
-                                      std::to_string(r.hi) + "]");
+  for (auto& kv : pl.opt.kv) {
+    const OptionSpec* spec = nullptr;
+    for (const OptionSpec& sp : kOptions)
+      if (kv.first == sp.key) spec = &sp;
+    if (!spec)
+      throw Error(SF_ERR_INVALID, "unknown plan option '" + kv.first + "' (sf_describe_options lists the " +
+                                      std::to_string(sizeof(kOptions) / sizeof(kOptions[0])) + " there are)");
+    if (kv.first == "slab") continue;
+    long long v = 0;
+    try {
+      size_t used = 0;
+      v = std::stoll(kv.second, &used);
+      if (used != kv.second.size()) throw std::invalid_argument("trailing text");
+    } catch (const std::exception&) {
+      throw Error(SF_ERR_INVALID, "option " + kv.first + " takes an integer, not '" + kv.second + "'");
+    }
+    if (v < spec->lo || v > spec->hi)
+      throw Error(SF_ERR_INVALID, std::string("option ") + spec->key + " must lie in [" + std::to_string(spec->lo) + ", " +
+                                      std::to_string(spec->hi) + "]");
   }
-  if (pl.opt.kv.count("k1.vk") && pl.opt.get("k1.vk", 4) != 1 && pl.opt.get("k1.vk", 4) != 2 &&
-      pl.opt.get("k1.vk", 4) != 4)
-    throw Error(SF_ERR_INVALID, "k1.vk must be 1, 2 or 4");
-  if (pl.opt.kv.count("k1.pfd") && pl.opt.get("k1.pfd", 1) != 1 && pl.opt.get("k1.pfd", 1) != 3)
-    throw Error(SF_ERR_INVALID, "k1.pfd must be 1 or 3");
+  if (pl.opt.kv.count("k1.vk") && pl.opt.get("k1.vk", 4) == 3) throw Error(SF_ERR_INVALID, "k1.vk must be 1, 2 or 4");
+  if (pl.opt.kv.count("k1.nt") && (pl.opt.get("k1.nt", 0) & ~5) != 0)
+    throw Error(SF_ERR_INVALID, "k1.nt: 1 (non-temporal stores), 4 (non-temporal loads of unshared rows) or 5");
 }
 
 // ---- DAG groups (kernels/star3d.h: stages over register windows) ---------------------------------------------
@@ -1230,7 +1219,7 @@ void build_plan(sf_plan& pl) {
     // spatial field, a box after a cross) while the compact kernel -- whose 27 offsets include every star -- could take
     // both: the longer group wins, it saves a write and a read of the field between them (round 4; the generator's
     // `num_fields_spatial 0.5` chains: 5 launches -> 4).  compact.prefer=0 restores the star-first order.
-    if (star && pl.opt.get("compact.prefer", 1) != 0) {
+    if (star) {
       const int ls = star_chain_len(k);
       if (ls < fuse && compact_chain_len(k) > ls) star = false;
     }
@@ -1462,7 +1451,7 @@ void build_plan(sf_plan& pl) {
         st.kernels.push_back(k);
       }
       // dense neighbourhoods of radius 2 (the generator's box of extent 2): one operator per launch, LDS tiles
-      const bool dense_r3 = pl.opt.get("dense.r3", 1) != 0 && dense_r3_eligible(P, P.kernels[k]);
+      const bool dense_r3 = dense_r3_eligible(P, P.kernels[k]);
       if (!st.star && st.kernels.size() == 1 && !generic_only && star_ok_dims && pl.opt.get("dense", 1) != 0 &&
           (dense_eligible(P, P.kernels[k]) || dense_r3)) {
         StarChoice choice = select_dense(pl, star_memo, k, P.kernels[k].dt, dense_r3 ? 3 : 2);
@@ -1637,21 +1626,19 @@ void build_plan(sf_plan& pl) {
       // 4 points per thread with aligned vector loads when rows allow it; the
       // one-point form is kept for short rows and for operators whose vector
       // form would spill (same acceptance rule as for the star kernels)
-      const bool vec = (P.n[2] % 4 == 0) && pl.opt.get("generic.vec", 1) != 0;
-      const bool xcd = pl.opt.get("generic.xcd", 1) != 0;
+      const bool vec = P.n[2] % 4 == 0;
+      const bool xcd = true;  // (XCD-aware block order)
       // non-temporal output stores for fields beyond the Infinity Cache (see rank_star_cfgs)
       const double out_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] *
                                (double)P.n[2] * (double)size_of(dt);  // (alike on all ranks of a slab run)
-      const bool nts = pl.opt.get("generic.nt", out_bytes >= 256.0 * 1024 * 1024 ? 1 : 0) != 0;
-      // marching form (a thread walks `generic.ppt` planes with a register window,
-      // default 8) for 3-D programs; generic.march=0 restores the one-plane form
-      const bool march = vec && P.n[0] > 1 && pl.opt.get("generic.march", 1) != 0 && pl.opt.get("generic.bio", 0) == 0 &&
-                         pl.opt.get("generic.fast", 0) == 0;  // (those two are variants of the one-plane form)
-      const int ppt = (int)std::max<long long>(1, std::min<long long>(march ? 256 : 8, pl.opt.get("generic.ppt", march ? 8 : 1)));
+      const bool nts = out_bytes >= 256.0 * 1024 * 1024;
+      // marching form (a thread walks 8 planes with a register window) for 3-D programs; the one-plane form where
+      // the marching one does not compile cleanly
+      const bool march = vec && P.n[0] > 1;
+      const int ppt = march ? 8 : 1;
       auto make = [&](bool marching) {
         return marching ? gen_generic_march(P, st.kernels[0], xcd, nts, ppt)
-               : vec    ? gen_generic_vec(P, st.kernels[0], xcd, nts, march ? 1 : ppt, pl.opt.get("generic.fast", 0) != 0,
-                                          pl.opt.get("generic.bio", 0) != 0)
+               : vec    ? gen_generic_vec(P, st.kernels[0], xcd, nts, 1, false, false)
                         : gen_generic(P, st.kernels[0], xcd, nts);
       };
       GenericKernelSource g = make(march);

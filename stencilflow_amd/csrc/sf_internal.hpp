@@ -139,7 +139,6 @@ struct sf_plan {
   std::string description;
   bool autotuned = false;
   std::string poisoned;  // a failed plan-time self-check: every later use of the plan reports it
-  void* debug_buffer = nullptr;  // diagnostic builds (option stamp=1): 8 x uint64
   // per-launch profiling events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<int> prof_kernel;
@@ -170,6 +169,7 @@ void check_pinned_compiler();
 // ---- planner.cpp: launch groups, tile search, buffers
 void build_plan(sf_plan& pl);
 std::string describe_plan(const sf_plan& pl);
+std::string describe_options();  // the table of plan options (planner.cpp: kOptions)
 size_t star_lds_bytes(const StarCfg& c, DT dt);
 long long star_chunk_length(const sf_plan& pl, const StarCfg& c, DT dt, int range, int ranges = 1);
 

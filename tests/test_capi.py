@@ -48,7 +48,7 @@ def test_fusion_and_buffer_reuse(tmp_path):
         assert "4 device buffers" in plan.describe()
         # the innermost-dimension halo travels through the DPP data path
         src = plan.kernel_source(0)
-        assert "#define SF_DPP 4" in src and "__builtin_amdgcn_update_dpp" in src
+        assert "__builtin_amdgcn_update_dpp" in src and "__shfl_up(" not in src
     with backend.Plan(lower(chain), options={"fuse": 3}) as plan:
         assert plan.num_launches == 4 and len(plan.kernel_names()) == 2
     c5 = programs.write_program(
@@ -119,9 +119,8 @@ def test_planner_shapes_for_the_benchmark_configurations(tmp_path):
 
 
 def test_memory_instruction_modes_compile_clean(tmp_path):
-    """Branch-free buffer loads/stores (k1.bio) and the four-slot input ring
-    (k1.pf2=2): the generated kernels compile for gfx950 without spills, and the
-    2-D and f64 defaults use them."""
+    """Branch-free buffer loads/stores and the four-slot input ring (2-D and float32 3-D; float64 3-D loads straight
+    into the freed window slot): the generated kernels compile for gfx950 without spills."""
     from stencilflow_amd.backend import Plan
     from stencilflow_amd.lowering import lower
     import stencilflow_amd as sf
@@ -130,38 +129,46 @@ def test_memory_instruction_modes_compile_clean(tmp_path):
         path = programs.write_program(prog, str(tmp_path / "p.json"))
         return Plan(lower(sf.KernelChainGraph(path)), options=options)
 
-    for opts in ({}, {"k1.bio": 0}, {"k1.pf2": 1}, {"k1.bio": 0, "k1.pf2": 0, "k1.ul": 1}):
-        with plan_of(programs.jacobi3d((64, 64, 128), 4), opts) as plan:
-            text, src = plan.describe(), plan.kernel_source(0)
-            assert "star T=2" in text and "spill 0 scratch 0" in text, text
-            assert "#define SF_BUFFER_IO %d" % opts.get("k1.bio", 1) in src
-            assert "#define SF_PREFETCH2 %d" % opts.get("k1.pf2", 2) in src
+    with plan_of(programs.jacobi3d((64, 64, 128), 4)) as plan:
+        text, src = plan.describe(), plan.kernel_source(0)
+        assert "star T=2" in text and "spill 0 scratch 0" in text, text
+        assert "#define SF_RING4 1" in src and "raw_buffer_load" in src and "raw_buffer_store" in src
     with plan_of(programs.jacobi2d((256, 512), 4)) as plan:
-        src = plan.kernel_source(0)
-        assert "#define SF_BUFFER_IO 1" in src and "#define SF_PREFETCH2 2" in src and "#define SF_REVERSE 0" in src
+        assert "#define SF_RING4 1" in plan.kernel_source(0)
     with plan_of(programs.diffusion_advection_laplacian((32, 64, 128))) as plan:
-        assert "#define SF_BUFFER_IO 1" in plan.kernel_source(0)
-    with pytest.raises(ValueError):
-        plan_of(programs.jacobi3d((64, 64, 128), 4), {"k1.pf2": 4})  # (3 = the five-slot ring of round 4)
+        assert "#define SF_RING4 0" in plan.kernel_source(0)
 
 
-def test_environment_options_and_generic_buffer_loads(tmp_path, monkeypatch):
-    """SF_HIP_OPTIONS supplies defaults that the caller's options override key by
-    key; generic.bio=1 turns the generic kernel's guarded loads into buffer loads."""
-    from stencilflow_amd.backend import Plan
+def test_environment_options_and_the_frozen_option_table(tmp_path, monkeypatch):
+    """SF_HIP_OPTIONS supplies defaults that the caller's options override key by key.  Round 5 froze the option table
+    (sf_describe_options: 24 keys): a key that is not in it -- the measurement switches of rounds 1-4, among them
+    `debug.whatif`, `experiment` and `stamp`, which built kernels with deliberately wrong results -- is refused,
+    from either source, and so is a value that is not an integer."""
+    from stencilflow_amd.backend import Plan, describe_options
     from stencilflow_amd.lowering import lower
     import stencilflow_amd as sf
     path = programs.write_program(programs.jacobi3d((16, 32, 64), 2), str(tmp_path / "p.json"))
     sfir = lower(sf.KernelChainGraph(path))
-    monkeypatch.setenv("SF_HIP_OPTIONS", "generic_only=1;generic.bio=1")
+    monkeypatch.setenv("SF_HIP_OPTIONS", "generic_only=1")
     with Plan(sfir) as plan:
         assert "[point]" in plan.describe()
-        assert "raw_buffer_load_b128" in plan.kernel_source(0)
     with Plan(sfir, options={"generic_only": 0}) as plan:
         assert "[star" in plan.describe()
+    monkeypatch.setenv("SF_HIP_OPTIONS", "debug.whatif=24")
+    with pytest.raises(ValueError, match="unknown plan option 'debug.whatif'"):
+        Plan(sfir)
     monkeypatch.delenv("SF_HIP_OPTIONS")
     with Plan(sfir, options={"generic_only": 1}) as plan:
         assert "[point]" in plan.describe()
+    keys = [line.split("=")[0] for line in describe_options().strip().splitlines()]
+    assert len(keys) == len(set(keys)) <= 25 and {"fuse", "slab", "k1.bx", "dense.t2", "generic_only"} <= set(keys), keys
+    for gone in ("debug.whatif", "experiment", "stamp", "k1.xlane", "k1.xbatch", "k1.pf2", "k1.skip", "k1.prio", "k1.bio",
+                 "dense.il", "dense.early", "dense.stream", "generic.fast", "fuze"):
+        assert gone not in keys
+        with pytest.raises(ValueError, match="unknown plan option"):
+            Plan(sfir, options={gone: 1})
+    with pytest.raises(ValueError, match="takes an integer"):
+        Plan(sfir, options="fuse=two")
 
 
 def test_autotune_compiles_alternative_tile_shapes(tmp_path):
@@ -338,32 +345,30 @@ def test_a_pinned_compiler_that_is_not_the_one_in_use_is_refused(tmp_path):
     assert "refused:" in r.stdout and "SF_HIP_COMGR pins the device compiler" in r.stdout, r.stdout + r.stderr
 
 
-def test_dense_and_compact_kernel_forms_of_round_4(tmp_path):
-    """Plan-time view (no device) of round 4's kernel forms: the generator's 125-point box -- terms plane by plane -- takes
-    the dense kernel's streaming form (two LDS slots instead of six) unless dense.stream=0; the 27-point box takes the
-    compact kernel with its LDS reads issued a row ahead, and the measured alternatives of its lane exchange (k1.xbatch,
-    k1.xlane, k1.ahead=0) compile without spilling at a tile the register budget allows."""
+def test_dense_and_compact_kernel_forms(tmp_path):
+    """Plan-time view (no device): the generator's 125-point box -- one plain sum -- takes the dense kernel's streaming form
+    with its planes arriving by LDS-DMA into a ring of two slots (round 5; six slots and staging registers in the general
+    form, which an operator that is not a plain sum takes); the 27-point box takes the compact kernel under dense.t2=0."""
     big, _ = programs.synthesize("float32", 2, 0.0, 64, 64, 64, 2, 2, 2, stencil_shape="box")
     sfir = lower(sf.KernelChainGraph(programs.write_program(big, str(tmp_path / "big.json"))))
     with backend.Plan(sfir) as plan:
         src = plan.kernel_source(0)
         assert "[dense" in plan.describe() and "#define SF_DENSE_STREAM 1" in src and "#define SFD_DLAST 2" in src
+        assert "#define SF_IN_SLOTS 2" in src and "offen lds" in src and "#define SF_LAG" not in src.split("typedef")[0]
         stream_lds = plan.kernel_resources()[plan.kernel_names()[0]]["lds"]
-    with backend.Plan(sfir, options={"dense.stream": 0}) as plan:
-        assert "#define SF_DENSE_STREAM 1" not in plan.kernel_source(0)
-        assert plan.kernel_resources()[plan.kernel_names()[0]]["lds"] == 3 * stream_lds
+        assert stream_lds % 2048 == 0  # (two slots of whole 1-KiB pieces)
+    for k in big["program"].values():
+        k["computation_string"] = k["computation_string"].replace(" + ", " - ", 1)  # (no longer a plain sum)
+    sfir = lower(sf.KernelChainGraph(programs.write_program(big, str(tmp_path / "general.json"))))
+    with backend.Plan(sfir) as plan:
+        assert "[dense" in plan.describe() and "#define SF_DENSE_STREAM 1" not in plan.kernel_source(0)
+        assert plan.kernel_resources()[plan.kernel_names()[0]]["lds"] > 2.5 * stream_lds  # (six slots)
     box, _ = programs.synthesize("float32", 2, 0.0, 64, 64, 64, 1, 1, 1, stencil_shape="box")
     sfir = lower(sf.KernelChainGraph(programs.write_program(box, str(tmp_path / "box.json"))))
-    with backend.Plan(sfir) as plan:
+    with backend.Plan(sfir, options={"dense.t2": 0}) as plan:
         assert "[compact" in plan.describe()
-        assert "#define SF_XLANE 1" not in plan.kernel_source(0) and "#define SF_XBATCH 1" not in plan.kernel_source(0)
-    for opt, macro in (({"k1.xbatch": 1}, "#define SF_XBATCH 1"), ({"k1.xlane": 1}, "#define SF_XLANE 1"),
-                       ({"k1.ahead": 0}, "#define SF_LDS_AHEAD 0")):
-        with backend.Plan(sfir, options=opt) as plan:
-            assert "[compact" in plan.describe(), (opt, plan.describe())
-            assert macro in plan.kernel_source(0), opt
-            res = plan.kernel_resources()[plan.kernel_names()[0]]
-            assert res["spills"] == 0 and res["scratch"] == 0, (opt, res)
+        res = plan.kernel_resources()[plan.kernel_names()[0]]
+        assert res["spills"] == 0 and res["scratch"] == 0, res
 
 
 def test_a_kernel_family_that_fails_to_compile_is_reported(tmp_path, monkeypatch, capfd):
@@ -385,33 +390,32 @@ def test_a_short_star_chain_joins_the_compact_group_that_follows(tmp_path):
     """The generator's chains with a second spatial field in every other operator (num_fields_spatial 0.5): operator 0 is a
     star, operator 1 is not -- the star chain would end after one operator and every later group start one operator
     late (5 launches for 8 operators).  The compact kernel takes both, so the planner forms the longer group (4
-    launches); compact.prefer=0 restores the star-first order."""
+    launches)."""
     prog, _ = programs.synthesize("float32", 8, 0.5, 64, 64, 64, 1, 1, 1)
     sfir = lower(sf.KernelChainGraph(programs.write_program(prog, str(tmp_path / "p.json"))))
     with backend.Plan(sfir) as plan:
         text = plan.describe()
         assert text.count("\n  launch ") == 4 and text.count("[compact windows 3 T=2") == 4, text
-    with backend.Plan(sfir, options={"compact.prefer": 0}) as plan:
-        text = plan.describe()
-        assert text.count("\n  launch ") == 5 and "[star T=1" in text, text
 
 
-def test_radius_three_boxes_take_the_streaming_dense_kernel(tmp_path):
+def test_radius_three_boxes_and_crosses_take_the_streaming_dense_kernel(tmp_path):
     """The generator's box of extent 3 (343 points): a plain sum ordered by plane -- the dense kernel's streaming form with
     seven open output planes (round 4); before, the operator did not even compile on the generic kernel (342 nested
-    parentheses; sources that deep now get -fbracket-depth).  A radius-3 cross lists its planes out of order and stays on
-    the generic kernel."""
+    parentheses; sources that deep now get -fbracket-depth).  A radius-3 CROSS lists its planes out of order (i-3 .. i+3,
+    then j, then k): since round 5 its 12 in-plane terms join their output plane three steps after the plane arrived,
+    the ring keeping three more planes (SF_LAG 3, codegen.hpp: stream_schedule) -- off the generic kernel."""
     box, _ = programs.synthesize("float32", 2, 0.0, 48, 48, 64, 3, 3, 3, stencil_shape="box")
     sfir = lower(sf.KernelChainGraph(programs.write_program(box, str(tmp_path / "box.json"))))
     with backend.Plan(sfir) as plan:
         assert "[dense" in plan.describe() and "#define SF_ACCS 7" in plan.kernel_source(0), plan.describe()
-    with backend.Plan(sfir, options={"dense.r3": 0}) as plan:
+    with backend.Plan(sfir, options={"dense": 0}) as plan:
         assert "[point]" in plan.describe()
         assert "-fbracket-depth" in plan.kernel_object(0)[1]
     cross, _ = programs.synthesize("float32", 2, 0.0, 48, 48, 64, 3, 3, 3)
     sfir = lower(sf.KernelChainGraph(programs.write_program(cross, str(tmp_path / "cross.json"))))
     with backend.Plan(sfir) as plan:
-        assert "[point]" in plan.describe()
+        src = plan.kernel_source(0)
+        assert "[dense" in plan.describe() and "#define SF_LAG 3" in src and "#define SF_IN_SLOTS 5" in src, plan.describe()
 
 
 def test_float64_boxes_take_the_fused_dense_form_or_compact_groups_two_deep(tmp_path):

@@ -143,22 +143,11 @@ def test_jacobi3d_chain_random(tmp_path, shape, fuse):
     {"fuse": 2, "k1.bx": 64, "k1.by": 4, "k1.rj": 4},
     {"fuse": 2, "k1.li": 7},
     {"fuse": 4, "k1.rj": 2, "k1.by": 8},
-    {"fuse": 2, "k1.pf2": 1},
-    {"fuse": 1, "k1.pf2": 1, "k1.li": 5},
-    {"fuse": 3, "k1.pf2": 1, "k1.spread": 0},
-    {"fuse": 2, "k1.spread": 0, "k1.db": 0},
-    {"fuse": 2, "k1.bio": 1},
-    {"fuse": 2, "k1.bio": 1, "k1.pf2": 2},
-    {"fuse": 3, "k1.pf2": 2},
-    {"fuse": 1, "k1.bio": 1, "k1.pf2": 0, "k1.li": 5},
-    {"fuse": 2, "k1.bio": 1, "k1.rev": 1},
-    {"fuse": 2, "k1.bio": 1, "k1.rev": 2, "k1.pfd": 3},
-    {"fuse": 2, "k1.ul": 1, "k1.pf2": 2},
-    {"fuse": 2, "k1.bio": 0},
-    {"fuse": 3, "k1.bio": 0, "k1.pf2": 1},
-    {"fuse": 2, "k1.bio": 0, "k1.pf2": 0, "k1.ul": 1},
+    {"fuse": 1, "k1.li": 5},
+    {"fuse": 3},
+    {"fuse": 2, "k1.nt": 5},
     {"generic_only": 1},
-])
+])  # (round 5: the switches between input schemes, step orders and memory instructions are gone with their variants)
 def test_jacobi3d_tile_shapes(tmp_path, options):
     shape, stages = (37, 50, 136), 4
     rng = np.random.default_rng(SEED + 1)
@@ -171,11 +160,7 @@ def test_jacobi3d_tile_shapes(tmp_path, options):
 
 
 @pytest.mark.parametrize("shape", [(20, 33, 64), (6, 5, 520), (70, 3, 8), (9, 30, 512)])
-@pytest.mark.parametrize("options", [
-    {"fuse": 1, "k1.bio": 1},
-    {"fuse": 2, "k1.bio": 1, "k1.pf2": 2},
-    {"fuse": 3, "k1.bio": 1, "k1.pf2": 1},
-])
+@pytest.mark.parametrize("options", [{"fuse": 1}, {"fuse": 2}, {"fuse": 3}])
 def test_buffer_io_nonzero_boundary(tmp_path, shape, options):
     """Branch-free buffer loads return 0 outside a plane; a boundary constant
     other than +0 must still come out of the padding select (partial tiles,
@@ -189,27 +174,6 @@ def test_buffer_io_nonzero_boundary(tmp_path, shape, options):
     got, desc = _run_gpu(path, {"a": x}, options=options)
     assert "star" in desc
     assert np.array_equal(got["b%d" % (stages - 1)], want)
-
-
-@pytest.mark.parametrize("options", [
-    {"k1.rev": 1},
-    {"k1.bio": 0},
-    {"k1.bio": 0, "k1.pf2": 1},
-    {"k1.bio": 1, "k1.pf2": 0},
-    {"k1.rev": 2, "k1.pfd": 3},
-])
-def test_jacobi2d_step_orders(tmp_path, options):
-    """The 2-D kernel's other step orders and input schemes (the default is
-    stage-1-first with the four-slot input ring and buffer loads/stores)."""
-    shape, stages = (333, 264), 8
-    rng = np.random.default_rng(SEED + 12)
-    x = rng.uniform(-1, 1, shape).astype(np.float32)
-    prog = programs.jacobi2d(shape, stages, bc_value=0.5)
-    path = _write(tmp_path, prog)
-    want = npo.run_reference(prog, {"a": x})["b7"]
-    got, desc = _run_gpu(path, {"a": x}, options=options)
-    assert "star" in desc
-    assert np.array_equal(got["b7"], want)
 
 
 def _lower_dim_aux_program(shape, dtype="float32"):
@@ -239,7 +203,7 @@ def _lower_dim_aux_program(shape, dtype="float32"):
 
 
 @pytest.mark.parametrize("shape", [(12, 20, 64), (9, 7, 130), (6, 33, 37)])
-@pytest.mark.parametrize("options", [{"fuse": 3}, {"fuse": 2}, {"fuse": 1, "k1.bio": 0}])
+@pytest.mark.parametrize("options", [{"fuse": 3}, {"fuse": 2}, {"fuse": 1}])
 def test_star_chain_with_lower_dimensional_auxiliary_fields(tmp_path, shape, options):
     """Fields lacking dimensions ride along as auxiliary fields of the fused star
     kernel (indexed by the dimensions they have; one value per vector where the
@@ -878,14 +842,11 @@ def test_full_c2_configuration_bit_exact():
     ((12, 18, 40), "float32", {"type": "shrink"}, True),
     ((70, 136), "float32", {"type": "constant", "value": 0.0}, True),
 ])
-@pytest.mark.parametrize("stream", [1, 0])
-def test_generator_box_of_extent_two_in_the_plain_sum_form(tmp_path, dims, dtype, bc, sum_form, stream):
+def test_generator_box_of_extent_two_in_the_plain_sum_form(tmp_path, dims, dtype, bc, sum_form):
     """The generator's box of extent 2 (125 points, 25 in 2-D) is ONE left-associated sum whose terms come plane by
-    plane: the dense kernel reads every plane from LDS once and adds it to the five output planes that are open
-    (SF_DENSE_STREAM, the default since round 4); with dense.stream=0 it accumulates all rows of a thread in step,
-    term by term in the order of the text, a row segment read from LDS serving every row that needs it
-    (codegen.hpp: dense_sum_form).  Same results, bit for bit, as the oracle -- whatever type the boundary literal
-    gives the sum."""
+    plane: the dense kernel reads every plane from LDS once -- where it arrived by LDS-DMA, round 5 -- and adds it to
+    the five output planes that are open (SF_DENSE_STREAM; codegen.hpp: dense_sum_form, stream_schedule).  Same
+    results, bit for bit, as the oracle -- whatever type the boundary literal gives the sum."""
     full = list(dims) + [0] * (3 - len(dims))
     ext = [2 if d else 0 for d in full]
     prog, _ = programs.synthesize(dtype, 2, 0.0, *full, *ext, stencil_shape="box")
@@ -898,10 +859,9 @@ def test_generator_box_of_extent_two_in_the_plain_sum_form(tmp_path, dims, dtype
     from stencilflow_amd.backend import Plan
     from stencilflow_amd.lowering import lower
     got = np.zeros(dims, dtype)
-    with Plan(lower(chain), options={"dense.stream": stream}) as plan:
+    with Plan(lower(chain)) as plan:
         assert "[dense" in plan.describe(), plan.describe()
-        assert ("#define SF_DENSE_ROWS 1" in plan.kernel_source(0)) == sum_form
-        assert ("#define SF_DENSE_STREAM 1" in plan.kernel_source(0)) == bool(stream)
+        assert ("#define SF_DENSE_STREAM 1" in plan.kernel_source(0)) == sum_form
         plan.run([x], [got], 1)
     if bc["type"] == "copy":
         with Plan(lower(chain), options={"generic_only": 1}) as ref:
@@ -922,11 +882,12 @@ def test_generator_box_of_extent_two_in_the_plain_sum_form(tmp_path, dims, dtype
     ((15, 19, 40), "float32", {"type": "shrink"}),
     ((90, 136), "float32", {"type": "constant", "value": -1}),
     ((60, 72), "float32", {"type": "constant", "value": 0.5}),       # float literal: the sum runs in double (49 points: still fits)
+    ((10, 13, 24), "float32", {"type": "constant", "value": 0.5}),   # ... and 343 points: one row per thread (round 5)
 ])  # (a 343-term operator takes ~25 s to compile per kernel form: few cases, the generic cross-check on the 2-D ones only)
 def test_generator_box_of_extent_three_streams_through_the_dense_kernel(tmp_path, dims, dtype, bc):
     """The generator's box of extent 3 (343 points, 49 in 2-D; verdict r03, next 9: radius 3) is a plain sum ordered by
     plane like its smaller siblings: the dense kernel's streaming form with seven open output planes and four halo
-    columns per LDS row (codegen.hpp: dense_r3_eligible).  Same results, bit for bit, as the oracle; dense.r3=0 leaves
+    columns per LDS row (codegen.hpp: dense_r3_eligible).  Same results, bit for bit, as the oracle; dense=0 leaves
     it to the generic kernel, which must agree."""
     full = list(dims) + [0] * (3 - len(dims))
     ext = [3 if d else 0 for d in full]
@@ -939,18 +900,18 @@ def test_generator_box_of_extent_three_streams_through_the_dense_kernel(tmp_path
     from stencilflow_amd.backend import Plan
     from stencilflow_amd.lowering import lower
     got = np.zeros(dims, dtype)
-    # (a float boundary literal types the sum of a float32 operator double: in 3-D seven sets of two-register
-    #  accumulators spill in every tile shape and the operator stays on the generic kernel -- correct, 40 x slower)
-    streams = not (len(dims) == 3 and dtype == "float32" and isinstance(bc.get("value"), float))
+    # (a float boundary literal types the sum of a float32 operator double: seven sets of two-register accumulators.
+    #  Until round 4 they spilled in every 3-D tile shape and the operator ran on the generic kernel, 46 x slower; with
+    #  the planes arriving by LDS-DMA -- no staging registers -- the one-row-per-thread shape is clean)
     with Plan(lower(chain)) as plan:
-        assert ("[dense" in plan.describe()) == streams, plan.describe()
-        if streams:
-            src = plan.kernel_source(0)
-            assert "#define SF_R 3" in src and "#define SF_RC 4" in src and "#define SF_ACCS 7" in src
+        assert "[dense" in plan.describe(), plan.describe()
+        src = plan.kernel_source(0)
+        assert "#define SF_R 3" in src and "#define SF_RC 4" in src and "#define SF_ACCS 7" in src
+        assert "#define SF_IN_SLOTS" in src  # (planes by LDS-DMA)
         plan.run([x], [got], 1)
     ref = None
     if len(dims) == 2:
-        with Plan(lower(chain), options={"dense.r3": 0}) as plan:
+        with Plan(lower(chain), options={"dense": 0}) as plan:
             assert "[dense" not in plan.describe()
             ref = np.zeros(dims, dtype)
             plan.run([x], [ref], 1)

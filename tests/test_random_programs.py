@@ -399,8 +399,8 @@ def test_hip_matches_oracle_on_random_dense_chains(seed, tmp_path):
 @pytest.mark.parametrize("seed", [0, 3, 4])
 def test_plain_sums_take_the_dense_kernels_sum_form(seed, tmp_path):
     """Operators that are one left-associated sum of accesses, the terms in any order (tests/random_programs.py:
-    dense_sum_program): the oracles agree, and the dense launches use the form that accumulates the rows of a
-    thread in step (SF_DENSE_ROWS 1 in the generated source)."""
+    dense_sum_program): the oracles agree, and the dense launches stream (SF_DENSE_STREAM 1 in the generated source: a
+    term joins its output plane at the step its plane and every earlier term have arrived, codegen.hpp: stream_schedule)."""
     prog, ins, chain = _dense_case(seed, tmp_path, "dense_sum_program")
     a = npo.run_reference(prog, inputs=ins)
     b = c_oracle.CompiledReference(prog).run(inputs=ins)
@@ -409,7 +409,7 @@ def test_plain_sums_take_the_dense_kernels_sum_form(seed, tmp_path):
     with Plan(lower(chain)) as plan:
         names = plan.kernel_names()
         dense = [i for i, n in enumerate(names) if n.startswith("sf_dense") and n in plan.describe()]
-        assert dense and all("#define SF_DENSE_ROWS 1" in plan.kernel_source(i) for i in dense), plan.describe()
+        assert dense and all("#define SF_DENSE_STREAM 1" in plan.kernel_source(i) for i in dense), plan.describe()
 
 
 @pytest.mark.gpu
@@ -561,25 +561,6 @@ def test_hip_matches_oracle_on_fused_pairs_of_plain_sums(seed, tmp_path):
         plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
         for n, got in zip(plan.output_names, outs):
             assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("extra", [{"k1.ahead": 0}, {"k1.xbatch": 1}, {"k1.xlane": 1}])
-@pytest.mark.parametrize("seed", COMPACT_GPU_SEEDS[:2])
-def test_compact_lane_exchange_variants_match_the_oracle(seed, extra, tmp_path):
-    """The measured alternatives of compact3d.h's neighbour exchange (round 4: LDS reads not issued a row ahead; the DPP
-    moves of a stage step in one burst; no DPP at all -- ds_swizzle and shifted reads of the row images) compute what
-    the default computes: bit for bit the oracle's results."""
-    prog, ins, chain, opt = _compact_case(seed, tmp_path)
-    want = npo.run_reference(prog, inputs=ins)
-    with Plan(lower(chain), options={**opt, **extra}) as plan:
-        if plan.scalar_names:
-            plan.set_scalars([ins[n] for n in plan.scalar_names])
-        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]])
-                for n in plan.output_names]
-        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
-        for n, got in zip(plan.output_names, outs):
-            assert np.array_equal(got, want[n], equal_nan=True), (seed, extra, n, plan.describe()[:600])
 
 
 @pytest.mark.gpu

@@ -5,7 +5,7 @@ random, awkward 3-D and 2-D domain sizes, each compared bit for bit with the ora
 Only + - * and selects, so every implementation must agree exactly.  Prints one JSON
 line per failing program and a progress line every 20 programs.
 
-usage: compact_fuzz.py [--seeds 300] [--first 0] [--options "k1.fence=0"]"""
+usage: compact_fuzz.py [--seeds 300] [--first 0] [--options "fuse=3"]"""
 import argparse
 import json
 import os

@@ -49,13 +49,11 @@ def main():
             sfir = lower(sf.KernelChainGraph(path))
             quick = "--quick" in sys.argv
             space = itertools.product([1, 2, 3], [64, 128], [1, 2, 4] if quick else [1, 2, 3, 4, 8],
-                                      [1, 2, 3, 5] if quick else [1, 2, 3, 4, 5, 6, 7, 8],
-                                      [1] if quick else [0, 1])
-            for fuse, bx, by, rj, db in space:
+                                      [1, 2, 3, 5] if quick else [1, 2, 3, 4, 5, 6, 7, 8])
+            for fuse, bx, by, rj in space:
                 if bx * by > 1024 or by * rj - 2 * fuse < 1:
                     continue
-                opt = {"fuse": fuse, "k1.bx": bx, "k1.by": by, "k1.rj": rj, "k1.db": db,
-                       "allow_spills": 1}
+                opt = {"fuse": fuse, "k1.bx": bx, "k1.by": by, "k1.rj": rj, "allow_spills": 1}
                 try:
                     plan = Plan(sfir, options=opt)
                 except ValueError:

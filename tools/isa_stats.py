@@ -101,14 +101,13 @@ def updates_per_iteration(name, mac):
     """Cell updates per thread in one iteration of the step loop."""
     t, rj, vk = mac.get("SF_T", 1), mac.get("SF_RJ", 1), mac.get("SF_VK", 1)
     if name.startswith("sf_star"):
-        pf2 = mac.get("SF_PREFETCH2", 0) if not mac.get("SF_REVERSE", 0) else 0
-        unroll = 3 + (2 if pf2 == 3 else 1 if pf2 == 2 else 0)
+        unroll = 3 + (1 if mac.get("SF_RING4", 0) else 0)  # (the four-slot input ring: the step loop is unrolled by four)
     elif name.startswith("sf_compact"):
         unroll = 4
     elif name.startswith("sf_wstar"):
         unroll = 5
     elif name.startswith("sf_dense"):
-        unroll, t = (5 if mac.get("SF_DENSE_STREAM", 0) else 6), 1  # (the streaming form rotates five accumulator sets)
+        unroll, t = (mac.get("SF_ACCS", 5) if mac.get("SF_DENSE_STREAM", 0) else 6), 1  # (the streaming form rotates its accumulator sets)
         if mac.get("SF_DENSE_T2", 0):
             unroll, t = 3, 2  # (two fused operators, three accumulator sets each)
         vk = mac.get("SF_VK", 4)

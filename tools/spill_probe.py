@@ -6,7 +6,7 @@ to spill, prints for every failing shape where the result differs, and keeps the
 generated source of failing and passing shapes under gpurun_out/spill/ for an
 offline look at the ISA (tools/isa_stats.py works on a program; here the source
 is saved as the library compiled it).
-usage: SF_HIP_UNSAFE_SGPR_SPILLS=1 SF_HIP_REPORT_SGPR_SPILLS=1 spill_probe.py [extra options, e.g. "k1.bio=0"]
+usage: SF_HIP_UNSAFE_SGPR_SPILLS=1 SF_HIP_REPORT_SGPR_SPILLS=1 spill_probe.py [extra options, e.g. "fuse=3"]
 (the first variable lets the library run code objects that spill SGPRs -- the
 thing under test; the second makes `scratch` of the resource record carry the
 SGPR spill count)"""

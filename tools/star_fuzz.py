@@ -4,7 +4,7 @@ plane-streaming kernel handles) on random, awkward domain sizes, each compared
 bit for bit with the oracle.  Only + - * and selects, so every implementation
 must agree exactly.  Prints one JSON line per failing program.
 
-usage: star_fuzz.py [--seeds 300] [--first 0] [--options "k1.rev=1"] [--generator star|wide]
+usage: star_fuzz.py [--seeds 300] [--first 0] [--options "fuse=3"] [--generator star|wide]
 (--generator wide: chains of radius-2 stars, kernels/wstar3d.h; fusion depth 1-3;
  --generator dense: operators with dense radius-2 neighbourhoods, kernels/dense3d.h;
  --generator box_sum: chains of plain sums over subsets of {-1,0,1}^d ordered by plane (round 4: the dense kernel's fused

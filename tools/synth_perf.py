@@ -2,7 +2,7 @@
 """GPU: throughput of programs from the workload generator (the reference's
 bin/synthesize.py conventions: integer boundary literals -> float32 sums,
 coefficient 1/n, optional extra fields) at benchmark size.
-usage: synth_perf.py [--size 512] [--stages 16] [--only hotspot] [--opts "k1.bio=1"]"""
+usage: synth_perf.py [--size 512] [--stages 16] [--only hotspot] [--opts "fuse=3"]"""
 import argparse
 import json
 import os
@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--stages", type=int, default=16)
     ap.add_argument("--only", default="", help="run the cases whose label contains this text")
-    ap.add_argument("--opts", default="", help="plan options, e.g. k1.bio=1;k1.pf2=2")
+    ap.add_argument("--opts", default="", help="plan options, e.g. fuse=3;k1.li=32")
     ap.add_argument("--fork", action="store_true",
                     help="only the fork / join programs (-fork_frequency 0.25), each with reorder=0 and reorder=1")
     args = ap.parse_args()
