@@ -56,6 +56,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+T_PROCESS_START = time.perf_counter()
 HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
 SEED = 20261003
 BLOCK = 64  # planes per seeded block of the synthetic grid
@@ -257,6 +258,13 @@ def make_workload(name, size, stages, slab_world=1):
         return dict(prog=prog, shape=shape, np_dtype=np.float32, dtype="f32", bpu=8.0, stages=stages, name=name,
                     label="radius-2 cross {}^3 float32 (bin/synthesize.py, extents 2 2 2), {}-operator chain".format(
                         n, stages))
+    if name == "cross3":
+        n = size or 512
+        shape = (n, n, n)
+        prog, _ = programs.synthesize("float32", stages, 0.0, n, n, n, 3, 3, 3)
+        return dict(prog=prog, shape=shape, np_dtype=np.float32, dtype="f32", bpu=8.0, stages=stages, name=name,
+                    label="radius-3 cross {}^3 float32 (bin/synthesize.py, extents 3 3 3), {}-operator chain".format(
+                        n, stages))
     if name == "dense":
         n = size or 512
         shape = (n, n, n)
@@ -314,6 +322,29 @@ def roofline_block(name, moved_per_full_launch, traffic, seconds, launches_equiv
         "algorithmic_achieved": alg / avg_s / 1e9,
         "algorithmic_frac": alg / avg_s / HBM_PEAK,
     }
+
+
+MALL_PEAK = 6.8e12  # B/s: a 64 MiB field copied back and forth inside the 256 MiB Infinity Cache (profiles/r03_copy_bw_64MiB_pingpong.log)
+
+
+def refine_roofline(roof, wl):
+    """Two workloads whose HBM fraction would mislead.
+    C2: the 64 MiB field of jacobi2d 4096^2 never leaves the Infinity Cache between launches -- FETCH_SIZE / WRITE_SIZE count
+    what crosses the fabric, not HBM -- so the launch is set against the rate of a ping-pong copy of the same field
+    (`bound: "mall"`, measured peak), and the HBM figure is kept beside it as `hbm_frac` for what it is worth.
+    C5: SURVEY.md 8(d) defines the figure of the fused f64 chain as 16 B per point per chain application; `frac` is that
+    one (the bytes the counters see, 1.05 x more, stay in `traffic` / `pmc_frac`)."""
+    if wl.get("name") == "c2":
+        roof["hbm_frac"] = roof["frac"]
+        roof.update(bound="mall", peak=MALL_PEAK / 1e9, frac=roof["achieved"] * 1e9 / MALL_PEAK,
+                    peak_basis="ping-pong copy of a 64 MiB field inside the Infinity Cache, 6.7-6.9 TB/s "
+                               "(profiles/r03_copy_bw_64MiB_pingpong.log); HBM sees none of this traffic in steady state")
+    elif wl.get("name") == "c5":
+        roof["pmc_frac"] = roof["frac"]
+        per_application = wl["bpu"] * float(np.prod(wl["shape"]))  # (one launch = one application of the three fused operators)
+        avg_s = roof["avg_launch_us"] * 1e-6
+        roof.update(frac=per_application / avg_s / HBM_PEAK, achieved=per_application / avg_s / 1e9,
+                    basis="algorithmic (SURVEY 8d: 16 B per point per application of the fused chain)")
 
 
 def launch_spread(plan, name):
@@ -404,6 +435,7 @@ def time_single(wl, options, steps, warmup, device=0):
             roof = roofline_block(name, traffic if traffic is not None else compulsory, traffic, kernel_ms * 1e-3,
                                   launches, launches, wl, fused, cells / launches)
             roof["compulsory_bytes_per_launch"] = compulsory
+            refine_roofline(roof, wl)
         else:
             # several kernels (fork / join programs): the roofline of the whole execution -- every launch's bytes
             # over the summed HIP-event time of the executions
@@ -631,17 +663,23 @@ class Decomposed:
             ladder = list(self.AFTER_TORCH)
         else:
             ladder = self.RUNGS[self.RUNGS.index(first):] if first in self.RUNGS else list(self.RUNGS)
-        native_env = os.environ.get("SF_BENCH_SCHEDULE")
         t_begin = time.perf_counter()
         best = None
+        self.ladder = []  # one record per rung tried: probe time, outcome, reason (config.ladder of the line)
         for rung in ladder:
             library_rung = rung in ("rccl", "p2p")
             if best is not None:
                 (elapsed, ) = self.agreed_max(time.perf_counter() - t_begin)
                 if first in self.RUNGS or first == "torch" or not library_rung or elapsed > budget:
                     break
-            native = library_rung and native_env != "python"
+            # the library's transports run the library's schedule (sf_plan_execute_decomposed); the spare rungs below
+            # them -- host memory, gloo -- have no sf_halo handle and run SlabRunner's Python form of it
+            native = library_rung
+            t_rung = time.perf_counter()
             seconds, runner, ex, check, msg = self.try_rung(rung, native)
+            (probe_s, ) = self.agreed_max(time.perf_counter() - t_rung)
+            self.ladder.append({"rung": rung, "ok": seconds is not None, "probe_s": round(probe_s, 3),
+                                "chain_ms": None if seconds is None else round(seconds * 1e3, 3), "reason": msg or None})
             if seconds is None:
                 self.notes.append("{} not used: {}".format(rung, msg))
                 continue
@@ -702,12 +740,6 @@ class Decomposed:
         self.notes.append("exchange {}, {} units reserved beside it ({})".format(
             "started a launch ahead" if early else "started with the launch that needs it", cus,
             ", ".join("{}/{}: {:.2f} ms".format("ahead" if e else "with", c, v * 1e3) for (e, c), v in timing.items())))
-        # the library's own schedule against SlabRunner's Python form of it (A/B)
-        if rung in ("rccl", "p2p") and os.environ.get("SF_BENCH_SCHEDULE") is None:
-            timing = {"native": self.chain_seconds(runner, True), "python": self.chain_seconds(runner, False)}
-            best["native"] = timing["native"] <= timing["python"]
-            self.notes.append("schedule: sf_plan_execute_decomposed {:.2f} ms, SlabRunner {:.2f} ms".format(
-                timing["native"] * 1e3, timing["python"] * 1e3))
         # the check follows the schedule that will be timed
         if groups == 8:
             check = best["check"]
@@ -756,11 +788,19 @@ class Decomposed:
         plan: the dominant kernel's bytes over its launch time (per GPU)."""
         runner = best["runner"]
         plan = runner.plan
+        ex = best["ex"]
         plan.set_profile(True)
+        if hasattr(ex, "set_profile"):
+            ex.set_profile(True)
         self.run_chain(runner, best["native"])
         plan.synchronize()
         stats, planes = plan.kernel_stats(), plan.kernel_planes()
         plan.set_profile(False)
+        self.exchange = None
+        if hasattr(ex, "exchange_times"):
+            count, mean_ms, max_ms = ex.exchange_times()
+            ex.set_profile(False)
+            self.exchange = {"exchanges": count, "mean_us": round(mean_ms * 1e3, 1), "max_us": round(max_ms * 1e3, 1)}
         name = max(stats, key=lambda k: stats[k]["algorithmic_bytes_per_launch"])
         n_local = runner.n_local
         full_launches = planes[name] / float(n_local)  # launches over ranges of other lengths, in full-slab units
@@ -770,6 +810,13 @@ class Decomposed:
         roof = roofline_block(name, traffic if traffic is not None else compulsory, traffic, stats[name]["total_ms"] * 1e-3,
                               full_launches, stats[name]["launches"], self.wl, fused, n_local * plane_cells * fused)
         roof["compulsory_bytes_per_launch"] = compulsory
+        if self.exchange:
+            # what an exchange has to hide behind: ONE interior launch (two with the exchange started a launch ahead)
+            self.exchange["interior_launch_us"] = roof.get("avg_launch_us")
+            self.exchange["cover_launches"] = 2 if getattr(runner, "early_exchange", False) else 1
+            self.exchange["scope"] = ("rank 0: HIP events on the transport's streams, from the moment the launches an exchange waits "
+                                      "for are done to the moment its planes have arrived (sf_halo_exchange_times)")
+            roof["exchange"] = self.exchange
         roof["scope"] = ("rank 0, one GPU: {} launches of one chain execution (interior, boundary and halo-extended "
                          "plane ranges) = {:.1f} full-slab launches; bytes scale with the planes a launch writes").format(
                              stats[name]["launches"], full_launches)
@@ -781,7 +828,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c3", "c2", "c5", "box", "wide", "dense", "fork"], default="c3",
+    ap.add_argument("--workload", choices=["c3", "c2", "c5", "box", "wide", "cross3", "dense", "fork"], default="c3",
                     help="c3 = jacobi3d 512^3 f32 (headline, default); c2 = "
                     "jacobi2d 4096^2 f32; c5 = diffusion/advection/laplacian "
                     "512^3 f64; box / wide = the generator's 27-point box chain / radius-2 cross "
@@ -865,7 +912,7 @@ def main():
             # (>= 10 timed steps each and the median beside the mean: SURVEY.md 8d; the whole set costs about
             # 1.5 s of GPU time)
             for name, stages, steps in (("c2", 1000, 10), ("c5", 300, 10), ("box", 16, 12), ("wide", 16, 12),
-                                        ("dense", 4, 12), ("fork", 16, 12)):
+                                        ("cross3", 8, 12), ("dense", 4, 12), ("fork", 16, 12)):
                 try:
                     owl = make_workload(name, 0, stages)
                     t = time_single(owl, {}, steps, 1, device=local_rank)
@@ -977,7 +1024,8 @@ def main():
     result["config"].update(
         decomposition="slab{} (halo {} planes, one exchange per {} launches, {})".format(
             slab_world, runner.halo, runner.halo // max(1, runner.steps[0][1]), transport),
-        ranks=world, transport=best["rung"],
+        ranks=world, transport=best["rung"], ladder=job.ladder,
+        wall_s=round(time.perf_counter() - T_PROCESS_START, 1),  # (the driver allows 600 s per run)
         schedule="sf_plan_execute_decomposed (libsf_hip.so)" if native else "SlabRunner (Python form of the same schedule)",
         verified=bool(verified),
         check=("first {} operators, decomposed vs each rank's local recomputation of its slab from the global "

@@ -327,6 +327,14 @@ const char* sf_halo_transport(const sf_halo* halo);
  * its planes next to the slab boundaries first -- so that a transfer slower than one
  * interior launch has two launches of cover. */
 int sf_halo_configure(sf_halo* halo, int reserved_cus, int early_exchange);
+/* Exchange profile (what the reference's distributed driver reports as communication time,
+ * bin/run_distributed_program.py:283-341 -- there per SMI channel, here per halo exchange): with `on` != 0 every
+ * sf_halo_start records two timing events on the transport's streams -- when the launches the exchange waits for are
+ * done, and when its planes have arrived.  sf_halo_exchange_times waits for the transport's streams and returns the
+ * number of exchanges since the profile was switched on and their mean / longest duration in milliseconds: to be set
+ * beside the duration of the interior launch an exchange has to hide behind (sf_plan_kernel_launch_times). */
+int sf_halo_set_profile(sf_halo* halo, int on);
+int sf_halo_exchange_times(sf_halo* halo, int* count, double* mean_ms, double* max_ms);
 /* One rank's execution of the whole chain, `repetitions` times, with the deep-halo
  * schedule: the plan was created with "slab=lo:hi:H" and every slab
  * buffer registered with `halo` under its buffer id.  After an exchange of H planes a

@@ -108,6 +108,8 @@ API = [
     ("sf_halo_use_rccl", _I, [_P, _P, _I, _I]),
     ("sf_halo_transport", _S, [_P]),
     ("sf_halo_configure", _I, [_P, _I, _I]),
+    ("sf_halo_set_profile", _I, [_P, _I]),
+    ("sf_halo_exchange_times", _I, [_P, _IP, _DP, _DP]),
     ("sf_plan_execute_decomposed", _I, [_P, _P, _I]),
 ]
 HALO_BLOB_BYTES = 256

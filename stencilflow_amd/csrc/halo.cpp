@@ -227,6 +227,16 @@ struct HaloBuffer {
 struct sf_halo {
   int rank = 0, world = 1, device = 0;
   unsigned timeout_ms = 20000;
+  // (RCCL rung) a word in pinned host memory the transport's stream ticks twice per exchange: sf_halo_check bounds the
+  // time WITHOUT PROGRESS with it
+  // exchange profile (sf_halo_set_profile): timing events on the transport's streams around every exchange -- from the
+  // moment the launches it waits for are done to the moment its planes have arrived
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  unsigned* progress = nullptr;       // device address
+  unsigned* progress_host = nullptr;  // the same word on the host
+  unsigned ticks = 0;
   std::string session;
   sf::FlagPage own, nb[2];
   std::map<int, sf::HaloBuffer> bufs;
@@ -363,6 +373,15 @@ int sf_halo_destroy(sf_halo* h) {
     if (can_abort) {
       if (h->send) (void)hipStreamSynchronize(h->send);
       if (h->recv) (void)hipStreamSynchronize(h->recv);
+    } else {
+      //  the stuck ncclSend / ncclRecv kernels are still on the streams: destroying the streams or freeing
+      // anything they use would block behind them for ever (hipFree synchronises the device) or pull memory from under
+      // a live kernel.  Everything the transport owns is LEAKED, and said so; the process is expected to end.
+      std::fprintf(stderr, "[sf_hip] sf_halo_destroy: rank %d: the failed RCCL communicator could not be aborted; its streams, events and "
+                           "mappings are leaked\n", h->rank);
+      h->bufs.clear();
+      delete h;
+      return SF_OK;
     }
   } else {
     if (h->send) (void)hipStreamSynchronize(h->send);
@@ -384,6 +403,11 @@ int sf_halo_destroy(sf_halo* h) {
   sf::unmap_flag_page(h->nb[1]);
   sf::unmap_flag_page(h->own);
   if (h->now) (void)hipEventDestroy(h->now);
+  for (auto& pe : h->prof_events) {
+    (void)hipEventDestroy(pe.first);
+    (void)hipEventDestroy(pe.second);
+  }
+  if (h->progress_host) (void)hipHostFree(h->progress_host);
   if (h->send) (void)hipStreamDestroy(h->send);
   if (h->recv) (void)hipStreamDestroy(h->recv);
   delete h;
@@ -436,6 +460,15 @@ int sf_halo_use_rccl(sf_halo* h, const void* id, int comm_rank, int comm_size) {
   sf::Rccl::comm_t comm = nullptr;
   SF_RCCL_CHECK(sf::rccl().CommInitRank(&comm, comm_size, uid, comm_rank));
   h->comm = comm;
+  if (!h->progress_host) {
+    void* word = nullptr;
+    SF_HIP_CHECK(hipHostMalloc(&word, 64, hipHostMallocMapped));
+    std::memset(word, 0, 64);
+    void* dev = nullptr;
+    SF_HIP_CHECK(hipHostGetDevicePointer(&dev, word, 0));
+    h->progress_host = static_cast<unsigned*>(word);
+    h->progress = static_cast<unsigned*>(dev);
+  }
   h->comm_rank = comm_rank;
   h->comm_size = comm_size;
   return SF_OK;
@@ -470,6 +503,7 @@ int sf_halo_export(sf_halo* h, int key, void* device_base, size_t plane_bytes, i
   if (h->world > 1 && !h->comm) SF_HIP_CHECK(hipIpcGetMemHandle(&out.mem, device_base));
   SF_HIP_CHECK(hipEventCreateWithFlags(&b.sent, hipEventDisableTiming));
   SF_HIP_CHECK(hipEventCreateWithFlags(&b.received, hipEventDisableTiming));
+
   out.plane_bytes = plane_bytes;
   out.n_local = n_local;
   out.halo = halo;
@@ -529,11 +563,24 @@ int sf_halo_start(sf_halo* h, int key, int depth, void* compute_stream) {
   // everything queued on the compute stream so far has completed
   SF_HIP_CHECK(hipEventRecord(h->now, (hipStream_t)compute_stream));
   SF_HIP_CHECK(hipStreamWaitEvent(h->send, h->now, 0));
+  hipEvent_t prof_end = nullptr;
+  if (h->profile) {
+    if (h->prof_used == h->prof_events.size()) {
+      hipEvent_t a = nullptr, z = nullptr;
+      SF_HIP_CHECK(hipEventCreate(&a));
+      SF_HIP_CHECK(hipEventCreate(&z));
+      h->prof_events.push_back({a, z});
+    }
+    SF_HIP_CHECK(hipEventRecord(h->prof_events[h->prof_used].first, h->send));
+    prof_end = h->prof_events[h->prof_used++].second;
+  }
   if (h->comm) {
     // RCCL: receives first, then sends, one pair per neighbour, in ONE group on the
     // transport's stream (ncclGroupStart; ncclSend/ncclRecv x <= 4; ncclGroupEnd)
     sf::Rccl& nc = sf::rccl();
     const bool self = h->comm_size == 1;
+    // (progress word: ticks when the launches the exchange waits for are done, and again when it has arrived)
+    if (h->progress) sf::halo_flag_set(h->send, h->progress, ++h->ticks);
     SF_RCCL_CHECK(nc.GroupStart());
     sf::Rccl::result_t r = 0;
     for (int d = 0; d < 2 && r == 0; ++d)
@@ -547,6 +594,8 @@ int sf_halo_start(sf_halo* h, int key, int depth, void* compute_stream) {
     const sf::Rccl::result_t e = nc.GroupEnd();
     SF_RCCL_CHECK(r);
     SF_RCCL_CHECK(e);
+    if (h->progress) sf::halo_flag_set(h->send, h->progress, ++h->ticks);
+    if (prof_end) SF_HIP_CHECK(hipEventRecord(prof_end, h->send));
     SF_HIP_CHECK(hipEventRecord(b.sent, h->send));
     SF_HIP_CHECK(hipEventRecord(b.received, h->send));
     b.pending = true;
@@ -565,9 +614,39 @@ int sf_halo_start(sf_halo* h, int key, int depth, void* compute_stream) {
   }
   for (int d = 0; d < 2; ++d)
     if (b.peer[d]) sf::halo_flag_wait(*h, h->recv, h->own.dev + 16 * key + 2 + d, n);
+  if (prof_end) SF_HIP_CHECK(hipEventRecord(prof_end, h->recv));
   SF_HIP_CHECK(hipEventRecord(b.sent, h->send));
   SF_HIP_CHECK(hipEventRecord(b.received, h->recv));
   b.pending = true;
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_halo_set_profile(sf_halo* h, int on) {
+  SF_API_BEGIN
+  if (!h) throw Error(SF_ERR_INVALID, "sf_halo_set_profile: null transport");
+  h->profile = on != 0;
+  h->prof_used = 0;
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_halo_exchange_times(sf_halo* h, int* count, double* mean_ms, double* max_ms) {
+  SF_API_BEGIN
+  if (!h || !count || !mean_ms || !max_ms) throw Error(SF_ERR_INVALID, "sf_halo_exchange_times: null argument");
+  SF_HIP_CHECK(hipSetDevice(h->device));
+  if (h->send) SF_HIP_CHECK(hipStreamSynchronize(h->send));
+  if (h->recv) SF_HIP_CHECK(hipStreamSynchronize(h->recv));
+  double sum = 0, worst = 0;
+  for (size_t i = 0; i < h->prof_used; ++i) {
+    float ms = 0;
+    SF_HIP_CHECK(hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second));
+    sum += ms;
+    worst = std::max(worst, (double)ms);
+  }
+  *count = (int)h->prof_used;
+  *mean_ms = h->prof_used ? sum / (double)h->prof_used : 0.0;
+  *max_ms = worst;
   return SF_OK;
   SF_API_END
 }
@@ -592,32 +671,42 @@ int sf_halo_check(sf_halo* h) {
     if (h->failed) throw Error(SF_ERR_DEVICE, "sf_halo: the RCCL transport has failed earlier (communicator ended)");
     sf::Rccl& nc = sf::rccl();
     // Bounded on the host: ncclSend / ncclRecv have no time limit of their own, so a neighbour that
-    // died or missed an exchange would hold every later synchronisation.  Every exchange started so far must have
-    // arrived within the transport's time limit; if not -- or if RCCL reports an asynchronous error -- the
-    // communicator is ended (ncclCommAbort: its kernels leave the streams) and the transport stays failed.
+    // died or missed an exchange would hold every later synchronisation.  The limit bounds the time WITHOUT PROGRESS
+    // (ADVICE r04): an exchange sits behind everything queued on the compute stream -- this rank's launches, and through
+    // its neighbour's sends the neighbour's -- so a healthy run with more queued work than the limit must not lose its
+    // communicator.  The transport's stream ticks a word in pinned host memory twice per exchange (when the launches it
+    // waits for are done, when it has arrived); the clock starts again whenever that word or an event moves.  If
+    // nothing moves for the limit -- or RCCL reports an asynchronous error -- the communicator is ended (ncclCommAbort:
+    // its kernels leave the streams) and the transport stays failed.
     SF_HIP_CHECK(hipSetDevice(h->device));
-    const auto t0 = std::chrono::steady_clock::now();
+    auto last_progress = std::chrono::steady_clock::now();
+    unsigned seen = h->progress_host ? __atomic_load_n(h->progress_host, __ATOMIC_ACQUIRE) : 0u;
+    auto fail = [&](const std::string& what) {
+      sf::halo_abort_comm(*h);
+      throw Error(SF_ERR_DEVICE, what);
+    };
     for (auto& kv : h->bufs) {
       sf::HaloBuffer& b = kv.second;
       if (b.count == 0 || !b.received) continue;
       for (;;) {
         sf::Rccl::result_t async = 0;
-        if (nc.CommGetAsyncError && nc.CommGetAsyncError(h->comm, &async) == 0 && async != 0) {
-          sf::halo_abort_comm(*h);
-          throw Error(SF_ERR_DEVICE, std::string("sf_halo: RCCL reports ") + nc.GetErrorString(async));
-        }
+        if (nc.CommGetAsyncError && nc.CommGetAsyncError(h->comm, &async) == 0 && async != 0)
+          fail(std::string("sf_halo: RCCL reports ") + nc.GetErrorString(async));
         const hipError_t q = hipEventQuery(b.received);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) {
-          sf::halo_abort_comm(*h);
-          throw Error(SF_ERR_DEVICE, std::string("sf_halo: ") + hipGetErrorString(q));
+        if (q == hipSuccess) {
+          last_progress = std::chrono::steady_clock::now();
+          break;
         }
-        const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
-        if (waited > (long long)h->timeout_ms) {
-          sf::halo_abort_comm(*h);
-          throw Error(SF_ERR_DEVICE, "sf_halo: rank " + std::to_string(h->rank) + ": an RCCL halo exchange did not complete within " +
-                                         std::to_string(h->timeout_ms) + " ms (communicator ended)");
+        if (q != hipErrorNotReady) fail(std::string("sf_halo: ") + hipGetErrorString(q));
+        const unsigned now_at = h->progress_host ? __atomic_load_n(h->progress_host, __ATOMIC_ACQUIRE) : seen;
+        if (now_at != seen) {
+          seen = now_at;
+          last_progress = std::chrono::steady_clock::now();
         }
+        const auto idle = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - last_progress).count();
+        if (idle > (long long)h->timeout_ms)
+          fail("sf_halo: rank " + std::to_string(h->rank) + ": the RCCL halo exchanges made no progress for " + std::to_string(h->timeout_ms) +
+               " ms (communicator ended)");
         std::this_thread::sleep_for(std::chrono::microseconds(200));
       }
     }

@@ -348,7 +348,7 @@ __device__ __forceinline__ void sf_step_stream(sf_t* lds, sf_t* __restrict__ out
   const sf_t* tb[SF_LAG + 1];  // the thread's patch of planes p, p - 1, .. p - LAG
 #pragma unroll
   for (int l = 0; l <= SF_LAG; ++l) tb[l] = lds + ((slot + SF_IN_SLOTS - l) % SF_IN_SLOTS) * SF_SLOT_STRIDE + cx.tb;
-  sf_dense::template accumulate<PH>(tb, acc);
+  sf_dense::template accumulate<PH>(tb, sc, acc);
   sf_pin(acc);
   sf_t rows[SF_RJ][SF_VK];
   sf_dense::finish(sc, acc[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);

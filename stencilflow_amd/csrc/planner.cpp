@@ -462,9 +462,8 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
   static const Shape streams3d_sparse[] = {{64, 4, 2}, {64, 2, 4}, {128, 4, 2}, {64, 4, 4}, {64, 4, 1}};
   DenseSum sum_form;
   if (dense_sum_form(P, P.kernels[kidx], &sum_form)) {
-    const Kernel& K = P.kernels[kidx];
     const bool wide_acc = dt == DT::F32 && radius == 3 &&
-                          (K.acc[sum_form.terms[0]].vtype == DT::F64 || K.acc[sum_form.terms[1]].vtype == DT::F64);
+                          (sum_form.ttype[0] == DT::F64 || sum_form.ttype[1] == DT::F64);
     if (pin_bx && (noj || (pin_by && pin_rj))) variants.push_back({todo[0], false, true});
     else if (noj) for (const Shape& sh : shapes2d) variants.push_back({sh, false, true});
     else if (wide_acc) for (const Shape& sh : streams3d_wide_acc) variants.push_back({sh, false, true});

@@ -628,6 +628,18 @@ class PeerExchanger:
     def check(self):
         self._check(self._lib.sf_halo_check(self._h))
 
+    def set_profile(self, on=True):
+        """Timing events around every exchange from now on (``sf_halo_set_profile``; resets the record)."""
+        self._check(self._lib.sf_halo_set_profile(self._h, 1 if on else 0))
+
+    def exchange_times(self):
+        """(count, mean ms, longest ms) of the exchanges since ``set_profile(True)``: from the moment the launches an
+        exchange waits for are done to the moment its planes have arrived (``sf_halo_exchange_times``)."""
+        ct = self._ct
+        n, mean, worst = ct.c_int(), ct.c_double(), ct.c_double()
+        self._check(self._lib.sf_halo_exchange_times(self._h, ct.byref(n), ct.byref(mean), ct.byref(worst)))
+        return n.value, mean.value, worst.value
+
     def wait_bounded(self):
         """RCCL rung: every exchange started so far has arrived, or the transport's time limit has passed and
         the communicator is ended (``sf_halo_check`` polls the exchanges' events on the host; ncclSend / ncclRecv

@@ -145,7 +145,7 @@ def test_traffic_records_belong_to_the_code_objects_the_bench_compiles():
     from stencilflow_amd.backend import Plan
     with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
         table = json.load(f)
-    for name, stages in (("c3", 1000), ("c2", 1000), ("c5", 300), ("box", 16), ("wide", 16), ("dense", 4), ("fork", 16)):
+    for name, stages in (("c3", 1000), ("c2", 1000), ("c5", 300), ("box", 16), ("wide", 16), ("cross3", 8), ("dense", 4), ("fork", 16)):
         wl = bench.make_workload(name, 0, stages)
         _, sfir = bench.lower_program(wl["prog"])
         with Plan(sfir) as plan:

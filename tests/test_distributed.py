@@ -531,8 +531,8 @@ def test_library_rccl_rung_sends_to_itself():
 
 
 def _rccl_bound_worker(rank, world, port):
-    """An RCCL exchange that cannot start within the transport's time limit (its stream is held by a flag
-    wait this test stages): the bounded wait must raise instead of waiting on."""
+    """An RCCL exchange that makes no progress within the transport's time limit (its stream is held by a flag
+    wait this test stages, nothing else is queued): the bounded wait must raise instead of waiting on."""
     import ctypes
     import time
     import torch
@@ -555,7 +555,7 @@ def _rccl_bound_worker(rank, world, port):
     assert lib.sf_flag_wait(raw_stream, fp, 1, 5000, sp) == 0  # holds the stream for 5 s
     assert lib.sf_halo_start(ex._h, 0, 4, raw_stream) == 0      # ... and with it the exchange
     t0 = time.perf_counter()
-    with pytest.raises(RuntimeError, match="did not complete within 1500 ms"):
+    with pytest.raises(RuntimeError, match="made no progress for 1500 ms"):
         ex.wait_bounded()
     waited = time.perf_counter() - t0
     assert 1.4 <= waited < 4.0, waited
@@ -566,6 +566,48 @@ def _rccl_bound_worker(rank, world, port):
     ex.close()  # a failed transport is not waited for
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _rccl_busy_worker(rank, world, port):
+    """healthy exchanges behind MORE queued compute than the transport's time limit -- 60 exchanges, each
+    behind ~20 ms of kernels on the compute stream, against a limit of 300 ms -- must not cost the communicator: the
+    limit bounds the time without progress, and the transport's progress word moves with every exchange."""
+    import ctypes
+    import time
+    import torch
+    sys.path.insert(0, ROOT)
+    from stencilflow_amd.distributed import PeerExchanger
+    dist = _init(rank, world, port)
+    torch.cuda.set_device(0)
+    ex = PeerExchanger(1, 3, "rq{}".format(port), device=0, timeout_ms=300, transport="rccl", self_loop=True)
+    lib = ex._lib
+    n_local, halo, plane = 12, 4, 1 << 16
+    raw = torch.zeros((n_local + 2 * halo) * plane, dtype=torch.uint8, device="cuda")
+    blob = ctypes.create_string_buffer(ex._blob_bytes)
+    assert lib.sf_halo_export(ex._h, 0, ctypes.c_void_p(raw.data_ptr()), plane, n_local, halo, blob) == 0
+    assert lib.sf_halo_connect(ex._h, 0, None, None) == 0
+    stream = torch.cuda.Stream()
+    raw_stream = ctypes.c_void_p(stream.cuda_stream)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(60):
+            torch.cuda._sleep(40_000_000)  # ~20 ms of a spinning kernel
+            assert lib.sf_halo_start(ex._h, 0, 4, raw_stream) == 0
+            assert lib.sf_halo_finish(ex._h, 0, raw_stream) == 0
+    queued = time.perf_counter() - t0
+    ex.wait_bounded()  # (raises if the communicator was ended)
+    total = time.perf_counter() - t0
+    stream.synchronize()
+    assert total > 0.6 and total > queued, (queued, total)  # the queue really outlasted the 300-ms limit
+    ex.check()
+    ex.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_rung_does_not_end_a_healthy_communicator_behind_long_compute():
+    _spawn(_rccl_busy_worker, 1)
 
 
 @pytest.mark.gpu

@@ -1113,3 +1113,150 @@ def test_command_line_with_a_named_reference_checker(programs_dir, tmp_path):
     assert out.size == 12 * 16 * 32 and np.array_equal(out, ref)
     bad = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, env=env)
     assert bad.returncode != 0 and "RuntimeError" in bad.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 5: the streaming dense forms take their planes by LDS-DMA, and a plain sum streams in ANY order of its terms
+# (codegen.hpp: stream_schedule) -- the generator's crosses and `diffusion` shapes of extent 3 left the generic kernel.
+def _synth_case(tmp_path, dtype, dims, extent, shape, bc, stages=2, seed=41):
+    full = list(dims) + [0] * (3 - len(dims))
+    ext = [extent if d else 0 for d in full]
+    prog, _ = programs.synthesize(dtype, stages, 0.0, *full, *ext, stencil_shape=shape)
+    for k in prog["program"].values():
+        for f in k["boundary_conditions"]:
+            k["boundary_conditions"][f] = dict(bc)
+    x = np.random.default_rng(SEED + seed).uniform(-1, 1, dims).astype(dtype)
+    return prog, x, sf.KernelChainGraph(_write(tmp_path, prog))
+
+
+def _plan_inputs(plan, prog, x):
+    """inputs in the plan's order: the field `a`, the scalars the generator's `diffusion` / `hotspot` shapes declare"""
+    if plan.scalar_names:
+        plan.set_scalars([float(str(prog["inputs"][n]["data"]).split(":")[-1]) for n in plan.scalar_names])
+    return [x for _ in plan.input_names]
+
+
+@pytest.mark.parametrize("dims,dtype,shape,bc", [
+    ((14, 19, 40), "float32", "cross", {"type": "constant", "value": 0}),
+    ((9, 26, 72), "float32", "cross", {"type": "constant", "value": 0.5}),     # float literal: double-typed sum
+    ((11, 13, 24), "float64", "cross", {"type": "constant", "value": -1}),
+    ((16, 21, 136), "float32", "cross", {"type": "shrink"}),
+    ((90, 136), "float32", "cross", {"type": "constant", "value": 2}),
+    ((70, 72), "float64", "cross", {"type": "constant", "value": 0.25}),
+    ((12, 17, 40), "float32", "diffusion", {"type": "constant", "value": 0}),  # centre first, then the crosses' order
+    ((10, 15, 24), "float64", "diffusion", {"type": "constant", "value": 0.5}),
+    ((80, 264), "float32", "diffusion", {"type": "constant", "value": 0}),
+])
+def test_generator_crosses_of_extent_three_stream_through_the_dense_kernel(tmp_path, dims, dtype, shape, bc):
+    """Radius-3 stars ran on the generic kernel until round 4: their text lists the planes out of order (i-3 .. i+3,
+    then the 12 in-plane terms).  The streaming form now adds a term to its output plane at the step by which its plane
+    AND every earlier term have arrived -- the in-plane terms three steps after their plane, which the LDS ring keeps
+    (SF_LAG 3) -- in the order of the text: bit for bit the oracle's results, whatever the sum's type, in 3-D and 2-D."""
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    prog, x, chain = _synth_case(tmp_path, dtype, dims, 3, shape, bc)
+    got = np.zeros(dims, dtype)
+    with Plan(lower(chain)) as plan:
+        assert "[dense" in plan.describe() and "[point]" not in plan.describe(), plan.describe()
+        src = plan.kernel_source(0)
+        assert "#define SF_DENSE_STREAM 1" in src and "#define SF_LAG 3" in src and "offen lds" in src
+        plan.run(_plan_inputs(plan, prog, x), [got], 1)
+    want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
+    if bc["type"] == "shrink":
+        inner = tuple(slice(6, -6) for _ in dims)
+        assert np.array_equal(got[inner], want[inner])
+    else:
+        assert np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("dims,extent,bc", [
+    ((13, 11, 520), 2, {"type": "constant", "value": 0.5}),   # one row of tiles, rows cut into three k-tiles
+    ((7, 70, 260), 2, {"type": "constant", "value": -2}),     # partial row tiles, a k-tile of four columns
+    ((6, 9, 8), 2, {"type": "constant", "value": 1}),         # the whole grid inside one tile's halo
+    ((21, 40, 1028), 1, {"type": "constant", "value": 0.5}),  # 27-point boxes, two per launch, rows cut into k-tiles
+    ((9, 37, 512), 1, {"type": "constant", "value": -1}),     # ... whole rows: one input slot, requested in mid-step
+    ((300, 520), 2, {"type": "constant", "value": 3}),        # 2-D: 25 points
+    ((64, 1032), 1, {"type": "constant", "value": 0.5}),      # 2-D: 9 points, two per launch
+])
+def test_nonzero_boundary_constants_under_lds_dma(tmp_path, dims, extent, bc):
+    """A plane requested by LDS-DMA arrives with ZEROS where it reaches beyond the domain (out-of-range lanes of
+    `buffer_load ... lds` write zero, tools/micro/lds_dma_probe.hip); a boundary constant other than zero is written over
+    them by the tiles that touch the edge, and over whole planes outside the global domain, before anything reads the
+    slot (dense3d.h: sf_fix_boundary).  Partial tiles, k-tiles, grids smaller than a halo: all results bit for bit."""
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    prog, x, chain = _synth_case(tmp_path, "float32", dims, extent, "box", bc, stages=2 if extent == 2 else 4, seed=42)
+    got = np.zeros(dims, np.float32)
+    with Plan(lower(chain), options={"dense.t2": 2}) as plan:
+        assert "[dense" in plan.describe(), plan.describe()
+        assert "offen lds" in plan.kernel_source(0)
+        plan.run([x], [got], 1)
+    want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("shape,extent,world", [("cross", 3, 2), ("cross", 3, 3), ("box", 3, 2), ("box", 2, 3)])
+def test_streaming_dense_launches_under_slab_decomposition(tmp_path, shape, extent, world):
+    """The streaming dense forms on in-process slabs: a launch reaches `extent` planes across a slab boundary, the
+    planes requested by LDS-DMA include ghost planes, and planes outside the GLOBAL domain (not the slab) are the ones
+    that hold the boundary constant."""
+    from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
+    from stencilflow_amd.lowering import lower
+    dims = (36, 14, 40)
+    prog, x, chain = _synth_case(tmp_path, "float32", dims, extent, shape, {"type": "constant", "value": 0.5}, stages=3, seed=43)
+    sfir = lower(chain)
+    exch = LocalExchanger(world)
+    runners = [SlabRunner(sfir, dims, r, world, exchanger=exch.for_rank(r), groups_per_exchange=1) for r in range(world)]
+    assert all("[dense" in r.plan.describe() for r in runners), runners[0].plan.describe()
+    for r in runners:
+        r.upload([x[r.lo:r.hi]])
+    run_lockstep(runners)
+    got = np.zeros(dims, np.float32)
+    for r in runners:
+        part = np.zeros(r.local_shape, np.float32)
+        r.download([part])
+        got[r.lo:r.hi] = part
+        r.close()
+    want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("pins,slots", [({"k1.bx": 128, "k1.by": 6, "k1.rj": 3}, 1), ({"k1.bx": 128, "k1.by": 4, "k1.rj": 4}, 2),
+                                         ({"k1.bx": 64, "k1.by": 8, "k1.rj": 2}, 2)])
+def test_fused_dense_form_with_one_and_two_input_slots(tmp_path, pins, slots):
+    """Two 27-point sums per launch: the input planes are requested a whole step ahead into a ring of two slots where
+    160 KB of LDS allow it, and in mid-step -- behind a second barrier, when every wave has read the one slot -- where
+    they do not (18-row tiles of 512 columns: what the planner picks at 512^3).  Same results either way."""
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    dims = (19, 45, 512)
+    prog, x, chain = _synth_case(tmp_path, "float32", dims, 1, "box", {"type": "constant", "value": 0}, stages=4, seed=44)
+    got = np.zeros(dims, np.float32)
+    with Plan(lower(chain), options=dict(pins, **{"dense.t2": 2})) as plan:
+        src = plan.kernel_source(0)
+        assert "sf_dense3d_f32_t2_" in plan.describe() and "#define SF_IN_SLOTS %d\n" % slots in src, plan.describe()
+        plan.run([x], [got], 1)
+    want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
+    assert np.array_equal(got, want)
+
+
+def test_full_size_radius_three_cross_bit_exact():
+    """The generator's radius-3 cross at the benchmark's 512^3 (bench.py's `cross3` workload): all 134 million results
+    of a two-operator chain against the C oracle -- the tile, chunk and ring shapes the planner picks at full size."""
+    import tempfile
+    from oracle import c_oracle
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    n = 512
+    prog, _ = programs.synthesize("float32", 2, 0.0, n, n, n, 3, 3, 3)
+    x = np.random.default_rng(SEED + 45).uniform(-1, 1, (n, n, n)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        chain = sf.KernelChainGraph(programs.write_program(prog, os.path.join(tmp, "w.json")))
+    got = np.zeros((n, n, n), np.float32)
+    with Plan(lower(chain)) as plan:
+        assert "[dense" in plan.describe() and "block 64x4 rows/thread 2" in plan.describe(), plan.describe()
+        plan.run([x], [got], 1)
+    ref = c_oracle.CompiledReference(prog)
+    ref.threads = _oracle_threads()
+    want = ref.run({"a": x})[prog["outputs"][0]]
+    assert np.array_equal(got, want), npo.max_rel_err(want, got)

@@ -3,7 +3,7 @@
 # bench command, and a summary of the line.   usage: bash tools/gpu_suite.sh <tag>   (files under gpurun_out/<tag>_*)
 set -o pipefail
 tag=${1:-r05}
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu --durations=25 > gpurun_out/${tag}_pytest_gpu.log 2>&1; rc=$?
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu --durations=60 > gpurun_out/${tag}_pytest_gpu.log 2>&1; rc=$?
 echo "pytest rc=$rc"; tail -6 gpurun_out/${tag}_pytest_gpu.log
 [ $rc -eq 0 ] || exit 1
 SF_HIP_NO_TORCH=1 timeout -k 10 200 python tools/no_torch_bench.py > gpurun_out/${tag}_no_torch.log 2>&1; echo "no-torch rc=$?"

@@ -102,7 +102,7 @@ def main():
                 result = json.load(f)
         except (OSError, ValueError):
             result = {}
-    for wl in ("c3", "c2", "c5", "box", "wide", "dense", "fork", "generic"):
+    for wl in ("c3", "c2", "c5", "box", "wide", "cross3", "dense", "fork", "generic"):
         root = "gpurun_out/prof_%s_%s" % (tag, wl)
         if not os.path.isdir(root):
             continue

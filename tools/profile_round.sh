@@ -24,13 +24,14 @@ fi
 # kernel); wide = its radius-2 cross chain (wide-star kernel); generic = c3 forced onto the
 # generic operator kernel (16 / 40 operators); dense = the generator's 125-point box (dense kernel); fork = its
 # fork / join program (several kernels: one record each)
-for wl in ${SF_PROFILE_WORKLOADS:-c3 c2 c5 box wide dense fork generic}; do
+for wl in ${SF_PROFILE_WORKLOADS:-c3 c2 c5 box wide cross3 dense fork generic}; do
   [ "$wl" = none ] && continue
   out=gpurun_out/prof_${tag}_$wl
   rm -rf $out; mkdir -p $out
   case $wl in
     box) base="--workload box --stages 16"; short="--workload box --stages 16";;
     wide) base="--workload wide --stages 16"; short="--workload wide --stages 16";;
+    cross3) base="--workload cross3 --stages 8 --steps 10"; short="--workload cross3 --stages 8";;
     dense) base="--workload dense --stages 4 --steps 10"; short="--workload dense --stages 4";;
     fork) base="--workload fork --stages 16 --steps 10"; short="--workload fork --stages 16";;
     generic) base="--workload c3 --stages 40 --options generic_only=1"; short="--workload c3 --stages 40 --options generic_only=1";;
