@@ -911,11 +911,14 @@ def main():
             others = []
             # (>= 10 timed steps each and the median beside the mean: SURVEY.md 8d; the whole set costs about
             # 1.5 s of GPU time)
-            for name, stages, steps in (("c2", 1000, 10), ("c5", 300, 10), ("box", 16, 12), ("wide", 16, 12),
-                                        ("cross3", 8, 12), ("dense", 4, 12), ("fork", 16, 12)):
+            # (the generator's chains are 4-28 launches long: 30 timed steps behind 5 untimed ones, so that the mean is the
+            #  rate a long chain sees -- the clock the chip holds under a vector-bound launch settles over some tens of
+            #  launches, profiles/r05_dense_whatif.log -- and not the rate of the first launches after a pause)
+            for name, stages, steps, warm in (("c2", 1000, 10, 1), ("c5", 300, 10, 1), ("box", 16, 30, 5), ("wide", 16, 30, 5),
+                                              ("cross3", 8, 30, 5), ("dense", 4, 30, 5), ("fork", 16, 30, 5)):
                 try:
                     owl = make_workload(name, 0, stages)
-                    t = time_single(owl, {}, steps, 1, device=local_rank)
+                    t = time_single(owl, {}, steps, warm, device=local_rank)
                 except Exception as exc:  # noqa: BLE001 -- a side line must not cost the headline
                     others.append({"workload": name, "error": "{}: {}".format(type(exc).__name__, str(exc)[:200])})
                     continue

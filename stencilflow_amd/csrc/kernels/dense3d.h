@@ -33,8 +33,8 @@
 //     is cut into tiles, four columns -- on either side are recomputed by the neighbouring tile); no register windows
 //     and no lane exchange, so the f32 adds of co-resident waves overlap.
 // Round 5: the streaming forms take their planes by LDS-DMA (`buffer_load_dwordx4 ... lds`: memory -> LDS, no staging
-// registers, no ds_write).  The input planes go through a ring of SF_IN_SLOTS slots, requested SF_IN_SLOTS - 1 planes
-// ahead (one slot: requested in mid-step, fused form only).  One wave-instruction writes 64 x 16 bytes of LDS in a row
+// registers, no ds_write).  The input planes go through a ring of SF_IN_SLOTS slots: SF_LAG planes kept behind the
+// one that has just arrived (terms that join their output plane late), the rest requested ahead.  One wave-instruction writes 64 x 16 bytes of LDS in a row
 // (M0 + 16 x lane) while the SOURCE address is per lane: a slot is filled in image order, chunk c of the slot by lane
 // c mod 64 of piece c / 64, and a lane whose chunk lies outside the (j,k) domain -- or every lane, for a plane outside
 // the global domain: a resource of zero records -- reads out of range, which WRITES ZERO and touches no memory
@@ -72,7 +72,10 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #endif
 #if SF_DENSE_STREAM
 #define SF_MID0 SF_IN_SLOTS  // first slot of the ring between the two operators
-#define SF_SLOTS (SF_DENSE_T2 ? SF_IN_SLOTS + 2 : SF_IN_SLOTS)
+#ifndef SF_MID_SLOTS
+#define SF_MID_SLOTS 2
+#endif
+#define SF_SLOTS (SF_DENSE_T2 ? SF_IN_SLOTS + SF_MID_SLOTS : SF_IN_SLOTS)
 #ifndef SF_ACCS
 #define SF_ACCS (2 * SF_R + 1)  // accumulator sets: output planes p - R .. p + R are open while plane p is read
 #endif
@@ -113,7 +116,7 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #ifndef SF_LAG
 #define SF_LAG 0  // planes the ring keeps behind the one that has just arrived (terms that join their output plane late)
 #endif
-#define SF_AHEAD (SF_IN_SLOTS - SF_LAG > 1 ? SF_IN_SLOTS - SF_LAG - 1 : 1)  // planes requested ahead of the one being read
+#define SF_AHEAD (SF_IN_SLOTS - SF_LAG - 1)  // planes requested ahead of the one being read (>= 1)
 #else
 #define SF_SLOT_STRIDE SF_SLOT_ELEMS
 #define SF_PAIRS_PER_ROW (SF_LS / 2)
@@ -361,31 +364,41 @@ __device__ __forceinline__ void sf_step_stream(sf_t* lds, sf_t* __restrict__ out
 // reads input plane p from slot `slot` of the input ring and finishes its plane q1 = p - SFD_DLAST, which goes to the
 // ring between the operators (slot parity of q1); operator 2 reads the plane that went there in the PREVIOUS step
 // (q1 - 1: this step's barrier has made it visible) and finishes output plane q1 - 1 - SFD2_DLAST.
-// Input ring of one slot (SF_IN_SLOTS 1): the next plane is requested in mid-step, behind a second barrier -- when
-// every wave has read the slot -- and lands while the second operator runs.
+// The input planes go through a ring of two slots (requested one step ahead); the ring between the operators has two
+// slots where 160 KB of LDS allow four, and ONE (SF_MID_SLOTS 1) where they allow three -- 18-row tiles of 512 columns.
 template <int PH>
 __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, const sf_scalars& sc, const sf_ctx& cx,
                                            const int p, const int p_begin, const int p_end, const int slot, const int s0,
                                            sf_dense::acc_t (&acc1)[SF_ACCS][SF_RJ][SF_VK],
                                            sf_dense2::acc_t (&acc2)[SF_ACCS][SF_RJ][SF_VK]) {
-  if constexpr (SF_IN_SLOTS == 1) sf_wait_plane<SF_RJ>(p == p_begin);
-  else sf_wait_plane<(SF_AHEAD - 1) * SF_NDMIN + SF_AHEAD * SF_RJ>(p - p_begin < SF_AHEAD);
+  sf_wait_plane<(SF_AHEAD - 1) * SF_NDMIN + SF_AHEAD * SF_RJ>(p - p_begin < SF_AHEAD);
   sf_t* in_slot = lds + slot * SF_SLOT_STRIDE;
   sf_fix_boundary<sf_dense>(cx, p, p < p_end, in_slot);
-  if constexpr (SF_IN_SLOTS > 1) sf_dma_plane(cx, p + SF_AHEAD, p + SF_AHEAD < p_end, (slot + SF_AHEAD) % SF_IN_SLOTS);
+  sf_dma_plane(cx, p + SF_AHEAD, p + SF_AHEAD < p_end, (slot + SF_AHEAD) % SF_IN_SLOTS);
+  const int q1 = p - SFD_DLAST;
+  constexpr int PH2 = (PH - SFD_DLAST - 1 + 2 * SF_ACCS) % SF_ACCS;
+  // where operator 1's plane q1 goes, and where the plane it published a step ago is read
+  const int mid_par = SF_MID_SLOTS == 1 ? 0 : (s0 + 2 - SFD_DLAST) & 1;
+  sf_t* mid_w = lds + (SF_MID0 + mid_par) * SF_SLOT_STRIDE + cx.tb + SF_RJH * SF_LS + SF_RC;
+  const sf_t* mid_r = lds + (SF_MID0 + (SF_MID_SLOTS == 1 ? 0 : (mid_par ^ 1))) * SF_SLOT_STRIDE + cx.tb;
+  auto second = [&]() {
+    // ---- operator 2 on the plane published a step ago
+    sf_dense2::template accumulate<PH2>(mid_r, acc2);
+    sf_pin(acc2);
+    sf_t rows[SF_RJ][SF_VK];
+    sf_dense2::finish(sc, acc2[(PH2 - SFD2_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
+    sf_store_rows(rows, out, cx, q1 - 1 - SFD2_DLAST);
+  };
+  // (one slot between the operators: operator 2 reads it FIRST -- what the previous step published --, operator 1's
+  //  plane goes there at the very end of the step, behind a second barrier that sits right before the next step's)
+  if constexpr (SF_MID_SLOTS == 1) second();
   // ---- operator 1: plane p joins the open planes, plane q1 is finished and published
   sf_dense::template accumulate<PH>(in_slot + cx.tb, acc1);
   sf_pin(acc1);
-  if constexpr (SF_IN_SLOTS == 1) {
-    asm volatile("s_barrier" ::: "memory");  // every wave has read the slot
-    sf_dma_plane(cx, p + 1, p + 1 < p_end, 0);
-  }
-  const int q1 = p - SFD_DLAST;
   const bool plane1_in = (q1 + cx.goff >= 0) && (q1 + cx.goff < SF_N0G);
   sf_t mid[SF_RJ][SF_VK];
   sf_dense::finish(sc, acc1[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], mid);
-  const int mid_par = (s0 + 2 - SFD_DLAST) & 1;
-  sf_t* mid_w = lds + (SF_MID0 + mid_par) * SF_SLOT_STRIDE + cx.tb + SF_RJH * SF_LS + SF_RC;
+  if constexpr (SF_MID_SLOTS == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read the slot
 #pragma unroll
   for (int r = 0; r < SF_RJ; ++r) {
     // outside the global domain operator 2 reads ITS boundary constant
@@ -395,14 +408,7 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
     for (int v = 0; v < SF_VK; ++v) w[v] = (row_in && ((cx.kmask >> v) & 1u)) ? mid[r][v] : sf_dense2::bc();
     *reinterpret_cast<sf_vec*>(&mid_w[r * SF_LS]) = w;  // (the thread's own columns: 16-byte aligned)
   }
-  // ---- operator 2 on the plane published a step ago
-  constexpr int PH2 = (PH - SFD_DLAST - 1 + 2 * SF_ACCS) % SF_ACCS;
-  const sf_t* mid_r = lds + (SF_MID0 + (mid_par ^ 1)) * SF_SLOT_STRIDE + cx.tb;
-  sf_dense2::template accumulate<PH2>(mid_r, acc2);
-  sf_pin(acc2);
-  sf_t rows[SF_RJ][SF_VK];
-  sf_dense2::finish(sc, acc2[(PH2 - SFD2_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
-  sf_store_rows(rows, out, cx, q1 - 1 - SFD2_DLAST);
+  if constexpr (SF_MID_SLOTS != 1) second();
 }
 #endif
 
@@ -501,7 +507,7 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   // the ring between the operators starts out as the second operator's boundary constant: its halo rows and columns
   // are never written again (they are right where the tile touches the edge of the domain; elsewhere the results
   // that read them are not stored)
-  for (int i = tid; i < 2 * SF_SLOT_STRIDE; i += SF_THREADS) lds[SF_MID0 * SF_SLOT_STRIDE + i] = sf_dense2::bc();
+  for (int i = tid; i < SF_MID_SLOTS * SF_SLOT_STRIDE; i += SF_THREADS) lds[SF_MID0 * SF_SLOT_STRIDE + i] = sf_dense2::bc();
   sf_dense::acc_t acc1[SF_ACCS][SF_RJ][SF_VK];
   sf_dense2::acc_t acc2[SF_ACCS][SF_RJ][SF_VK];
 #pragma unroll

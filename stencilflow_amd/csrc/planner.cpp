@@ -603,11 +603,13 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     // the input ring (planes by LDS-DMA, requested `slots - 1` ahead) and the two slots between the operators: as many
     // input slots, up to three, as fit; one = the next plane requested in mid-step, behind a second barrier
     const size_t slot = ((size_t)(tj + (noj ? 0 : 2)) * (size_t)(tk + 2 * (16 / size_of(dt))) * size_of(dt) + 1023) / 1024 * 1024;
-    const long long fit = (long long)(160 * 1024 / slot) - 2;
-    if (fit < 1) continue;
-    // (two input slots against one, 16-row tiles: 286 against 294 us; a third buys nothing)
-    c.dense_in_slots = (int)std::min<long long>(2, fit);
-    const size_t lds = (size_t)(c.dense_in_slots + 2) * slot;
+    // (two input slots -- the plane requested a whole step ahead -- and two between the operators where four slots fit;
+    //  three slots: ONE between the operators, written at the very end of a step behind a second barrier)
+    const long long fit = (long long)(160 * 1024 / slot);
+    if (fit < 3) continue;
+    c.dense_in_slots = 2;
+    c.dense_mid_slots = fit >= 4 ? 2 : 1;
+    const size_t lds = (size_t)(c.dense_in_slots + c.dense_mid_slots) * slot;
     c.lds_bytes = lds;
     const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] * (double)P.n[2] *
                                (double)size_of(dt);

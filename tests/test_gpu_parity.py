@@ -1146,6 +1146,8 @@ def _plan_inputs(plan, prog, x):
     ((12, 17, 40), "float32", "diffusion", {"type": "constant", "value": 0}),  # centre first, then the crosses' order
     ((10, 15, 24), "float64", "diffusion", {"type": "constant", "value": 0.5}),
     ((80, 264), "float32", "diffusion", {"type": "constant", "value": 0}),
+    ((60, 136), "float32", "cross", {"type": "shrink"}),
+    ((8, 12, 24), "float32", "diffusion", {"type": "constant", "value": 0.5}),  # double-typed products and sums
 ])
 def test_generator_crosses_of_extent_three_stream_through_the_dense_kernel(tmp_path, dims, dtype, shape, bc):
     """Radius-3 stars ran on the generic kernel until round 4: their text lists the planes out of order (i-3 .. i+3,
@@ -1174,9 +1176,11 @@ def test_generator_crosses_of_extent_three_stream_through_the_dense_kernel(tmp_p
     ((7, 70, 260), 2, {"type": "constant", "value": -2}),     # partial row tiles, a k-tile of four columns
     ((6, 9, 8), 2, {"type": "constant", "value": 1}),         # the whole grid inside one tile's halo
     ((21, 40, 1028), 1, {"type": "constant", "value": 0.5}),  # 27-point boxes, two per launch, rows cut into k-tiles
-    ((9, 37, 512), 1, {"type": "constant", "value": -1}),     # ... whole rows: one input slot, requested in mid-step
+    ((9, 37, 512), 1, {"type": "constant", "value": -1}),     # ... whole rows of 512 columns
     ((300, 520), 2, {"type": "constant", "value": 3}),        # 2-D: 25 points
     ((64, 1032), 1, {"type": "constant", "value": 0.5}),      # 2-D: 9 points, two per launch
+    ((50, 72), 3, {"type": "constant", "value": -1}),         # 2-D: 49 points, seven open rows
+    ((5, 6, 8), 1, {"type": "constant", "value": 2}),         # 27-point boxes on a grid smaller than a tile
 ])
 def test_nonzero_boundary_constants_under_lds_dma(tmp_path, dims, extent, bc):
     """A plane requested by LDS-DMA arrives with ZEROS where it reaches beyond the domain (out-of-range lanes of
@@ -1185,7 +1189,7 @@ def test_nonzero_boundary_constants_under_lds_dma(tmp_path, dims, extent, bc):
     slot (dense3d.h: sf_fix_boundary).  Partial tiles, k-tiles, grids smaller than a halo: all results bit for bit."""
     from stencilflow_amd.backend import Plan
     from stencilflow_amd.lowering import lower
-    prog, x, chain = _synth_case(tmp_path, "float32", dims, extent, "box", bc, stages=2 if extent == 2 else 4, seed=42)
+    prog, x, chain = _synth_case(tmp_path, "float32", dims, extent, "box", bc, stages=4 if extent == 1 else 2, seed=42)
     got = np.zeros(dims, np.float32)
     with Plan(lower(chain), options={"dense.t2": 2}) as plan:
         assert "[dense" in plan.describe(), plan.describe()
@@ -1221,12 +1225,13 @@ def test_streaming_dense_launches_under_slab_decomposition(tmp_path, shape, exte
     assert np.array_equal(got, want, equal_nan=True)
 
 
-@pytest.mark.parametrize("pins,slots", [({"k1.bx": 128, "k1.by": 6, "k1.rj": 3}, 1), ({"k1.bx": 128, "k1.by": 4, "k1.rj": 4}, 2),
-                                         ({"k1.bx": 64, "k1.by": 8, "k1.rj": 2}, 2)])
-def test_fused_dense_form_with_one_and_two_input_slots(tmp_path, pins, slots):
-    """Two 27-point sums per launch: the input planes are requested a whole step ahead into a ring of two slots where
-    160 KB of LDS allow it, and in mid-step -- behind a second barrier, when every wave has read the one slot -- where
-    they do not (18-row tiles of 512 columns: what the planner picks at 512^3).  Same results either way."""
+@pytest.mark.parametrize("pins,mid_slots", [({"k1.bx": 128, "k1.by": 6, "k1.rj": 3}, 1), ({"k1.bx": 128, "k1.by": 4, "k1.rj": 4}, 2),
+                                             ({"k1.bx": 64, "k1.by": 8, "k1.rj": 2}, 2)])
+def test_fused_dense_form_with_one_and_two_slots_between_the_operators(tmp_path, pins, mid_slots):
+    """Two 27-point sums per launch: the input planes are requested a whole step ahead into a ring of two slots; the ring
+    between the operators has two slots where 160 KB of LDS allow four, and ONE where they allow three (18-row tiles of
+    512 columns: what the planner picks at 512^3) -- operator 2 then reads it first and operator 1's plane goes there at
+    the very end of the step, behind a second barrier.  Same results either way."""
     from stencilflow_amd.backend import Plan
     from stencilflow_amd.lowering import lower
     dims = (19, 45, 512)
@@ -1234,7 +1239,8 @@ def test_fused_dense_form_with_one_and_two_input_slots(tmp_path, pins, slots):
     got = np.zeros(dims, np.float32)
     with Plan(lower(chain), options=dict(pins, **{"dense.t2": 2})) as plan:
         src = plan.kernel_source(0)
-        assert "sf_dense3d_f32_t2_" in plan.describe() and "#define SF_IN_SLOTS %d\n" % slots in src, plan.describe()
+        assert "sf_dense3d_f32_t2_" in plan.describe() and "#define SF_IN_SLOTS 2\n" in src, plan.describe()
+        assert ("#define SF_MID_SLOTS 1\n" in src) == (mid_slots == 1)
         plan.run([x], [got], 1)
     want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
     assert np.array_equal(got, want)

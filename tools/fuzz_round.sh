@@ -10,6 +10,7 @@ for g in $gens; do
 done
 SF_HIP_OPTIONS="dense.t2=2" timeout -k 10 $((secs + 60)) python tools/star_fuzz.py --generator box_sum --seeds 100000 --first $first --seconds $secs > gpurun_out/${tag}_fuzz_box_sum_forced.log 2>&1
 echo "fuzz box_sum (dense.t2=2) rc=$? $(tail -1 gpurun_out/${tag}_fuzz_box_sum_forced.log)"
+[ "$part" = undivided ] && exit 0
 for g in mixed star wide compact dense box_sum dag; do
   opt=""; [ $g = box_sum ] && opt="dense.t2=2"
   SF_HIP_OPTIONS="$opt" timeout -k 10 $((secs + 60)) python tools/slab_fuzz.py --generator $g --seeds 100000 --first $first --seconds $secs > gpurun_out/${tag}_fuzz_slab_$g.log 2>&1
