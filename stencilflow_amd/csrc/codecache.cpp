@@ -8,6 +8,7 @@
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
+#include <link.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -197,6 +198,27 @@ static std::map<std::string, std::vector<char>> g_code_cache;  // name + source 
 // preloads it): same versions reported, different compilers (round 3: C5's five-row tile spills under one of
 // them).  $SF_HIP_COMGR pins it: stencilflow_amd.backend loads that file first, and a process whose comgr is
 // another file is refused at plan creation (check_pinned_compiler) instead of compiling other code silently.
+// Every libamd_comgr resident in the process (`dladdr` of the symbol THIS library resolved names the copy this
+// library bound, which need not be the one libhiprtc bound -- a wheel with renamed sonames or RPATH-local copies can hold
+// two).  More than one: the id says so, and a pinned compiler is refused, because which copy compiles can then not be
+// told from outside.
+static std::vector<std::string> resident_comgrs() {
+  std::vector<std::string> found;
+  ::dl_iterate_phdr(
+      [](struct dl_phdr_info* info, size_t, void* data) {
+        auto* out = static_cast<std::vector<std::string>*>(data);
+        if (info->dlpi_name && std::strstr(info->dlpi_name, "libamd_comgr")) {
+          char real[PATH_MAX];
+          const char* r = ::realpath(info->dlpi_name, real);
+          const std::string path = r ? r : info->dlpi_name;
+          if (std::find(out->begin(), out->end(), path) == out->end()) out->push_back(path);
+        }
+        return 0;
+      },
+      &found);
+  return found;
+}
+
 std::string compiler_id() {
   int major = 0, minor = 0, runtime = 0;
   hiprtcVersion(&major, &minor);
@@ -207,9 +229,16 @@ std::string compiler_id() {
   const char* comgr_path = (::dladdr(reinterpret_cast<void*>(&amd_comgr_get_version), &comgr_lib) && comgr_lib.dli_fname)
                                ? comgr_lib.dli_fname
                                : "?";
+  std::string also;
+  const std::vector<std::string> all = resident_comgrs();
+  if (all.size() > 1) {
+    also = " [" + std::to_string(all.size()) + " copies of libamd_comgr resident:";
+    for (auto& p : all) also += " " + p;
+    also += "]";
+  }
   return "hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " runtime " + std::to_string(runtime) +
          " build " + HIP_VERSION_GITHASH + " comgr " + comgr_path + " (" + std::to_string(cmaj) + "." +
-         std::to_string(cmin) + ")";
+         std::to_string(cmin) + ")" + also;
 }
 
 void check_pinned_compiler() {
@@ -223,6 +252,13 @@ void check_pinned_compiler() {
   const char* ra = ::realpath(want, a);
   const char* rb = ::realpath(have, b);
   if (!ra) throw Error(SF_ERR_INVALID, std::string("SF_HIP_COMGR names '") + want + "', which does not exist");
+  const std::vector<std::string> all = resident_comgrs();
+  if (all.size() > 1) {
+    std::string list;
+    for (auto& p : all) list += " " + p;
+    throw Error(SF_ERR_STATE, std::string("SF_HIP_COMGR pins the device compiler to ") + ra + " but " + std::to_string(all.size()) +
+                                  " copies of libamd_comgr are resident (" + list.substr(1) + "): which one hipRTC compiles through cannot be told");
+  }
   if (!rb || std::strcmp(ra, rb) != 0)
     throw Error(SF_ERR_STATE, std::string("SF_HIP_COMGR pins the device compiler to ") + ra + " but this process compiles through " +
                                   (rb ? rb : have) + ": that library must be loaded before libhiprtc (stencilflow_amd.backend does so; "
@@ -359,13 +395,14 @@ CompiledKernel compile_cached(const std::string& prefix, const std::string& sour
   return k;
 }
 
-void record_verdict(CompiledKernel& k, int verdict) {
+void record_verdict(CompiledKernel& k, int verdict, bool persist) {
   k.verdict = verdict;
   if (k.foreign || k.cache_key.empty()) return;  // (hand-assembled diagnostics objects are never cached)
   {
     std::lock_guard<std::mutex> lock(g_code_cache_mutex);
     g_verdicts[k.cache_key] = verdict;
   }
+  if (!persist) return;  // (this process only)
   const std::string path = disk_cache_path(k.cache_key);
   if (!path.empty()) write_cache_file(path, k.code, verdict);
 }

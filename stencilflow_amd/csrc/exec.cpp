@@ -659,8 +659,20 @@ void self_check(sf_plan& pl) {
           again = self_check_range(pl, st, refs, gens, 0, span);
           again += self_check_range(pl, st, refs, gens, n - span, n);
         }
-        if (again == 0) throw Error(SF_ERR_DEVICE, "self-check: a mismatch of " + pl.kernels[st.ck].name + " did not reproduce (" +
-                                                      std::to_string(bad) + " differing results, then none); nothing recorded");
+        if (again == 0) {
+          //  a mismatch that does not reproduce is the signature of a race inside the fused kernel -- an LDS
+          // ring or a counted wait one short -- at least as much as of a disturbed box: the code object is refused for
+          // the rest of THIS process (verdict kept in memory only: the next process checks it afresh, and a pass can
+          // then be recorded only by a run that sees no mismatch at all), and the plan is poisoned like after a
+          // reproducing mismatch.
+          record_verdict(pl.kernels[st.ck], 2, /*persist=*/false);
+          if (failed.empty())
+            failed = pl.kernels[st.ck].name + " (" + std::to_string(bad) + " results differed from the operators run one by one in the planes [0, " +
+                     std::to_string(std::min(n, span)) + ") and [" + std::to_string(std::max(0, n - span)) + ", " + std::to_string(n) +
+                     ") of seeded data, and none when the comparison was repeated: a race is suspected, nothing written to the disk cache)";
+          ++g_self_checks;
+          continue;
+        }
         bad = again;
       }
       ++g_self_checks;

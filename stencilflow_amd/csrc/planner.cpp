@@ -1207,6 +1207,7 @@ void build_plan(sf_plan& pl) {
 
   // ---- group kernels into launches
   std::map<std::string, StarChoice> star_memo;
+  std::set<int> star_first;  // operators whose longer compact group did not come out: the star path after all
   for (int k = 0; k < K;) {
     Step st;
     StarShape shape;
@@ -1219,10 +1220,16 @@ void build_plan(sf_plan& pl) {
     // A star chain that ends early because the NEXT operator is not a star (the generator's operators with a second
     // spatial field, a box after a cross) while the compact kernel -- whose 27 offsets include every star -- could take
     // both: the longer group wins, it saves a write and a read of the field between them (round 4; the generator's
-    // `num_fields_spatial 0.5` chains: 5 launches -> 4).  compact.prefer=0 restores the star-first order.
-    if (star) {
+    // `num_fields_spatial 0.5` chains: 5 launches -> 4).  The estimate is compile-free; if the compact group then
+    // does not come out -- no clean tile, or cut back to no more operators than the star chain -- the operator is planned
+    // again on the star path instead of dropping to the generic kernel.
+    int demoted_from = 0;
+    if (star && !star_first.count(k)) {
       const int ls = star_chain_len(k);
-      if (ls < fuse && compact_chain_len(k) > ls) star = false;
+      if (ls < fuse && compact_chain_len(k) > ls) {
+        star = false;
+        demoted_from = ls;
+      }
     }
     // radius-2 stars (bin/synthesize.py with an extent of 2): kernels/wstar3d.h, two fused by default
     // (ten planes of register window per thread: deeper groups shrink the tile too far)
@@ -1465,6 +1472,10 @@ void build_plan(sf_plan& pl) {
           st.sig = choice.sig;
         }
       }
+    }
+    if (demoted_from > 0 && !(st.compact && (int)st.kernels.size() > demoted_from)) {
+      star_first.insert(k);
+      continue;  // (the same operator again, star path; everything compiled on the way is cached)
     }
     k += (int)st.kernels.size();
     pl.steps.push_back(st);

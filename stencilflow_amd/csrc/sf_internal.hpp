@@ -160,7 +160,7 @@ void code_cache_stats(long* disk_hits, long* compiled, long* rebuilt, bool drop_
 // a kernel that belongs to no plan's kernel list (the self-check's reference operators): both cache levels
 CompiledKernel compile_cached(const std::string& prefix, const std::string& source, const std::string& flags);
 // store the self-check's verdict with the code object (process and disk level)
-void record_verdict(CompiledKernel& k, int verdict);
+void record_verdict(CompiledKernel& k, int verdict, bool persist = true);
 
 // the device compiler of this process (hipRTC + the comgr it binds); $SF_HIP_COMGR pins the latter
 std::string compiler_id();

@@ -1,14 +1,16 @@
 #!/bin/bash
 # GPU: the fuzz campaigns of a round on every program generator (tests/random_programs.py), undivided and under slab
 # decomposition, the plan-time self-check on; one log per campaign under gpurun_out/<tag>_fuzz_*.log (copy the ones that
-# are to be judged into profiles/).   usage: bash tools/fuzz_round.sh <tag> [seconds per campaign, default 60] [generators]
-tag=${1:-r05}; secs=${2:-60}; gens=${3:-"star wide compact dense dense_sum box_sum dag copy"}
+# are to be judged into profiles/).   usage: bash tools/fuzz_round.sh <tag> [seconds per campaign, default 60] [undivided|slab|all]
+tag=${1:-r05}; secs=${2:-60}; part=${3:-all}
+gens="star wide compact dense dense_sum box_sum dag copy"
+[ "$part" = slab ] && gens=""
 first=$((RANDOM % 5000))
 for g in $gens; do
   timeout -k 10 $((secs + 60)) python tools/star_fuzz.py --generator $g --seeds 100000 --first $first --seconds $secs > gpurun_out/${tag}_fuzz_$g.log 2>&1
   echo "fuzz $g rc=$? $(tail -1 gpurun_out/${tag}_fuzz_$g.log)"
 done
-SF_HIP_OPTIONS="dense.t2=2" timeout -k 10 $((secs + 60)) python tools/star_fuzz.py --generator box_sum --seeds 100000 --first $first --seconds $secs > gpurun_out/${tag}_fuzz_box_sum_forced.log 2>&1
+[ "$part" = slab ] || SF_HIP_OPTIONS="dense.t2=2" timeout -k 10 $((secs + 60)) python tools/star_fuzz.py --generator box_sum --seeds 100000 --first $first --seconds $secs > gpurun_out/${tag}_fuzz_box_sum_forced.log 2>&1
 echo "fuzz box_sum (dense.t2=2) rc=$? $(tail -1 gpurun_out/${tag}_fuzz_box_sum_forced.log)"
 [ "$part" = undivided ] && exit 0
 for g in mixed star wide compact dense box_sum dag; do
