@@ -57,6 +57,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 T_PROCESS_START = time.perf_counter()
+# compiled kernels are kept in the tree (git-ignored; tools/warm_test_cache.sh fills the cache where there is no GPU, and it
+# travels with the snapshot like the built library): a run on a fresh box does not spend its first seconds in hipRTC
+os.environ.setdefault("SF_HIP_CACHE_DIR", os.path.join(ROOT, ".sf_cache"))
 HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
 SEED = 20261003
 BLOCK = 64  # planes per seeded block of the synthetic grid

@@ -29,11 +29,13 @@ for wl in ${SF_PROFILE_WORKLOADS:-c3 c2 c5 box wide cross3 dense fork generic}; 
   out=gpurun_out/prof_${tag}_$wl
   rm -rf $out; mkdir -p $out
   case $wl in
-    box) base="--workload box --stages 16"; short="--workload box --stages 16";;
-    wide) base="--workload wide --stages 16"; short="--workload wide --stages 16";;
-    cross3) base="--workload cross3 --stages 8 --steps 10"; short="--workload cross3 --stages 8";;
-    dense) base="--workload dense --stages 4 --steps 10"; short="--workload dense --stages 4";;
-    fork) base="--workload fork --stages 16 --steps 10"; short="--workload fork --stages 16";;
+    # (the generator's workloads: 30 timed steps behind 5 untimed ones, as in bench.py's `other_configs` -- the mean of a run of
+    #  a few dozen launches after a pause is dominated by the clock settling, NOTES.md round 5)
+    box) base="--workload box --stages 16 --steps 30 --warmup 5"; short="--workload box --stages 16";;
+    wide) base="--workload wide --stages 16 --steps 30 --warmup 5"; short="--workload wide --stages 16";;
+    cross3) base="--workload cross3 --stages 8 --steps 30 --warmup 5"; short="--workload cross3 --stages 8";;
+    dense) base="--workload dense --stages 4 --steps 30 --warmup 5"; short="--workload dense --stages 4";;
+    fork) base="--workload fork --stages 16 --steps 30 --warmup 5"; short="--workload fork --stages 16";;
     generic) base="--workload c3 --stages 40 --options generic_only=1"; short="--workload c3 --stages 40 --options generic_only=1";;
     *) base="--workload $wl"; short="--workload $wl --stages 100";;
   esac

@@ -51,6 +51,16 @@ def main():
         # radius-2 boxes (125 / 25 points): no fused kernel, one generic launch per operator
         ("big box 3-D f32 (radius 2, 125 points)", ("float32", min(st, 4), 0.0, n, n, n, 2, 2, 2), {"stencil_shape": "box"}),
         ("big box 2-D f32 (radius 2, 25 points)", ("float32", min(st, 8), 0.0, 8 * n, 8 * n, 0, 2, 2, 0), {"stencil_shape": "box"}),
+        # extent 3 (round 5: the dense kernel's streaming form in any order of the terms)
+        ("cross 3-D f32 (radius 3)", ("float32", min(st, 8), 0.0, n, n, n, 3, 3, 3), {}),
+        ("diffusion 3-D f32 (radius 3)", ("float32", min(st, 8), 0.0, n, n, n, 3, 3, 3), {"stencil_shape": "diffusion"}),
+        ("cross 3-D f64 (radius 3)", ("float64", min(st, 4), 0.0, n, n, n, 3, 3, 3), {}),
+        ("cross 2-D f32 (radius 3)", ("float32", min(st, 8), 0.0, 8 * n, 8 * n, 0, 3, 3, 0), {}),
+        ("box 3-D f32 (radius 3, 343 points)", ("float32", 2, 0.0, n, n, n, 3, 3, 3), {"stencil_shape": "box"}),
+        ("diffusion 3-D f32 (radius 2)", ("float32", st, 0.0, n, n, n, 2, 2, 2), {"stencil_shape": "diffusion"}),
+        ("box 3-D f64", ("float64", st, 0.0, n, n, n, 1, 1, 1), {"stencil_shape": "box"}),
+        ("hotspot 3-D f64", ("float64", st, 0.0, n, n, n, 1, 1, 1), {"stencil_shape": "hotspot"}),
+        ("box 3-D f32, extra field every 2nd stage", ("float32", st, 0.5, n, n, n, 1, 1, 1), {"stencil_shape": "box"}),
     ]
     # fork / join sections (reference bin/synthesize.py:228-253): two branches of two operators every fourth operator
     forks = [
@@ -92,7 +102,8 @@ def main():
             ops = len(prog["program"])
             cells = float(np.prod(shape)) * ops
             bpu = 8.0 if dtype == np.float32 else 16.0
-            kinds = plan.describe().count("[star") + plan.describe().count("[compact"), plan.describe().count("[point]")
+            d = plan.describe()
+            kinds = d.count("[star") + d.count("[compact") + d.count("[wide") + d.count("[dense"), d.count("[point]")
             print(json.dumps({"case": label, "opts": args.opts, "dims": shape, "operators": ops, "launches": plan.num_launches,
                               "streaming/point launches": kinds, "ms": round(ms, 3),
                               "Mcells/s": round(cells / ms / 1e3), "frac_8TB": round(cells * bpu / (ms * 1e-3) / 8e12, 3),

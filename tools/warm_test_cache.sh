@@ -13,9 +13,15 @@ timeout 3000 python -m pytest tests -q -m gpu -n $n -p no:cacheprovider \
   --ignore=tests/test_distributed.py --ignore=tests/test_capi_slab.py --ignore=tests/test_bench_launcher.py \
   --deselect tests/test_gpu_parity.py::test_command_line_with_a_named_reference_checker > /tmp/warm_test_cache.log 2>&1
 tail -1 /tmp/warm_test_cache.log
-# the bench workloads and everything __graft_entry__.build() compiles
+# the bench's single-GPU workloads and everything __graft_entry__.build() compiles
 python - <<'PY'
 import __graft_entry__
 __graft_entry__.build()
+import bench
+from stencilflow_amd.backend import Plan
+for name, stages in (("c3", 1000), ("c2", 1000), ("c5", 300), ("box", 16), ("wide", 16), ("cross3", 8), ("dense", 4), ("fork", 16)):
+    wl = bench.make_workload(name, 0, stages)
+    _, sfir = bench.lower_program(wl["prog"])
+    Plan(sfir).close()
 PY
 echo "$(ls .sf_cache | wc -l) code objects, $(du -sh .sf_cache | cut -f1)"
