@@ -32,6 +32,12 @@
 //     evaluates both operators on its whole thread tile and stores the second one's interior (one row -- and, when a row
 //     is cut into tiles, four columns -- on either side are recomputed by the neighbouring tile); no register windows
 //     and no lane exchange, so the f32 adds of co-resident waves overlap.
+//     Round 5, SF_RS 2: two operators that each reach TWO points (sums of few terms -- the generator's radius-2 crosses,
+//     whose in-plane terms join their output plane two steps after their own plane arrived): five accumulator sets per
+//     operator, both rings keep the planes the late terms read (SF_LAG, SF_LAG2), tiles overlap by two rows, and the ring
+//     between the operators holds the TJ rows of the thread tile only (SF_MID_HALO 0).  Rows of 34 threads (136 columns,
+//     128 kept: a row of 512 is four tiles) make blocks that are not whole waves: the last wave has lanes off and
+//     requests no pieces (SF_ODD_WAVE).
 // Round 5: the streaming forms take their planes by LDS-DMA (`buffer_load_dwordx4 ... lds`: memory -> LDS, no staging
 // registers, no ds_write).  The input planes go through a ring of SF_IN_SLOTS slots: SF_LAG planes kept behind the
 // one that has just arrived (terms that join their output plane late), the rest requested ahead.  One wave-instruction writes 64 x 16 bytes of LDS in a row
@@ -45,7 +51,8 @@
 // and is read in aligned pieces (float, RC = 2: 8 + 16 + 8 bytes).
 //
 // Macros from codegen: SF_R SF_VK SF_RJ SF_BX SF_BY SF_NOJ SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_NT SF_KERNEL_NAME,
-//   general forms SF_NLOADS, streaming forms SF_IN_SLOTS SF_RCL [SF_RC SF_ACCS SF_RJH SF_KTILED]; typedef sf_t; struct
+//   general forms SF_NLOADS, streaming forms SF_IN_SLOTS SF_RCL [SF_RC SF_ACCS SF_RJH SF_KTILED SF_LAG; fused: SF_RS
+//   SF_LAG2 SF_MID_SLOTS SF_MID_HALO]; typedef sf_t; struct
 //   sf_scalars; struct sf_auxptrs; struct sf_dense (and sf_dense2) {bc(), bc_zero, apply_row / apply_rows / accumulate + finish}.
 
 typedef sf_t sf_vec __attribute__((ext_vector_type(SF_VK)));
@@ -71,9 +78,14 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_DENSE_T2 0
 #endif
 #if SF_DENSE_STREAM
-#define SF_MID0 SF_IN_SLOTS  // first slot of the ring between the two operators
 #ifndef SF_MID_SLOTS
 #define SF_MID_SLOTS 2
+#endif
+#ifndef SF_RS
+#define SF_RS 1  // fused form: what ONE of the two operators reaches (planes and rows; SF_R = 2 RS is the pair's)
+#endif
+#ifndef SF_LAG2
+#define SF_LAG2 0  // fused form: planes the ring between the operators keeps for the second operator's late terms
 #endif
 #define SF_SLOTS (SF_DENSE_T2 ? SF_IN_SLOTS + SF_MID_SLOTS : SF_IN_SLOTS)
 #ifndef SF_ACCS
@@ -110,7 +122,8 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_NCH (SF_SLOT_ELEMS / SF_CE)       // 16-byte chunks of a slot
 #define SF_NI ((SF_NCH + 63) / 64)           // pieces (wave-instructions, 1 KiB each) that fill one
 #define SF_SLOT_STRIDE (SF_NI * 64 * SF_CE)  // elements from slot to slot: the last piece ends inside the slot's padding
-#define SF_NW (SF_THREADS / 64)
+#define SF_NW (SF_THREADS / 64)               // whole waves of the block: the ones that request pieces (a block whose
+#define SF_ODD_WAVE (SF_THREADS % 64 != 0)   // thread count is no multiple of 64 has one more wave, with lanes off)
 #define SF_ND ((SF_NI + SF_NW - 1) / SF_NW)  // pieces a wave issues per plane, at most / at least
 #define SF_NDMIN (SF_NI / SF_NW)
 #ifndef SF_LAG
@@ -121,6 +134,21 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_SLOT_STRIDE SF_SLOT_ELEMS
 #define SF_PAIRS_PER_ROW (SF_LS / 2)
 #define SF_PAIRS (SF_LROWS * SF_PAIRS_PER_ROW)
+#endif
+#if SF_DENSE_T2
+// The ring between the operators.  SF_MID_HALO 1: slots of the input ring's geometry (halo rows that stay the second
+// operator's boundary constant).  0 (the pairs of reach two): the TJ rows of the thread tile only -- a result that is
+// stored reads nothing beyond them, the tiles overlapping by the second operator's reach; the threads at the rim of
+// the tile, whose results are not stored, read the neighbouring slots (SF_MID_PAD keeps the last one's reads inside).
+#ifndef SF_MID_HALO
+#define SF_MID_HALO 1
+#endif
+#define SF_MID_STRIDE (SF_MID_HALO ? SF_SLOT_STRIDE : (SF_TJ * SF_LS + SF_CE - 1) / SF_CE * SF_CE)
+#define SF_MID_PAD (SF_MID_HALO ? 0 : SF_RJH * SF_LS + SF_CE)
+#define SF_MID0 (SF_IN_SLOTS * SF_SLOT_STRIDE)  // first element of that ring
+#define SF_LDS_ELEMS (SF_MID0 + SF_MID_SLOTS * SF_MID_STRIDE + SF_MID_PAD)
+#else
+#define SF_LDS_ELEMS (SF_SLOTS * SF_SLOT_STRIDE)
 #endif
 
 // slot of plane q + di when the plane written this step (p = q + R) sits in slot PH
@@ -202,7 +230,8 @@ __device__ __forceinline__ void sf_dma_plane(const sf_ctx& cx, const int p, cons
 #pragma unroll
   for (int n = 0; n < SF_ND; ++n) {
     const unsigned piece = (unsigned)n * SF_NW + cx.wave;
-    if (n < SF_NDMIN || piece < (unsigned)SF_NI) sf_dma16(rs, cx.ld_off[n], dst + piece * 1024u);
+    if ((n < SF_NDMIN || piece < (unsigned)SF_NI) && (!SF_ODD_WAVE || cx.wave < (unsigned)SF_NW))
+      sf_dma16(rs, cx.ld_off[n], dst + piece * 1024u);
   }
 }
 
@@ -231,7 +260,8 @@ __device__ __forceinline__ void sf_fix_boundary(const sf_ctx& cx, const int p, c
 #pragma unroll
       for (int n = 0; n < SF_ND; ++n) {
         const unsigned c = ((unsigned)n * SF_NW + cx.wave) * 64u + (threadIdx.x + threadIdx.y * SF_BX) % 64u;
-        if (c < (unsigned)SF_NCH && (!plane_in || cx.ld_off[n] == SF_OOB)) *reinterpret_cast<sf_chunk*>(&sl[c * SF_CE]) = fill;
+        if (c < (unsigned)SF_NCH && (!plane_in || cx.ld_off[n] == SF_OOB) && (!SF_ODD_WAVE || cx.wave < (unsigned)SF_NW))
+          *reinterpret_cast<sf_chunk*>(&sl[c * SF_CE]) = fill;
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -360,15 +390,15 @@ __device__ __forceinline__ void sf_step_stream(sf_t* lds, sf_t* __restrict__ out
 #endif
 
 #if SF_DENSE_T2
-// One step of the fused form.  PH = (p - p_begin) mod 3 names the accumulator sets as in sf_step_stream.  Operator 1
-// reads input plane p from slot `slot` of the input ring and finishes its plane q1 = p - SFD_DLAST, which goes to the
-// ring between the operators (slot parity of q1); operator 2 reads the plane that went there in the PREVIOUS step
-// (q1 - 1: this step's barrier has made it visible) and finishes output plane q1 - 1 - SFD2_DLAST.
-// The input planes go through a ring of two slots (requested one step ahead); the ring between the operators has two
-// slots where 160 KB of LDS allow four, and ONE (SF_MID_SLOTS 1) where they allow three -- 18-row tiles of 512 columns.
+// One step of the fused form.  PH = (p - p_begin) mod ACCS names the accumulator sets as in sf_step_stream.  Operator 1
+// reads input plane p (and the SF_LAG planes before it) from the input ring and finishes its plane q1 = p - SFD_DLAST,
+// which goes to slot `mw` of the ring between the operators; operator 2 reads the plane that went there in the PREVIOUS
+// step (q1 - 1: this step's barrier has made it visible; and the SF_LAG2 planes before it) and finishes output plane
+// q1 - 1 - SFD2_DLAST.  The input planes are requested one step ahead; the ring between the operators has 2 + LAG2
+// slots, or ONE (SF_MID_SLOTS 1) where 160 KB of LDS hold three slots in all -- 18-row tiles of 512 columns.
 template <int PH>
 __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, const sf_scalars& sc, const sf_ctx& cx,
-                                           const int p, const int p_begin, const int p_end, const int slot, const int s0,
+                                           const int p, const int p_begin, const int p_end, const int slot, const int mw,
                                            sf_dense::acc_t (&acc1)[SF_ACCS][SF_RJ][SF_VK],
                                            sf_dense2::acc_t (&acc2)[SF_ACCS][SF_RJ][SF_VK]) {
   sf_wait_plane<(SF_AHEAD - 1) * SF_NDMIN + SF_AHEAD * SF_RJ>(p - p_begin < SF_AHEAD);
@@ -377,13 +407,16 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
   sf_dma_plane(cx, p + SF_AHEAD, p + SF_AHEAD < p_end, (slot + SF_AHEAD) % SF_IN_SLOTS);
   const int q1 = p - SFD_DLAST;
   constexpr int PH2 = (PH - SFD_DLAST - 1 + 2 * SF_ACCS) % SF_ACCS;
-  // where operator 1's plane q1 goes, and where the plane it published a step ago is read
-  const int mid_par = SF_MID_SLOTS == 1 ? 0 : (s0 + 2 - SFD_DLAST) & 1;
-  sf_t* mid_w = lds + (SF_MID0 + mid_par) * SF_SLOT_STRIDE + cx.tb + SF_RJH * SF_LS + SF_RC;
-  const sf_t* mid_r = lds + (SF_MID0 + (SF_MID_SLOTS == 1 ? 0 : (mid_par ^ 1))) * SF_SLOT_STRIDE + cx.tb;
+  // the thread's patch in a slot between the operators (row 0 of such a slot: the tile's row -RJH, or its row 0)
+  const int mid_tb = cx.tb - (SF_MID_HALO ? 0 : SF_RJH * SF_LS);
+  sf_t* mid_w = lds + SF_MID0 + mw * SF_MID_STRIDE + mid_tb + SF_RJH * SF_LS + SF_RC;
   auto second = [&]() {
     // ---- operator 2 on the plane published a step ago
-    sf_dense2::template accumulate<PH2>(mid_r, acc2);
+    const sf_t* tb2[SF_LAG2 + 1];
+#pragma unroll
+    for (int l = 0; l <= SF_LAG2; ++l)
+      tb2[l] = lds + SF_MID0 + (SF_MID_SLOTS == 1 ? 0 : (mw + SF_MID_SLOTS - 1 - l) % SF_MID_SLOTS) * SF_MID_STRIDE + mid_tb;
+    sf_dense2::template accumulate<PH2>(tb2, acc2);
     sf_pin(acc2);
     sf_t rows[SF_RJ][SF_VK];
     sf_dense2::finish(sc, acc2[(PH2 - SFD2_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
@@ -393,7 +426,10 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
   //  plane goes there at the very end of the step, behind a second barrier that sits right before the next step's)
   if constexpr (SF_MID_SLOTS == 1) second();
   // ---- operator 1: plane p joins the open planes, plane q1 is finished and published
-  sf_dense::template accumulate<PH>(in_slot + cx.tb, acc1);
+  const sf_t* tb1[SF_LAG + 1];
+#pragma unroll
+  for (int l = 0; l <= SF_LAG; ++l) tb1[l] = lds + ((slot + SF_IN_SLOTS - l) % SF_IN_SLOTS) * SF_SLOT_STRIDE + cx.tb;
+  sf_dense::template accumulate<PH>(tb1, acc1);
   sf_pin(acc1);
   const bool plane1_in = (q1 + cx.goff >= 0) && (q1 + cx.goff < SF_N0G);
   sf_t mid[SF_RJ][SF_VK];
@@ -416,7 +452,7 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, sf_auxptrs aux, int halo,
                    int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2) {
   (void)aux;
-  __shared__ __attribute__((aligned(1024))) sf_t lds[SF_SLOTS * SF_SLOT_STRIDE];
+  __shared__ __attribute__((aligned(1024))) sf_t lds[SF_LDS_ELEMS];
 
   sf_ctx cx;
   cx.in = in;
@@ -441,9 +477,9 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   if (cx.cb >= cx.ce) return;
 
 #if SF_DENSE_T2
-  // the thread tile overlaps its neighbours: the second operator's results are valid one row (four columns when a row
+  // the thread tile overlaps its neighbours: the second operator's results are valid RS rows (four columns when a row
   // is cut into tiles) inside it
-  const int tj0 = SF_NOJ ? 0 : jt * (SF_TJ - 2) - 1, tk0 = SF_KTILED ? kt * (SF_TK - 8) - 4 : 0;
+  const int tj0 = SF_NOJ ? 0 : jt * (SF_TJ - 2 * SF_RS) - SF_RS, tk0 = SF_KTILED ? kt * (SF_TK - 8) - 4 : 0;
 #else
   const int tj0 = SF_NOJ ? 0 : jt * SF_TJ, tk0 = kt * SF_TK;  // first output point of the tile
 #endif
@@ -480,7 +516,7 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     const int j = tj0 + (SF_NOJ ? 0 : ty * SF_RJ + r), k = tk0 + tx * SF_VK;
 #if SF_DENSE_T2
     const int tr = ty * SF_RJ + r, tc = tx * SF_VK;
-    const bool valid = (SF_NOJ || (tr >= 1 && tr < SF_TJ - 1)) && (!SF_KTILED || (tc >= 4 && tc < SF_TK - 4));
+    const bool valid = (SF_NOJ || (tr >= SF_RS && tr < SF_TJ - SF_RS)) && (!SF_KTILED || (tc >= 4 && tc < SF_TK - 4));
     const bool inside = valid && j >= 0 && j < SF_N1 && k >= 0 && k + SF_VK <= SF_N2;
 #else
     const bool inside = j < SF_N1 && k + SF_VK <= SF_N2;
@@ -507,7 +543,7 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   // the ring between the operators starts out as the second operator's boundary constant: its halo rows and columns
   // are never written again (they are right where the tile touches the edge of the domain; elsewhere the results
   // that read them are not stored)
-  for (int i = tid; i < SF_MID_SLOTS * SF_SLOT_STRIDE; i += SF_THREADS) lds[SF_MID0 * SF_SLOT_STRIDE + i] = sf_dense2::bc();
+  for (int i = tid; i < SF_MID_SLOTS * SF_MID_STRIDE + SF_MID_PAD; i += SF_THREADS) lds[SF_MID0 + i] = sf_dense2::bc();
   sf_dense::acc_t acc1[SF_ACCS][SF_RJ][SF_VK];
   sf_dense2::acc_t acc2[SF_ACCS][SF_RJ][SF_VK];
 #pragma unroll
@@ -523,13 +559,17 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   for (int a = 0; a < SF_AHEAD; ++a) sf_dma_plane(cx, p_begin + a, p_begin + a < p_end, a % SF_IN_SLOTS);
   // output plane q2 leaves at step q2 + SFD_DLAST + 1 + SFD2_DLAST; input planes up to ce + R - 1 are read
   const int p_stop = cx.ce + SFD_DLAST + 1 + SFD2_DLAST;
-  int slot = 0;
+  int slot = 0, mw = 0;  // the input plane's slot; the slot operator 1's plane goes to
   for (int p = p_begin; p < p_stop; p += SF_ACCS) {
-    const int s0 = (p - p_begin) & 1;  // three steps per trip: the slot parity alternates from trip to trip
-    sf_step_t2<0>(lds, out, sc, cx, p, p_begin, p_end, slot, s0, acc1, acc2);
-    sf_step_t2<1>(lds, out, sc, cx, p + 1, p_begin, p_end, (slot + 1) % SF_IN_SLOTS, s0 ^ 1, acc1, acc2);
-    sf_step_t2<2>(lds, out, sc, cx, p + 2, p_begin, p_end, (slot + 2) % SF_IN_SLOTS, s0, acc1, acc2);
-    slot = (slot + 3) % SF_IN_SLOTS;
+    sf_step_t2<0>(lds, out, sc, cx, p, p_begin, p_end, slot, mw, acc1, acc2);
+    sf_step_t2<1>(lds, out, sc, cx, p + 1, p_begin, p_end, (slot + 1) % SF_IN_SLOTS, (mw + 1) % SF_MID_SLOTS, acc1, acc2);
+    sf_step_t2<2>(lds, out, sc, cx, p + 2, p_begin, p_end, (slot + 2) % SF_IN_SLOTS, (mw + 2) % SF_MID_SLOTS, acc1, acc2);
+#if SF_ACCS == 5
+    sf_step_t2<3>(lds, out, sc, cx, p + 3, p_begin, p_end, (slot + 3) % SF_IN_SLOTS, (mw + 3) % SF_MID_SLOTS, acc1, acc2);
+    sf_step_t2<4>(lds, out, sc, cx, p + 4, p_begin, p_end, (slot + 4) % SF_IN_SLOTS, (mw + 4) % SF_MID_SLOTS, acc1, acc2);
+#endif
+    slot = (slot + SF_ACCS) % SF_IN_SLOTS;
+    mw = (mw + SF_ACCS) % SF_MID_SLOTS;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (requests of planes nobody reads: landed before the LDS is given back)
 #elif SF_DENSE_STREAM

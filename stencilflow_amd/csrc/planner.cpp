@@ -544,14 +544,22 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
   return out;
 }
 
-// Two radius-1 plain sums in one streaming dense launch (kernels/dense3d.h: SF_DENSE_T2, codegen.hpp: gen_dense_t2).
-// Tiles overlap by one row (and, when a row is cut, four columns) on either side; four LDS slots of (TJ + 2) x (TK + 4).
+// Two plain sums in one streaming dense launch (kernels/dense3d.h: SF_DENSE_T2, codegen.hpp: gen_dense_t2): radius-1
+// boxes, or (round 5) radius-2 sums of few terms -- the generator's crosses.  Tiles overlap by what ONE operator reaches
+// in rows (and, when a row is cut, four columns) on either side.
 static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>& memo, int k1, int k2, DT dt) {
   const Program& P = pl.P;
   const bool noj = P.n[1] == 1;
   struct Shape {
     int bx, by, rj;
   };
+  StarChoice out;
+  int reach = 1;
+  if (!dense_t2_eligible(P, P.kernels[k1], P.kernels[k2], &reach)) return out;
+  DenseSum sum1, sum2;
+  dense_sum_form(P, P.kernels[k1], &sum1);
+  dense_sum_form(P, P.kernels[k2], &sum2);
+  const int lag1 = stream_schedule(P.kernels[k1], sum1).max_lag, lag2 = stream_schedule(P.kernels[k2], sum2).max_lag;
   // (27-point box 512^3 f32, profiles/r04_dense_t2.log: 128x8x2 9.3e5 Mcells/s, 128x4x4 8.7e5, 128x6x2 8.5-8.7e5,
   //  128x4x3 8.4e5, 64x8x2 7.7e5, 64x4x4 7.4e5 against 8.5e5 on the compact kernel; 9-point box 4096^2: 64 lanes 1.18e6,
   //  128 lanes 1.11e6, 256 lanes 0.97e6 against 1.0e6)
@@ -562,21 +570,32 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
   //  kernel two deep and 1.6e5 three deep)
   static const Shape shapes3d_f64[] = {{256, 3, 3}, {256, 4, 2}, {128, 8, 2}, {128, 4, 4}, {64, 8, 2}};
   static const Shape shapes2d[] = {{64, 1, 1}, {128, 1, 1}, {256, 1, 1}};
+  // reach two: two rows per thread; rows of 34 threads -- 136 columns, 128 of them kept: a row of 512 is four tiles --
+  // or of 32; the shape that keeps most of what it computes on this grid is tried first
+  static const Shape shapes3d_reach2[] = {{34, 15, 2}, {34, 16, 2}, {32, 16, 2}, {34, 12, 2}, {32, 14, 2}, {32, 12, 2}, {32, 8, 2}, {32, 6, 2}};
   // dense.t2: 0 never, 1 (default) where a tile shape wastes at most a quarter of its lanes and rows on this grid,
   // 2 wherever a shape compiles (tests, fuzz campaigns on small grids)
   const bool force = pl.opt.get("dense.t2", 1) >= 2;
-  StarChoice out;
   const std::string prefix = std::string(noj ? "sf_dense2d_" : "sf_dense3d_") + short_of(dt) + "_t2";
   const long long pin_bx = pl.opt.get(noj ? "k2.bx" : "k1.bx", 0), pin_by = pl.opt.get("k1.by", 0), pin_rj = pl.opt.get("k1.rj", 0);
   std::vector<Shape> todo;
   if (pin_bx && (noj || (pin_by && pin_rj))) todo.push_back({(int)pin_bx, noj ? 1 : (int)pin_by, noj ? 1 : (int)pin_rj});
   else if (noj) todo.assign(std::begin(shapes2d), std::end(shapes2d));
+  else if (reach == 2) todo.assign(std::begin(shapes3d_reach2), std::end(shapes3d_reach2));
   else if (dt == DT::F64) todo.assign(std::begin(shapes3d_f64), std::end(shapes3d_f64));
   else todo.assign(std::begin(shapes3d_f32), std::end(shapes3d_f32));
+  auto kept = [&](const Shape& sh) {  // what the tiles of this shape cover against what the grid holds
+    const long long tk = (long long)sh.bx * (dt == DT::F64 ? 2 : 4), tj = noj ? 1 : (long long)sh.by * sh.rj;
+    if (tk <= 8 || (!noj && tj <= 2 * reach)) return 0.0;
+    const long long nkt = tk != P.n[2] ? (P.n[2] + (tk - 8) - 1) / (tk - 8) : 1, njt = noj ? 1 : (P.n[1] + (tj - 2 * reach) - 1) / (tj - 2 * reach);
+    return ((double)P.n[2] / ((double)nkt * (double)tk)) * (noj ? 1.0 : (double)P.n[1] / ((double)njt * (double)tj));
+  };
+  if (reach == 2 && !pin_bx)
+    std::stable_sort(todo.begin(), todo.end(), [&](const Shape& a, const Shape& b) { return kept(a) > kept(b) + 0.02; });
   for (const Shape& sh : todo) {
     StarCfg c;
     c.T = 1;
-    c.R = 2;  // (the group reaches two planes, one per operator: what the slab halo and the chunking see)
+    c.R = 2 * reach;  // (what the group reaches, `reach` planes per operator: what the slab halo and the chunking see)
     c.dense = true;
     c.dense_stream = 1;
     c.dense_t2 = 1;
@@ -589,27 +608,39 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     c.n0g = P.n[0];
     c.n1 = P.n[1];
     c.n2 = P.n[2];
-    if (sh.bx * sh.by > 1024 || sh.bx * sh.by < 64 || (sh.bx * sh.by) % 64 != 0) continue;
+    // (reach two: a block need not be whole waves -- its last wave runs with lanes off and requests no pieces)
+    if (sh.bx * sh.by > 1024 || sh.bx * sh.by < 64 || ((sh.bx * sh.by) % 64 != 0 && reach != 2)) continue;
     const long long tk = (long long)c.BX * c.VK, tj = noj ? 1 : (long long)c.BY * c.RJ;
-    if (!noj && tj < 3) continue;
+    if (!noj && tj < 2 * reach + 1) continue;
     c.ktiled = tk != P.n[2];
     if (c.ktiled && tk <= 8) continue;
     c.HK = 0;
     c.NKT = c.ktiled ? (int)((P.n[2] + (tk - 8) - 1) / (tk - 8)) : 1;
-    c.NJT = noj ? 1 : (int)((P.n[1] + (tj - 2) - 1) / (tj - 2));
+    c.NJT = noj ? 1 : (int)((P.n[1] + (tj - 2 * reach) - 1) / (tj - 2 * reach));
     // what the tiles cover against what the grid holds (rows recomputed by the neighbouring tile, lanes beyond the row)
     const double used = ((double)P.n[2] / ((double)c.NKT * (double)tk)) * (noj ? 1.0 : (double)P.n[1] / ((double)c.NJT * (double)tj));
-    if (!force && !pin_bx && used < 0.75) continue;
-    // the input ring (planes by LDS-DMA, requested `slots - 1` ahead) and the two slots between the operators: as many
-    // input slots, up to three, as fit; one = the next plane requested in mid-step, behind a second barrier
-    const size_t slot = ((size_t)(tj + (noj ? 0 : 2)) * (size_t)(tk + 2 * (16 / size_of(dt))) * size_of(dt) + 1023) / 1024 * 1024;
-    // (two input slots -- the plane requested a whole step ahead -- and two between the operators where four slots fit;
-    //  three slots: ONE between the operators, written at the very end of a step behind a second barrier)
-    const long long fit = (long long)(160 * 1024 / slot);
-    if (fit < 3) continue;
-    c.dense_in_slots = 2;
-    c.dense_mid_slots = fit >= 4 ? 2 : 1;
-    const size_t lds = (size_t)(c.dense_in_slots + c.dense_mid_slots) * slot;
+    if (!force && !pin_bx && used < (reach == 2 ? 0.6 : 0.75)) continue;
+    const size_t row_bytes = (size_t)(tk + 2 * (16 / size_of(dt))) * size_of(dt);
+    const size_t slot = ((size_t)(tj + (noj ? 0 : 2 * reach)) * row_bytes + 1023) / 1024 * 1024;
+    c.dense_in_slots = 2;  // (the plane requested a whole step ahead)
+    c.dense_lag = lag1;
+    size_t lds = 0;
+    if (reach == 1) {
+      // two input slots and two between the operators where four slots fit; three slots: ONE between the operators,
+      // written at the very end of a step behind a second barrier
+      const long long fit = (long long)(160 * 1024 / slot);
+      if (fit < 3 || lag1 != 0 || lag2 != 0) continue;
+      c.dense_mid_slots = fit >= 4 ? 2 : 1;
+      lds = (size_t)(c.dense_in_slots + c.dense_mid_slots) * slot;
+    } else {
+      // the input ring keeps the planes the first operator's late terms read; between the operators: the slot being
+      // written, the plane published a step ago and the ones the second operator reads late -- TJ rows each, no halo
+      // rows (dense3d.h: SF_MID_HALO 0)
+      c.dense_mid_slots = 2 + lag2;
+      lds = (size_t)(c.dense_in_slots + lag1) * slot + (size_t)c.dense_mid_slots * ((size_t)tj * row_bytes) +
+            (size_t)(noj ? 0 : reach) * row_bytes + 16;
+      if (lds > 160 * 1024) continue;
+    }
     c.lds_bytes = lds;
     const double field_bytes = (double)(pl.plan_extent > 0 ? pl.plan_extent : pl.n_local) * (double)P.n[1] * (double)P.n[2] *
                                (double)size_of(dt);
@@ -1234,7 +1265,29 @@ void build_plan(sf_plan& pl) {
     // radius-2 stars (bin/synthesize.py with an extent of 2): kernels/wstar3d.h, two fused by default
     // (ten planes of register window per thread: deeper groups shrink the tile too far)
     const bool wide = !generic_only && star_ok_dims && pl.opt.get("wide", 1) != 0 && wide_eligible(P, P.kernels[k]);
-    if (wide) {
+    // ... unless the operator and the next one are plain sums of few terms (the generator's crosses): the dense kernel's
+    // fused streaming form (round 5: no register windows, no lanes recomputed beyond the tile's rim; select_dense_t2)
+    bool wide_pair = false;
+    // (float32, three dimensions: the radius-2 cross 512^3 runs 249 us per launch of two against 303 on the wide-star
+    //  kernel; float64 524-598 against 424 -- profiles/r05_cross2_fused.log)
+    if (wide && P.n[1] > 1 && P.kernels[k].dt == DT::F32 && pl.opt.get("dense.t2", 1) != 0 && pl.opt.get("dense", 1) != 0 &&
+        k + 1 < K && pl.opt.get("fuse", 2) >= 2 && dense_t2_eligible(P, P.kernels[k], P.kernels[k + 1]) &&
+        P.field(P.kernels[k].name).role == Role::Temp && consumers[P.kernels[k].name] == 1) {
+      StarChoice choice = select_dense_t2(pl, star_memo, k, k + 1, P.kernels[k].dt);
+      if (choice.ok) {
+        st.star = true;
+        st.dense = true;
+        st.kernels = {k, k + 1};
+        st.cfg = choice.cfg;
+        st.ck = choice.ck;
+        st.alts = choice.alts;
+        st.sig = choice.sig;
+        wide_pair = true;
+      }
+    }
+    if (wide_pair) {
+      // (planned above)
+    } else if (wide) {
       std::vector<int> group{k};
       // (f64 too since round 4: 64x8 threads x 5 rows, 238 registers -- 3.4 -> 6.3e5 Mcells/s on the generator's
       // radius-2 cross 512^3, profiles/r04_c5_tiles_wide_f64.log)
@@ -1457,6 +1510,24 @@ void build_plan(sf_plan& pl) {
         }
       } else {
         st.kernels.push_back(k);
+      }
+      // plain sums of few terms within two points (not stars: those are planned above), float32, three dimensions: two
+      // per launch in the dense kernel's fused streaming form
+      int pair_reach = 0;
+      if (!st.star && st.kernels.size() == 1 && !generic_only && star_ok_dims && P.n[1] > 1 && P.kernels[k].dt == DT::F32 &&
+          pl.opt.get("dense.t2", 1) != 0 && pl.opt.get("dense", 1) != 0 && k + 1 < K && fuse >= 2 &&
+          dense_t2_eligible(P, P.kernels[k], P.kernels[k + 1], &pair_reach) && pair_reach == 2 &&
+          P.field(P.kernels[k].name).role == Role::Temp && consumers[P.kernels[k].name] == 1) {
+        StarChoice choice = select_dense_t2(pl, star_memo, k, k + 1, P.kernels[k].dt);
+        if (choice.ok) {
+          st.star = true;
+          st.dense = true;
+          st.kernels = {k, k + 1};
+          st.cfg = choice.cfg;
+          st.ck = choice.ck;
+          st.alts = choice.alts;
+          st.sig = choice.sig;
+        }
       }
       // dense neighbourhoods of radius 2 (the generator's box of extent 2): one operator per launch, LDS tiles
       const bool dense_r3 = dense_r3_eligible(P, P.kernels[k]);

@@ -671,6 +671,72 @@ def box_sum_program(seed):
     return prog
 
 
+def sparse_sum_program(seed):
+    """Chains of 2-6 operators, each ONE left-associated sum of at most 16 terms within two points of the centre: the
+    generator's radius-2 cross in its own order (i-2 .. i+2 first, then the in-plane terms -- which meet their output
+    plane two steps after their own plane arrived), the same cross shuffled, or a random sparse subset of {-2..2}^d in
+    random order; optionally scaled once; constant boundaries, now and then `shrink` or a 27-point operator in between
+    (those end a fused pair).  What the dense kernel's fused streaming form takes two at a time since round 5 (dense3d.h:
+    SF_RS 2, SF_LAG / SF_LAG2; planner: select_dense_t2)."""
+    rng = np.random.default_rng(123_000 + seed)
+    nd = 3 if rng.random() < 0.85 else 2
+    its = ["i", "j", "k"][3 - nd:]
+    if nd == 3:
+        dims = [int(rng.integers(4, 26)), int(rng.integers(3, 60)), 4 * int(rng.integers(2, 140))]
+    else:
+        dims = [int(rng.integers(5, 140)), 4 * int(rng.integers(2, 300))]
+    dtype = "float32" if rng.random() < 0.8 else "float64"
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": [],
+            "dimensions": dims, "program": {}}
+    if rng.random() < 0.4:
+        prog["inputs"]["s0"] = {"data": float(np.round(rng.uniform(-1, 1), 3)), "data_type": dtype, "input_dims": []}
+    stages = int(rng.integers(2, 7))
+    prev = "a"
+    for s in range(stages):
+        name = "b%d" % s
+        shape = rng.random()
+        cross = [tuple(d if a == ax else 0 for a in range(nd)) for ax in range(nd) for d in (-2, -1, 1, 2)]
+        if shape < 0.3:
+            offs = cross
+        elif shape < 0.5:
+            offs = [cross[int(t)] for t in rng.permutation(len(cross))]
+        elif shape < 0.92:
+            count = int(rng.integers(2, 16))
+            cells = [tuple(int(x) - 2 for x in idx) for idx in np.ndindex(*([5] * nd)) if any(int(x) != 2 for x in idx)]
+            offs = [cells[int(t)] for t in rng.permutation(len(cells))[:count]]
+            if not any(2 in map(abs, o) for o in offs):
+                offs.append(tuple(int(rng.choice([-2, 2])) if d == 0 else 0 for d in range(nd)))
+        else:  # a 27-point (9-point) sum ordered by plane: not one of the sparse ones
+            offs = [tuple(int(x) - 1 for x in idx) for idx in np.ndindex(*([3] * nd))]
+        if shape < 0.92 and rng.random() < 0.5:
+            offs.insert(int(rng.integers(0, len(offs) + 1)), (0, ) * nd)
+        offs = list(dict.fromkeys(offs))
+        terms = ["%s[%s]" % (prev, ",".join(it if o == 0 else "%s%+d" % (it, o) for it, o in zip(its, off))) for off in offs]
+        expr = " + ".join(terms)
+        c = rng.random()
+        if c < 0.5:
+            expr = "%r * (%s)" % (float(np.round(rng.uniform(0.01, 0.3), 8)), expr)
+        elif c < 0.7 and "s0" in prog["inputs"]:
+            expr = "s0 * (%s)" % expr
+        kind = rng.random()
+        if kind < 0.06:
+            bc = {"type": "shrink"}
+        elif kind < 0.5:
+            bc = {"type": "constant", "value": int(rng.integers(-1, 3))}
+        else:
+            bc = {"type": "constant", "value": float(rng.choice(EXACT))}
+        prog["program"][name] = {"computation_string": "%s = %s" % (name, expr),
+                                 "boundary_conditions": {prev: bc}, "data_type": dtype}
+        prev = name
+    prog["outputs"].append(prev)
+    if rng.random() < 0.3 and stages >= 3:
+        prog["outputs"].append("b%d" % int(rng.integers(0, stages - 1)))  # an intermediate that is also an output
+    text = " ".join(k["computation_string"] for k in prog["program"].values())
+    if "s0" in prog["inputs"] and "s0 *" not in text:
+        del prog["inputs"]["s0"]
+    return prog
+
+
 # --- random chains of COMPACT operators (kernels/compact3d.h): any subset of the 27
 # offsets {-1,0,1}^3 of the previous stage, optionally a second full input field read
 # through such offsets, scalar / literal coefficients, int / float / shrink boundaries,

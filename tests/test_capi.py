@@ -442,3 +442,29 @@ def test_a_compact_group_that_mostly_recomputes_is_planned_one_operator_at_a_tim
         assert text.count("\n  launch ") == 4 and "T=2" not in text, text
     with backend.Plan(sfir, options={"fuse": 2}) as plan:
         assert "[compact windows 3 T=2" in plan.describe(), plan.describe()
+
+
+def test_radius_two_crosses_pair_up_in_the_fused_dense_form(tmp_path):
+    """The generator's radius-2 cross, float32, 512^3 (bench.py's `wide` workload): two operators per launch in the dense
+    kernel's fused streaming form since round 5 -- each operator reaches two planes (SF_RS 2), its eight in-plane terms
+    join their output plane two steps after their own plane arrived (SF_LAG / SF_LAG2 2: four input slots, four slots of
+    TJ rows between the operators), rows of 34 threads so that a row of 512 is four tiles of 128 kept columns (a block
+    of 510 threads: its last wave requests no pieces).  float64, 2-D and dense.t2=0 keep the wide-star kernel
+    (profiles/r05_cross2_fused.log: 249 against 303 us per launch in float32, 524 against 424 in float64)."""
+    cross, _ = programs.synthesize("float32", 4, 0.0, 512, 512, 512, 2, 2, 2)
+    sfir = lower(sf.KernelChainGraph(programs.write_program(cross, str(tmp_path / "cross.json"))))
+    with backend.Plan(sfir) as plan:
+        text, src = plan.describe(), plan.kernel_source(0)
+        assert "2 launches" in text and "sf_dense3d_f32_t2_" in text and "block 34x15 rows/thread 2 tiles 20x4" in text, text
+        for macro in ("#define SF_RS 2\n", "#define SF_MID_HALO 0\n", "#define SF_LAG 2\n", "#define SF_LAG2 2\n", "#define SF_IN_SLOTS 4\n",
+                      "#define SF_MID_SLOTS 4\n", "#define SF_ACCS 5\n", "#define SFD_DLAST 2\n"):
+            assert macro in src, macro
+        res = plan.kernel_resources()[plan.kernel_names()[0]]
+        assert res["spills"] == 0 and res["scratch"] == 0 and res["vgprs"] <= 128 and res["lds"] <= 160 * 1024, res
+    with backend.Plan(sfir, options={"dense.t2": 0}) as plan:
+        assert "[wide star T=2" in plan.describe()
+    for dtype, dims in (("float64", (512, 512, 512)), ("float32", (4096, 4096, 0))):
+        other, _ = programs.synthesize(dtype, 4, 0.0, *dims, 2, 2, 2 if dims[2] else 0)
+        sfir = lower(sf.KernelChainGraph(programs.write_program(other, str(tmp_path / "other.json"))))
+        with backend.Plan(sfir) as plan:
+            assert "[wide star" in plan.describe() and "_t2_" not in plan.describe().replace("wstar3d_f64_t2", "").replace("wstar2d_f32_t2", ""), plan.describe()

@@ -926,7 +926,8 @@ def test_generator_box_of_extent_three_streams_through_the_dense_kernel(tmp_path
 
 
 @pytest.mark.parametrize("args,kwargs,stages,kernel,options", [
-    ((2, 2, 2), {}, 4, "[wide star T=2", None),
+    ((2, 2, 2), {}, 4, "sf_dense3d_f32_t2_", None),                               # round 5: two radius-2 crosses per streaming dense launch
+    ((2, 2, 2), {}, 4, "[wide star T=2", {"dense.t2": 0}),                        # the wide-star kernel (rounds 3-4)
     ((1, 1, 1), {"stencil_shape": "box"}, 4, "sf_dense3d_f32_t2_", None),         # round 4: two boxes per streaming dense launch
     ((1, 1, 1), {"stencil_shape": "box"}, 4, "[compact", {"dense.t2": 0}),        # the compact kernel (rounds 2-3)
     ((2, 2, 2), {"stencil_shape": "box"}, 2, "[dense", None),
@@ -1199,19 +1200,23 @@ def test_nonzero_boundary_constants_under_lds_dma(tmp_path, dims, extent, bc):
     assert np.array_equal(got, want, equal_nan=True)
 
 
-@pytest.mark.parametrize("shape,extent,world", [("cross", 3, 2), ("cross", 3, 3), ("box", 3, 2), ("box", 2, 3)])
+@pytest.mark.parametrize("shape,extent,world", [("cross", 3, 2), ("cross", 3, 3), ("box", 3, 2), ("box", 2, 3), ("cross", 2, 2),
+                                                ("cross", 2, 3)])
 def test_streaming_dense_launches_under_slab_decomposition(tmp_path, shape, extent, world):
-    """The streaming dense forms on in-process slabs: a launch reaches `extent` planes across a slab boundary, the
-    planes requested by LDS-DMA include ghost planes, and planes outside the GLOBAL domain (not the slab) are the ones
-    that hold the boundary constant."""
+    """The streaming dense forms on in-process slabs: a launch reaches `extent` planes across a slab boundary (the fused
+    pair of radius-2 crosses: four), the planes requested by LDS-DMA include ghost planes, and planes outside the GLOBAL
+    domain (not the slab) are the ones that hold the boundary constant."""
     from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
     from stencilflow_amd.lowering import lower
     dims = (36, 14, 40)
     prog, x, chain = _synth_case(tmp_path, "float32", dims, extent, shape, {"type": "constant", "value": 0.5}, stages=3, seed=43)
     sfir = lower(chain)
     exch = LocalExchanger(world)
-    runners = [SlabRunner(sfir, dims, r, world, exchanger=exch.for_rank(r), groups_per_exchange=1) for r in range(world)]
+    runners = [SlabRunner(sfir, dims, r, world, exchanger=exch.for_rank(r), groups_per_exchange=1,
+                          options={"dense.t2": 2} if extent == 2 and shape == "cross" else None) for r in range(world)]
     assert all("[dense" in r.plan.describe() for r in runners), runners[0].plan.describe()
+    if extent == 2 and shape == "cross":
+        assert all("#define SF_RS 2\n" in r.plan.kernel_source(0) for r in runners)
     for r in runners:
         r.upload([x[r.lo:r.hi]])
     run_lockstep(runners)
@@ -1244,6 +1249,37 @@ def test_fused_dense_form_with_one_and_two_slots_between_the_operators(tmp_path,
         plan.run([x], [got], 1)
     want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("dims,bc,stages,pins", [
+    ((14, 37, 72), {"type": "constant", "value": 0}, 2, {}),
+    ((9, 30, 136), {"type": "constant", "value": 0.5}, 4, {}),                               # float literal: double-typed sums
+    ((20, 33, 520), {"type": "constant", "value": -1}, 2, {}),                               # rows cut into five k-tiles
+    ((7, 5, 8), {"type": "constant", "value": 2}, 2, {}),                                    # the whole grid inside a halo
+    ((31, 70, 264), {"type": "constant", "value": 0.25}, 3, {}),                             # the odd one out: wide-star kernel
+    ((12, 64, 512), {"type": "constant", "value": 0}, 2, {"k1.bx": 32, "k1.by": 16, "k1.rj": 2}),  # whole waves, rows of 128 columns
+    ((12, 64, 512), {"type": "constant", "value": 1}, 2, {"k1.bx": 34, "k1.by": 30, "k1.rj": 1}),  # 1020 threads, one row each
+    ((70, 41, 136), {"type": "constant", "value": 0.5}, 4, {"k1.bx": 34, "k1.by": 7, "k1.rj": 2}),  # several chunks of planes
+])
+def test_radius_two_crosses_two_per_streaming_dense_launch(tmp_path, dims, bc, stages, pins):
+    """Round 5: the generator's radius-2 crosses (bin/synthesize.py:19-31,95-101: i-2 .. i+2 first, then the j and k terms)
+    two per launch in the dense kernel's fused streaming form -- every operator reaches two planes and rows, its in-plane
+    terms join their output plane two steps after their own plane arrived (the input ring and the ring between the
+    operators keep two more planes each), tiles overlap by two rows and four columns, blocks of 34-thread rows end in a
+    wave with lanes off.  dense.t2=2 forces the form onto grids it would not choose; bit for bit the oracle's results."""
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    prog, x, chain = _synth_case(tmp_path, "float32", dims, 2, "cross", bc, stages=stages, seed=46)
+    got = np.zeros(dims, np.float32)
+    with Plan(lower(chain), options=dict(pins, **{"dense.t2": 2})) as plan:
+        src = plan.kernel_source(0)
+        assert "sf_dense3d_f32_t2_" in plan.describe() and "[point]" not in plan.describe(), plan.describe()
+        assert "#define SF_RS 2\n" in src and "#define SF_LAG 2\n" in src and "#define SF_LAG2 2\n" in src and "offen lds" in src
+        if pins:
+            assert "block %dx%d rows/thread %d" % (pins["k1.bx"], pins["k1.by"], pins["k1.rj"]) in plan.describe(), plan.describe()
+        plan.run([x], [got], 1)
+    want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
+    assert np.array_equal(got, want, equal_nan=True)
 
 
 def test_full_size_radius_three_cross_bit_exact():

@@ -3,6 +3,7 @@ implementations agree bit for bit (CPU), the front end lowers every program and
 the library compiles it (CPU), and the HIP backend agrees with the oracle bit
 for bit (GPU)."""
 import json
+import re
 
 import numpy as np
 import pytest
@@ -553,6 +554,61 @@ def test_radius_one_plain_sums_pair_up_in_the_dense_kernel(seed, tmp_path):
 @pytest.mark.parametrize("seed", list(range(0, 6)))
 def test_hip_matches_oracle_on_fused_pairs_of_plain_sums(seed, tmp_path):
     prog, ins, chain = _box_sum_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain), options={"dense.t2": 2}) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]]) for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
+
+
+def _sparse_sum_case(seed, tmp_path):
+    import tests.random_programs as rp
+    prog = rp.sparse_sum_program(seed)
+    rng = np.random.default_rng(seed + 7)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    path = programs.write_program(prog, str(tmp_path / "p.json"))
+    return prog, ins, sf.KernelChainGraph(path)
+
+
+@pytest.mark.parametrize("seed", [0, 3, 4])
+def test_sparse_radius_two_sums_pair_up_in_the_dense_kernel(seed, tmp_path):
+    """Chains of plain sums of at most 16 terms within two points, in the generator's cross order, shuffled, or random
+    subsets in random order (tests/random_programs.py: sparse_sum_program): the oracles agree, and with dense.t2=2
+    consecutive float32 3-D pairs share one streaming dense launch whose rings keep the planes the late terms read (CPU:
+    hipRTC only); dense.t2=0 plans none."""
+    prog, ins, chain = _sparse_sum_case(seed, tmp_path)
+    a = npo.run_reference(prog, inputs=ins)
+    b = c_oracle.CompiledReference(prog).run(inputs=ins)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (seed, k)
+    with Plan(lower(chain), options={"dense.t2": 2}) as plan:
+        text = plan.describe()
+        pairs = [i for i, n in enumerate(plan.kernel_names()) if n.startswith("sf_dense") and "_t2_" in n and n in text]
+        assert pairs, text
+        reach2 = [i for i in pairs if "#define SF_RS 2\n" in plan.kernel_source(i)]
+        assert reach2, text
+        for i in reach2:
+            src = plan.kernel_source(i)
+            slots = {m: int(re.search(r"#define %s (\d+)\n" % m, src).group(1)) if re.search(r"#define %s (\d+)\n" % m, src) else d
+                     for m, d in (("SF_IN_SLOTS", 0), ("SF_LAG", 0), ("SF_MID_SLOTS", 2), ("SF_LAG2", 0))}
+            assert slots["SF_IN_SLOTS"] == 2 + slots["SF_LAG"] and slots["SF_MID_SLOTS"] == 2 + slots["SF_LAG2"], slots
+        assert sorted(plan.output_names) == sorted(prog["outputs"])
+    with Plan(lower(chain), options={"dense.t2": 0}) as plan:
+        assert "_t2_" not in "".join(n for n in plan.kernel_names() if n.startswith("sf_dense"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(0, 8)))
+def test_hip_matches_oracle_on_fused_pairs_of_sparse_radius_two_sums(seed, tmp_path):
+    prog, ins, chain = _sparse_sum_case(seed, tmp_path)
     want = npo.run_reference(prog, inputs=ins)
     with Plan(lower(chain), options={"dense.t2": 2}) as plan:
         if plan.scalar_names:

@@ -3,7 +3,7 @@
 benchmark size -- time per launch for a list of plan-option variants, every result compared bit for bit with the same
 program on the generic kernel (`generic_only=1`).
 usage: dense_probe.py WORKLOAD [--variants "k1.bx=64;k1.by=2;k1.rj=4|dense.inslots=2|..."] [--stages N] [--reps N]
-  WORKLOAD: box27 | box27_f64 | box9_2d | box125 | box125_f64 | box25_2d | box343 | box49_2d
+  WORKLOAD: box27 | box27_f64 | box9_2d | box125 | box125_f64 | box25_2d | box343 | box49_2d | cross2 | cross2_f64 | cross3
   a variant is a plan-option string; the empty variant is the planner's default.  SF_HIP_LIBNAME=libsf_hip_head.so in the
   environment runs the same variants on another build of the library (A/B on one box)."""
 import argparse
@@ -30,6 +30,9 @@ WORKLOADS = {
     "box25_2d": ("float32", (4096, 4096, 0), 2, 4),
     "box343": ("float32", (512, 512, 512), 3, 2),
     "box49_2d": ("float32", (4096, 4096, 0), 3, 2),
+    "cross2": ("float32", (512, 512, 512), 2, 4, "cross"),
+    "cross2_f64": ("float64", (512, 512, 512), 2, 4, "cross"),
+    "cross3": ("float32", (512, 512, 512), 3, 2, "cross"),
 }
 
 
@@ -42,10 +45,11 @@ def main():
     ap.add_argument("--bc", default=None, help="boundary constant of every operator (default: the generator's 0)")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
-    dtype, dims, extent, stages = WORKLOADS[args.workload]
+    dtype, dims, extent, stages = WORKLOADS[args.workload][:4]
+    stencil_shape = (WORKLOADS[args.workload] + ("box",))[4]
     stages = args.stages or stages
     ext = [extent if d else 0 for d in dims]
-    prog, _ = programs.synthesize(dtype, stages, 0.0, *dims, *ext, stencil_shape="box")
+    prog, _ = programs.synthesize(dtype, stages, 0.0, *dims, *ext, stencil_shape=stencil_shape)
     if args.bc is not None:
         for k in prog["program"].values():
             for f in k["boundary_conditions"]:

@@ -3,7 +3,8 @@
 of extent 1 -- 27 points, 9 in 2-D -- over grids that fit a tile, need several, cut rows into k-tiles or leave most of a
 tile empty, float32 / float64, 2-4 operators (an odd one out stays on the compact kernel), int and float boundary
 literals; every result against the NumPy oracle.  dense.t2=2 forces the form onto grids it would not choose.
-usage (from the repository root, on a GPU box): python tools/dense_t2_check.py"""
+`cross2`: the generator's radius-2 crosses instead (round 5: reach two per operator, terms that join their plane late).
+usage (from the repository root, on a GPU box): python tools/dense_t2_check.py [cross2]"""
 import os
 import sys
 import tempfile
@@ -17,6 +18,7 @@ from stencilflow_amd.lowering import lower
 from oracle import numpy_oracle as npo
 bad = 0
 cases = []
+CROSS2 = len(sys.argv) > 1 and sys.argv[1] == "cross2"
 for dims in [(20, 37, 72), (9, 14, 24), (33, 50, 512), (7, 16, 516), (12, 70, 1028), (70, 136), (40, 512), (25, 1032)]:
     for dtype in ("float32", "float64"):
         for stages in (2, 3, 4):
@@ -26,8 +28,10 @@ rng = np.random.default_rng(5)
 for dims, dtype, stages, bc in cases:
     if rng.random() < 0.5 and len(cases) > 60: continue
     full = list(dims) + [0] * (3 - len(dims))
-    ext = [1 if d else 0 for d in full]
-    prog, _ = programs.synthesize(dtype, stages, 0.0, *full, *ext, stencil_shape="box")
+    if CROSS2 and (len(dims) < 3 or dtype != "float32"):
+        continue
+    ext = [(2 if CROSS2 else 1) if d else 0 for d in full]
+    prog, _ = programs.synthesize(dtype, stages, 0.0, *full, *ext, stencil_shape="cross" if CROSS2 else "box")
     for k in prog["program"].values():
         for f in k["boundary_conditions"]:
             k["boundary_conditions"][f] = {"type": "constant", "value": bc}

@@ -52,7 +52,11 @@ def cases():
         "hotspot": (syn("float32", 4, 0.0, 512, 512, 512, 1, 1, 1, stencil_shape="hotspot")[0], None),
         "hotspot2d": (syn("float32", 4, 0.0, 4096, 4096, 0, 1, 1, 0, stencil_shape="hotspot")[0], None),
         "cross_f64": (syn("float64", 4, 0.0, 512, 512, 512, 1, 1, 1)[0], None),
-        "wide": (syn("float32", 4, 0.0, 512, 512, 512, 2, 2, 2)[0], None),
+        "wide": (syn("float32", 4, 0.0, 512, 512, 512, 2, 2, 2)[0], "dense.t2=0"),
+        "cross2_fused": (syn("float32", 4, 0.0, 512, 512, 512, 2, 2, 2)[0], None),
+        "box_fused": (syn("float32", 4, 0.0, 512, 512, 512, 1, 1, 1, stencil_shape="box")[0], None),
+        "dense": (syn("float32", 2, 0.0, 512, 512, 512, 2, 2, 2, stencil_shape="box")[0], None),
+        "cross3": (syn("float32", 2, 0.0, 512, 512, 512, 3, 3, 3)[0], None),
         "wide_f64": (syn("float64", 2, 0.0, 512, 512, 512, 2, 2, 2)[0], None),
         "wide2d": (syn("float32", 4, 0.0, 4096, 4096, 0, 2, 2, 0)[0], None),
         "fork": (syn("float32", 12, 0.0, 512, 512, 512, 1, 1, 1, fork_frequency=0.25)[0], None),

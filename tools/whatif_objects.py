@@ -6,7 +6,7 @@ SF_HIP_OBJECT_DIR=<out>/<variant> SF_HIP_SELF_CHECK=0 makes the library launch t
 (csrc/codecache.cpp: intern_kernel) -- e.g. under tools/dense_probe.py --no-check.  This replaces round 4's
 `debug.whatif` plan option: no wrong-result build is reachable through sf_plan_create any more.
 usage: whatif_objects.py WORKLOAD "PLAN OPTIONS" OUT_DIR [variant ...]
-  variants: asis nobar nolds nodma nostore nomem (= nodma + nostore) valu (= everything but the arithmetic)"""
+  variants: asis nobar nolds nodma nostore nomem (= nodma + nostore) valu (= everything but the arithmetic) ahead2"""
 import os
 import re
 import subprocess
@@ -30,6 +30,8 @@ def edit(text, variant):
     for part in parts:
         if part == "asis":
             continue
+        elif part == "ahead2":  # (one more input slot: planes requested two steps ahead -- the results stay right)
+            text = re.sub(r"#define SF_IN_SLOTS (\d+)", lambda m: "#define SF_IN_SLOTS %d" % (int(m.group(1)) + 1), text)
         elif part == "nobar":
             text = text.replace("\\n\\ts_barrier", "").replace('asm volatile("s_barrier" ::: "memory");', "")
         elif part == "nolds":
@@ -50,9 +52,9 @@ def edit(text, variant):
 def main():
     workload, opts, out_dir = sys.argv[1], sys.argv[2] or None, sys.argv[3]
     variants = sys.argv[4:] or ["asis", "nobar", "nolds", "nomem", "valu"]
-    dtype, dims, extent, stages = WORKLOADS[workload]
+    dtype, dims, extent, stages = WORKLOADS[workload][:4]
     ext = [extent if d else 0 for d in dims]
-    prog, _ = programs.synthesize(dtype, stages, 0.0, *dims, *ext, stencil_shape="box")
+    prog, _ = programs.synthesize(dtype, stages, 0.0, *dims, *ext, stencil_shape=(WORKLOADS[workload] + ("box",))[4])
     with tempfile.TemporaryDirectory() as tmp:
         plan = Plan(lower(sf.KernelChainGraph(programs.write_program(prog, os.path.join(tmp, "p.json")))), options=opts)
         name, source = plan.kernel_names()[0], plan.kernel_source(0)
