@@ -608,8 +608,8 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     c.n0g = P.n[0];
     c.n1 = P.n[1];
     c.n2 = P.n[2];
-    // (reach two: a block need not be whole waves -- its last wave runs with lanes off and requests no pieces)
-    if (sh.bx * sh.by > 1024 || sh.bx * sh.by < 64 || ((sh.bx * sh.by) % 64 != 0 && reach != 2)) continue;
+    // (a block need not be whole waves -- its last wave runs with lanes off and requests no pieces)
+    if (sh.bx * sh.by > 1024 || sh.bx * sh.by < 64) continue;
     const long long tk = (long long)c.BX * c.VK, tj = noj ? 1 : (long long)c.BY * c.RJ;
     if (!noj && tj < 2 * reach + 1) continue;
     c.ktiled = tk != P.n[2];
@@ -833,7 +833,7 @@ static const OptionSpec kOptions[] = {
     {"compact", 0, 1, "kernel family switch: fused groups over {-1,0,1}^3, kernels/compact3d.h (default 1)"},
     {"wide", 0, 1, "kernel family switch: fused radius-2 star groups, kernels/wstar3d.h (default 1)"},
     {"dense", 0, 1, "kernel family switch: dense neighbourhoods and plain sums, kernels/dense3d.h (default 1)"},
-    {"dense.t2", 0, 2, "two radius-1 plain sums per dense launch: 0 never, 1 where a tile fits the grid (default), 2 wherever one compiles"},
+    {"dense.t2", 0, 2, "two plain sums per dense launch (radius-1 boxes; float32 3-D sums of few terms within two points): 0 never, 1 where a tile fits the grid (default), 2 wherever one compiles"},
     {"generic_only", 0, 1, "every operator on the generic kernel, one per launch"},
     {"k1.bx", 0, 1024, "pin the tile shape, 3-D: lanes per row (with k1.by and k1.rj)"},
     {"k1.by", 0, 64, "pin the tile shape, 3-D: thread rows"},

@@ -44,9 +44,12 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--bc", default=None, help="boundary constant of every operator (default: the generator's 0)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--dims", default="", help="grid other than the workload's, e.g. 256,256,256")
     args = ap.parse_args()
     dtype, dims, extent, stages = WORKLOADS[args.workload][:4]
     stencil_shape = (WORKLOADS[args.workload] + ("box",))[4]
+    if args.dims:
+        dims = tuple(int(d) for d in args.dims.split(","))
     stages = args.stages or stages
     ext = [extent if d else 0 for d in dims]
     prog, _ = programs.synthesize(dtype, stages, 0.0, *dims, *ext, stencil_shape=stencil_shape)
