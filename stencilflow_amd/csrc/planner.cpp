@@ -555,7 +555,7 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
   };
   StarChoice out;
   int reach = 1;
-  if (!dense_t2_eligible(P, P.kernels[k1], P.kernels[k2], &reach)) return out;
+  if (!dense_t2_eligible(P, P.kernels[k1], P.kernels[k2], &reach, true)) return out;
   DenseSum sum1, sum2;
   dense_sum_form(P, P.kernels[k1], &sum1);
   dense_sum_form(P, P.kernels[k2], &sum2);
@@ -625,11 +625,11 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     c.dense_in_slots = 2;  // (the plane requested a whole step ahead)
     c.dense_lag = lag1;
     size_t lds = 0;
-    if (reach == 1) {
+    if (reach == 1 && lag1 == 0 && lag2 == 0) {
       // two input slots and two between the operators where four slots fit; three slots: ONE between the operators,
       // written at the very end of a step behind a second barrier
       const long long fit = (long long)(160 * 1024 / slot);
-      if (fit < 3 || lag1 != 0 || lag2 != 0) continue;
+      if (fit < 3) continue;
       c.dense_mid_slots = fit >= 4 ? 2 : 1;
       lds = (size_t)(c.dense_in_slots + c.dense_mid_slots) * slot;
     } else {
@@ -1414,7 +1414,7 @@ void build_plan(sf_plan& pl) {
       // qualifies and a tile shape fits the grid (dense.t2, select_dense_t2); else the compact kernel
       bool dense_pair = false;
       if (compact && cshape.extra.empty() && pl.opt.get("dense.t2", 1) != 0 && pl.opt.get("dense", 1) != 0 && k + 1 < K &&
-          fuse >= 2 && dense_t2_eligible(P, P.kernels[k], P.kernels[k + 1]) &&
+          fuse >= 2 && dense_t2_eligible(P, P.kernels[k], P.kernels[k + 1], nullptr, pl.opt.get("star", 1) == 0) &&
           P.field(P.kernels[k].name).role == Role::Temp && consumers[P.kernels[k].name] == 1) {
         StarChoice choice = select_dense_t2(pl, star_memo, k, k + 1, P.kernels[k].dt);
         if (choice.ok) {

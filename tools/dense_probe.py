@@ -33,6 +33,7 @@ WORKLOADS = {
     "cross2": ("float32", (512, 512, 512), 2, 4, "cross"),
     "cross2_f64": ("float64", (512, 512, 512), 2, 4, "cross"),
     "cross3": ("float32", (512, 512, 512), 3, 2, "cross"),
+    "jacobi3d": ("float32", (512, 512, 512), 1, 8, "jacobi3d"),  # (the benchmark's operator: programs.jacobi3d)
 }
 
 
@@ -52,7 +53,10 @@ def main():
         dims = tuple(int(d) for d in args.dims.split(","))
     stages = args.stages or stages
     ext = [extent if d else 0 for d in dims]
-    prog, _ = programs.synthesize(dtype, stages, 0.0, *dims, *ext, stencil_shape=stencil_shape)
+    if stencil_shape == "jacobi3d":
+        prog = programs.jacobi3d(tuple(dims), stages)
+    else:
+        prog, _ = programs.synthesize(dtype, stages, 0.0, *dims, *ext, stencil_shape=stencil_shape)
     if args.bc is not None:
         for k in prog["program"].values():
             for f in k["boundary_conditions"]:

@@ -30,8 +30,8 @@ def edit(text, variant):
     for part in parts:
         if part == "asis":
             continue
-        elif part == "ahead2":  # (one more input slot: planes requested two steps ahead -- the results stay right)
-            text = re.sub(r"#define SF_IN_SLOTS (\d+)", lambda m: "#define SF_IN_SLOTS %d" % (int(m.group(1)) + 1), text)
+        elif part in ("ahead2", "ahead3"):  # (more input slots: planes requested two / three steps ahead -- the results stay right)
+            text = re.sub(r"#define SF_IN_SLOTS (\d+)", lambda m: "#define SF_IN_SLOTS %d" % (int(m.group(1)) + int(part[-1]) - 1), text)
         elif part == "nobar":
             text = text.replace("\\n\\ts_barrier", "").replace('asm volatile("s_barrier" ::: "memory");', "")
         elif part == "nolds":
@@ -54,7 +54,8 @@ def main():
     variants = sys.argv[4:] or ["asis", "nobar", "nolds", "nomem", "valu"]
     dtype, dims, extent, stages = WORKLOADS[workload][:4]
     ext = [extent if d else 0 for d in dims]
-    prog, _ = programs.synthesize(dtype, stages, 0.0, *dims, *ext, stencil_shape=(WORKLOADS[workload] + ("box",))[4])
+    shape = (WORKLOADS[workload] + ("box",))[4]
+    prog = programs.jacobi3d(tuple(dims), stages) if shape == "jacobi3d" else programs.synthesize(dtype, stages, 0.0, *dims, *ext, stencil_shape=shape)[0]
     with tempfile.TemporaryDirectory() as tmp:
         plan = Plan(lower(sf.KernelChainGraph(programs.write_program(prog, os.path.join(tmp, "p.json")))), options=opts)
         name, source = plan.kernel_names()[0], plan.kernel_source(0)
