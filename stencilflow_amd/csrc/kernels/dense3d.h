@@ -87,6 +87,15 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #ifndef SF_LAG2
 #define SF_LAG2 0  // fused form: planes the ring between the operators keeps for the second operator's late terms
 #endif
+#ifndef SF_NST
+#define SF_NST 2  // fused form: operators per launch (three: a second ring, between the second and the third)
+#endif
+#ifndef SF_LAG3
+#define SF_LAG3 0
+#endif
+#ifndef SF_MID2_SLOTS
+#define SF_MID2_SLOTS (SF_NST == 3 ? 2 + SF_LAG3 : 0)
+#endif
 #define SF_SLOTS (SF_DENSE_T2 ? SF_IN_SLOTS + SF_MID_SLOTS : SF_IN_SLOTS)
 #ifndef SF_ACCS
 #define SF_ACCS (2 * SF_R + 1)  // accumulator sets: output planes p - R .. p + R are open while plane p is read
@@ -144,10 +153,16 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_MID_HALO 1
 #endif
 #define SF_MID_STRIDE (SF_MID_HALO ? SF_SLOT_STRIDE : (SF_TJ * SF_LS + SF_CE - 1) / SF_CE * SF_CE)
-#define SF_MID_PAD (SF_MID_HALO ? 0 : SF_RJH * SF_LS + SF_CE)
-#define SF_MID0 (SF_IN_SLOTS * SF_SLOT_STRIDE)  // first element of that ring
-#define SF_LDS_ELEMS (SF_MID0 + SF_MID_SLOTS * SF_MID_STRIDE + SF_MID_PAD)
+#define SF_MID_PAD (SF_MID_HALO ? 0 : SF_RJH * SF_LS + 2 * SF_CE)
+// (SF_RCL 0 -- rows without halo columns, below -- : the first thread of a slot's first row reads SF_RC elements before
+//  it; one 1-KiB piece in front of slot 0 keeps that inside the array and the slots on whole pieces)
+#define SF_LDS_FRONT (SF_RCL < SF_RC ? 1024 / (int)sizeof(sf_t) : 0)
+#define SF_EDGE ((SF_NST - 1) * SF_RS)  // rows on either side of the thread tile whose results are not stored
+#define SF_MID0 (SF_IN_SLOTS * SF_SLOT_STRIDE)              // first element of the ring between operators 1 and 2 (from slot 0)
+#define SF_MIDB0 (SF_MID0 + SF_MID_SLOTS * SF_MID_STRIDE)  // ... between operators 2 and 3
+#define SF_LDS_ELEMS (SF_LDS_FRONT + SF_MIDB0 + SF_MID2_SLOTS * SF_MID_STRIDE + SF_MID_PAD)
 #else
+#define SF_LDS_FRONT 0
 #define SF_LDS_ELEMS (SF_SLOTS * SF_SLOT_STRIDE)
 #endif
 
@@ -393,14 +408,33 @@ __device__ __forceinline__ void sf_step_stream(sf_t* lds, sf_t* __restrict__ out
 // One step of the fused form.  PH = (p - p_begin) mod ACCS names the accumulator sets as in sf_step_stream.  Operator 1
 // reads input plane p (and the SF_LAG planes before it) from the input ring and finishes its plane q1 = p - SFD_DLAST,
 // which goes to slot `mw` of the ring between the operators; operator 2 reads the plane that went there in the PREVIOUS
-// step (q1 - 1: this step's barrier has made it visible; and the SF_LAG2 planes before it) and finishes output plane
-// q1 - 1 - SFD2_DLAST.  The input planes are requested one step ahead; the ring between the operators has 2 + LAG2
-// slots, or ONE (SF_MID_SLOTS 1) where 160 KB of LDS hold three slots in all -- 18-row tiles of 512 columns.
+// step (q1 - 1: this step's barrier has made it visible; and the SF_LAG2 planes before it) and finishes plane
+// q2 = q1 - 1 - SFD2_DLAST -- the launch's output, or (SF_NST 3) the plane that goes to slot `mw2` of a second such ring,
+// from which operator 3 finishes output plane q2 - 1 - SFD3_DLAST the same way.  The input planes are requested one
+// step ahead; a ring between two operators has 2 + LAG slots, or ONE (SF_MID_SLOTS 1, two operators) where 160 KB of
+// LDS hold three slots in all -- 18-row tiles of 512 columns.
+template <typename F>
+__device__ __forceinline__ void sf_publish(const sf_ctx& cx, const sf_t (&rows)[SF_RJ][SF_VK], const bool plane_in, sf_t* dst) {
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r) {
+    // outside the global domain the next operator reads ITS boundary constant
+    const bool row_in = plane_in && ((cx.jmask >> r) & 1u);
+    sf_vec w;
+#pragma unroll
+    for (int v = 0; v < SF_VK; ++v) w[v] = (row_in && ((cx.kmask >> v) & 1u)) ? rows[r][v] : F::bc();
+    *reinterpret_cast<sf_vec*>(&dst[r * SF_LS]) = w;  // (the thread's own columns: 16-byte aligned)
+  }
+}
+
 template <int PH>
 __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, const sf_scalars& sc, const sf_ctx& cx,
                                            const int p, const int p_begin, const int p_end, const int slot, const int mw,
-                                           sf_dense::acc_t (&acc1)[SF_ACCS][SF_RJ][SF_VK],
-                                           sf_dense2::acc_t (&acc2)[SF_ACCS][SF_RJ][SF_VK]) {
+                                           const int mw2, sf_dense::acc_t (&acc1)[SF_ACCS][SF_RJ][SF_VK],
+                                           sf_dense2::acc_t (&acc2)[SF_ACCS][SF_RJ][SF_VK]
+#if SF_NST == 3
+                                           , sf_dense3::acc_t (&acc3)[SF_ACCS][SF_RJ][SF_VK]
+#endif
+) {
   sf_wait_plane<(SF_AHEAD - 1) * SF_NDMIN + SF_AHEAD * SF_RJ>(p - p_begin < SF_AHEAD);
   sf_t* in_slot = lds + slot * SF_SLOT_STRIDE;
   sf_fix_boundary<sf_dense>(cx, p, p < p_end, in_slot);
@@ -420,7 +454,23 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
     sf_pin(acc2);
     sf_t rows[SF_RJ][SF_VK];
     sf_dense2::finish(sc, acc2[(PH2 - SFD2_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
-    sf_store_rows(rows, out, cx, q1 - 1 - SFD2_DLAST);
+    const int q2 = q1 - 1 - SFD2_DLAST;
+#if SF_NST == 3
+    // ---- ... published in turn; operator 3 on the plane that went there a step ago
+    sf_publish<sf_dense3>(cx, rows, (q2 + cx.goff >= 0) && (q2 + cx.goff < SF_N0G),
+                          lds + SF_MIDB0 + mw2 * SF_MID_STRIDE + mid_tb + SF_RJH * SF_LS + SF_RC);
+    constexpr int PH3 = (PH2 - SFD2_DLAST - 1 + 2 * SF_ACCS) % SF_ACCS;
+    const sf_t* tb3[SF_LAG3 + 1];
+#pragma unroll
+    for (int l = 0; l <= SF_LAG3; ++l) tb3[l] = lds + SF_MIDB0 + ((mw2 + SF_MID2_SLOTS - 1 - l) % SF_MID2_SLOTS) * SF_MID_STRIDE + mid_tb;
+    sf_dense3::template accumulate<PH3>(tb3, acc3);
+    sf_pin(acc3);
+    sf_t rows3[SF_RJ][SF_VK];
+    sf_dense3::finish(sc, acc3[(PH3 - SFD3_DLAST + 2 * SF_ACCS) % SF_ACCS], rows3);
+    sf_store_rows(rows3, out, cx, q2 - 1 - SFD3_DLAST);
+#else
+    sf_store_rows(rows, out, cx, q2);
+#endif
   };
   // (one slot between the operators: operator 2 reads it FIRST -- what the previous step published --, operator 1's
   //  plane goes there at the very end of the step, behind a second barrier that sits right before the next step's)
@@ -431,19 +481,10 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
   for (int l = 0; l <= SF_LAG; ++l) tb1[l] = lds + ((slot + SF_IN_SLOTS - l) % SF_IN_SLOTS) * SF_SLOT_STRIDE + cx.tb;
   sf_dense::template accumulate<PH>(tb1, acc1);
   sf_pin(acc1);
-  const bool plane1_in = (q1 + cx.goff >= 0) && (q1 + cx.goff < SF_N0G);
   sf_t mid[SF_RJ][SF_VK];
   sf_dense::finish(sc, acc1[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], mid);
   if constexpr (SF_MID_SLOTS == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read the slot
-#pragma unroll
-  for (int r = 0; r < SF_RJ; ++r) {
-    // outside the global domain operator 2 reads ITS boundary constant
-    const bool row_in = plane1_in && ((cx.jmask >> r) & 1u);
-    sf_vec w;
-#pragma unroll
-    for (int v = 0; v < SF_VK; ++v) w[v] = (row_in && ((cx.kmask >> v) & 1u)) ? mid[r][v] : sf_dense2::bc();
-    *reinterpret_cast<sf_vec*>(&mid_w[r * SF_LS]) = w;  // (the thread's own columns: 16-byte aligned)
-  }
+  sf_publish<sf_dense2>(cx, mid, (q1 + cx.goff >= 0) && (q1 + cx.goff < SF_N0G), mid_w);
   if constexpr (SF_MID_SLOTS != 1) second();
 }
 #endif
@@ -452,7 +493,8 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     SF_KERNEL_NAME(const sf_t* __restrict__ in, sf_t* __restrict__ out, sf_scalars sc, sf_auxptrs aux, int halo,
                    int goff, int i_begin, int i_end, int li, int nch1, int i_begin2, int i_end2) {
   (void)aux;
-  __shared__ __attribute__((aligned(1024))) sf_t lds[SF_LDS_ELEMS];
+  __shared__ __attribute__((aligned(1024))) sf_t lds_all[SF_LDS_ELEMS];
+  sf_t* const lds = lds_all + SF_LDS_FRONT;  // slot 0
 
   sf_ctx cx;
   cx.in = in;
@@ -477,9 +519,9 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   if (cx.cb >= cx.ce) return;
 
 #if SF_DENSE_T2
-  // the thread tile overlaps its neighbours: the second operator's results are valid RS rows (four columns when a row
-  // is cut into tiles) inside it
-  const int tj0 = SF_NOJ ? 0 : jt * (SF_TJ - 2 * SF_RS) - SF_RS, tk0 = SF_KTILED ? kt * (SF_TK - 8) - 4 : 0;
+  // the thread tile overlaps its neighbours: the last operator's results are valid (NST - 1) RS rows (four columns when
+  // a row is cut into tiles) inside it
+  const int tj0 = SF_NOJ ? 0 : jt * (SF_TJ - 2 * SF_EDGE) - SF_EDGE, tk0 = SF_KTILED ? kt * (SF_TK - 8) - 4 : 0;
 #else
   const int tj0 = SF_NOJ ? 0 : jt * SF_TJ, tk0 = kt * SF_TK;  // first output point of the tile
 #endif
@@ -516,7 +558,7 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
     const int j = tj0 + (SF_NOJ ? 0 : ty * SF_RJ + r), k = tk0 + tx * SF_VK;
 #if SF_DENSE_T2
     const int tr = ty * SF_RJ + r, tc = tx * SF_VK;
-    const bool valid = (SF_NOJ || (tr >= SF_RS && tr < SF_TJ - SF_RS)) && (!SF_KTILED || (tc >= 4 && tc < SF_TK - 4));
+    const bool valid = (SF_NOJ || (tr >= SF_EDGE && tr < SF_TJ - SF_EDGE)) && (!SF_KTILED || (tc >= 4 && tc < SF_TK - 4));
     const bool inside = valid && j >= 0 && j < SF_N1 && k >= 0 && k + SF_VK <= SF_N2;
 #else
     const bool inside = j < SF_N1 && k + SF_VK <= SF_N2;
@@ -543,7 +585,13 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   // the ring between the operators starts out as the second operator's boundary constant: its halo rows and columns
   // are never written again (they are right where the tile touches the edge of the domain; elsewhere the results
   // that read them are not stored)
+#if SF_NST == 3
+  for (int i = tid; i < SF_MID_SLOTS * SF_MID_STRIDE; i += SF_THREADS) lds[SF_MID0 + i] = sf_dense2::bc();
+  for (int i = tid; i < SF_MID2_SLOTS * SF_MID_STRIDE + SF_MID_PAD; i += SF_THREADS) lds[SF_MIDB0 + i] = sf_dense3::bc();
+  sf_dense3::acc_t acc3[SF_ACCS][SF_RJ][SF_VK];
+#else
   for (int i = tid; i < SF_MID_SLOTS * SF_MID_STRIDE + SF_MID_PAD; i += SF_THREADS) lds[SF_MID0 + i] = sf_dense2::bc();
+#endif
   sf_dense::acc_t acc1[SF_ACCS][SF_RJ][SF_VK];
   sf_dense2::acc_t acc2[SF_ACCS][SF_RJ][SF_VK];
 #pragma unroll
@@ -554,23 +602,38 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
       for (int v = 0; v < SF_VK; ++v) {
         acc1[a][r][v] = (sf_dense::acc_t)0;
         acc2[a][r][v] = (sf_dense2::acc_t)0;
+#if SF_NST == 3
+        acc3[a][r][v] = (sf_dense3::acc_t)0;
+#endif
       }
 #pragma unroll
   for (int a = 0; a < SF_AHEAD; ++a) sf_dma_plane(cx, p_begin + a, p_begin + a < p_end, a % SF_IN_SLOTS);
-  // output plane q2 leaves at step q2 + SFD_DLAST + 1 + SFD2_DLAST; input planes up to ce + R - 1 are read
+  // output plane q leaves at step q + SFD_DLAST + 1 + SFD2_DLAST (+ 1 + SFD3_DLAST); input planes up to ce + R - 1 are read
+#if SF_NST == 3
+  const int p_stop = cx.ce + SFD_DLAST + 1 + SFD2_DLAST + 1 + SFD3_DLAST;
+#define SF_ACCS_ARGS acc1, acc2, acc3
+#define SF_M2(n) ((mw2 + (n)) % SF_MID2_SLOTS)
+#else
   const int p_stop = cx.ce + SFD_DLAST + 1 + SFD2_DLAST;
-  int slot = 0, mw = 0;  // the input plane's slot; the slot operator 1's plane goes to
+#define SF_ACCS_ARGS acc1, acc2
+#define SF_M2(n) 0
+#endif
+  int slot = 0, mw = 0, mw2 = 0;  // the input plane's slot; the slots operator 1's and operator 2's planes go to
   for (int p = p_begin; p < p_stop; p += SF_ACCS) {
-    sf_step_t2<0>(lds, out, sc, cx, p, p_begin, p_end, slot, mw, acc1, acc2);
-    sf_step_t2<1>(lds, out, sc, cx, p + 1, p_begin, p_end, (slot + 1) % SF_IN_SLOTS, (mw + 1) % SF_MID_SLOTS, acc1, acc2);
-    sf_step_t2<2>(lds, out, sc, cx, p + 2, p_begin, p_end, (slot + 2) % SF_IN_SLOTS, (mw + 2) % SF_MID_SLOTS, acc1, acc2);
+    sf_step_t2<0>(lds, out, sc, cx, p, p_begin, p_end, slot, mw, SF_M2(0), SF_ACCS_ARGS);
+    sf_step_t2<1>(lds, out, sc, cx, p + 1, p_begin, p_end, (slot + 1) % SF_IN_SLOTS, (mw + 1) % SF_MID_SLOTS, SF_M2(1), SF_ACCS_ARGS);
+    sf_step_t2<2>(lds, out, sc, cx, p + 2, p_begin, p_end, (slot + 2) % SF_IN_SLOTS, (mw + 2) % SF_MID_SLOTS, SF_M2(2), SF_ACCS_ARGS);
 #if SF_ACCS == 5
-    sf_step_t2<3>(lds, out, sc, cx, p + 3, p_begin, p_end, (slot + 3) % SF_IN_SLOTS, (mw + 3) % SF_MID_SLOTS, acc1, acc2);
-    sf_step_t2<4>(lds, out, sc, cx, p + 4, p_begin, p_end, (slot + 4) % SF_IN_SLOTS, (mw + 4) % SF_MID_SLOTS, acc1, acc2);
+    sf_step_t2<3>(lds, out, sc, cx, p + 3, p_begin, p_end, (slot + 3) % SF_IN_SLOTS, (mw + 3) % SF_MID_SLOTS, SF_M2(3), SF_ACCS_ARGS);
+    sf_step_t2<4>(lds, out, sc, cx, p + 4, p_begin, p_end, (slot + 4) % SF_IN_SLOTS, (mw + 4) % SF_MID_SLOTS, SF_M2(4), SF_ACCS_ARGS);
 #endif
     slot = (slot + SF_ACCS) % SF_IN_SLOTS;
     mw = (mw + SF_ACCS) % SF_MID_SLOTS;
+#if SF_NST == 3
+    mw2 = (mw2 + SF_ACCS) % SF_MID2_SLOTS;
+#endif
   }
+  (void)mw2;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (requests of planes nobody reads: landed before the LDS is given back)
 #elif SF_DENSE_STREAM
   // (an output plane before cb collects planes that were never added to it: it is not stored; the first stored plane

@@ -6,6 +6,7 @@
 #include "sf_internal.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -547,19 +548,28 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
 // Two plain sums in one streaming dense launch (kernels/dense3d.h: SF_DENSE_T2, codegen.hpp: gen_dense_t2): radius-1
 // boxes, or (round 5) radius-2 sums of few terms -- the generator's crosses.  Tiles overlap by what ONE operator reaches
 // in rows (and, when a row is cut, four columns) on either side.
-static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>& memo, int k1, int k2, DT dt) {
+static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>& memo, const std::vector<int>& kernels, DT dt) {
   const Program& P = pl.P;
   const bool noj = P.n[1] == 1;
   struct Shape {
     int bx, by, rj;
   };
   StarChoice out;
+  const int nst = (int)kernels.size();  // operators per launch: two, or three (radius 1)
+  if (nst != 2 && nst != 3) return out;
   int reach = 1;
-  if (!dense_t2_eligible(P, P.kernels[k1], P.kernels[k2], &reach, true)) return out;
-  DenseSum sum1, sum2;
-  dense_sum_form(P, P.kernels[k1], &sum1);
-  dense_sum_form(P, P.kernels[k2], &sum2);
-  const int lag1 = stream_schedule(P.kernels[k1], sum1).max_lag, lag2 = stream_schedule(P.kernels[k2], sum2).max_lag;
+  std::vector<int> lags;
+  for (int s = 0; s < nst; ++s) {
+    int rs = 1;
+    if (s + 1 < nst && !dense_t2_eligible(P, P.kernels[kernels[s]], P.kernels[kernels[s + 1]], &rs, true)) return out;
+    reach = std::max(reach, rs);
+    DenseSum sum;
+    dense_sum_form(P, P.kernels[kernels[s]], &sum);
+    lags.push_back(stream_schedule(P.kernels[kernels[s]], sum).max_lag);
+  }
+  if (nst == 3 && reach != 1) return out;
+  const int k2 = kernels[1];
+  const int lag1 = lags[0], lag2 = lags[1], lag3 = nst == 3 ? lags[2] : 0;
   // (27-point box 512^3 f32, profiles/r04_dense_t2.log: 128x8x2 9.3e5 Mcells/s, 128x4x4 8.7e5, 128x6x2 8.5-8.7e5,
   //  128x4x3 8.4e5, 64x8x2 7.7e5, 64x4x4 7.4e5 against 8.5e5 on the compact kernel; 9-point box 4096^2: 64 lanes 1.18e6,
   //  128 lanes 1.11e6, 256 lanes 0.97e6 against 1.0e6)
@@ -573,10 +583,12 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
   // reach two: two rows per thread; rows of 34 threads -- 136 columns, 128 of them kept: a row of 512 is four tiles --
   // or of 32; the shape that keeps most of what it computes on this grid is tried first
   static const Shape shapes3d_reach2[] = {{34, 15, 2}, {34, 16, 2}, {32, 16, 2}, {34, 12, 2}, {32, 14, 2}, {32, 12, 2}, {32, 8, 2}, {32, 6, 2}};
+  // radius-1 sums whose terms are not ordered by plane, and three operators per launch
+  static const Shape shapes3d_lagged[] = {{34, 15, 3}, {34, 15, 2}, {34, 16, 2}, {34, 12, 3}, {34, 12, 2}, {32, 16, 2}, {32, 12, 2}, {32, 8, 2}};
   // dense.t2: 0 never, 1 (default) where a tile shape wastes at most a quarter of its lanes and rows on this grid,
   // 2 wherever a shape compiles (tests, fuzz campaigns on small grids)
   const bool force = pl.opt.get("dense.t2", 1) >= 2;
-  const std::string prefix = std::string(noj ? "sf_dense2d_" : "sf_dense3d_") + short_of(dt) + "_t2";
+  const std::string prefix = std::string(noj ? "sf_dense2d_" : "sf_dense3d_") + short_of(dt) + (nst == 3 ? "_t3" : "_t2");
   const long long pin_bx = pl.opt.get(noj ? "k2.bx" : "k1.bx", 0), pin_by = pl.opt.get("k1.by", 0), pin_rj = pl.opt.get("k1.rj", 0);
   std::vector<Shape> todo;
   if (pin_bx && (noj || (pin_by && pin_rj))) todo.push_back({(int)pin_bx, noj ? 1 : (int)pin_by, noj ? 1 : (int)pin_rj});
@@ -584,18 +596,21 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
   else if (reach == 2) todo.assign(std::begin(shapes3d_reach2), std::end(shapes3d_reach2));
   else if (dt == DT::F64) todo.assign(std::begin(shapes3d_f64), std::end(shapes3d_f64));
   else todo.assign(std::begin(shapes3d_f32), std::end(shapes3d_f32));
+  const int edge = (nst - 1) * reach;  // rows on either side of a tile whose results are not stored
+  const bool lagged = lag1 != 0 || lag2 != 0 || lag3 != 0;
   auto kept = [&](const Shape& sh) {  // what the tiles of this shape cover against what the grid holds
     const long long tk = (long long)sh.bx * (dt == DT::F64 ? 2 : 4), tj = noj ? 1 : (long long)sh.by * sh.rj;
-    if (tk <= 8 || (!noj && tj <= 2 * reach)) return 0.0;
-    const long long nkt = tk != P.n[2] ? (P.n[2] + (tk - 8) - 1) / (tk - 8) : 1, njt = noj ? 1 : (P.n[1] + (tj - 2 * reach) - 1) / (tj - 2 * reach);
+    if (tk <= 8 || (!noj && tj <= 2 * edge)) return 0.0;
+    const long long nkt = tk != P.n[2] ? (P.n[2] + (tk - 8) - 1) / (tk - 8) : 1, njt = noj ? 1 : (P.n[1] + (tj - 2 * edge) - 1) / (tj - 2 * edge);
     return ((double)P.n[2] / ((double)nkt * (double)tk)) * (noj ? 1.0 : (double)P.n[1] / ((double)njt * (double)tj));
   };
-  if (reach == 2 && !pin_bx)
+  if (reach == 1 && (lagged || nst == 3) && !noj && !pin_bx && dt == DT::F32) todo.assign(std::begin(shapes3d_lagged), std::end(shapes3d_lagged));
+  if ((reach == 2 || lagged || nst == 3) && !pin_bx)
     std::stable_sort(todo.begin(), todo.end(), [&](const Shape& a, const Shape& b) { return kept(a) > kept(b) + 0.02; });
   for (const Shape& sh : todo) {
     StarCfg c;
     c.T = 1;
-    c.R = 2 * reach;  // (what the group reaches, `reach` planes per operator: what the slab halo and the chunking see)
+    c.R = nst * reach;  // (what the group reaches, `reach` planes per operator: what the slab halo and the chunking see)
     c.dense = true;
     c.dense_stream = 1;
     c.dense_t2 = 1;
@@ -611,34 +626,35 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     // (a block need not be whole waves -- its last wave runs with lanes off and requests no pieces)
     if (sh.bx * sh.by > 1024 || sh.bx * sh.by < 64) continue;
     const long long tk = (long long)c.BX * c.VK, tj = noj ? 1 : (long long)c.BY * c.RJ;
-    if (!noj && tj < 2 * reach + 1) continue;
+    if (!noj && tj < 2 * edge + 1) continue;
     c.ktiled = tk != P.n[2];
     if (c.ktiled && tk <= 8) continue;
     c.HK = 0;
     c.NKT = c.ktiled ? (int)((P.n[2] + (tk - 8) - 1) / (tk - 8)) : 1;
-    c.NJT = noj ? 1 : (int)((P.n[1] + (tj - 2 * reach) - 1) / (tj - 2 * reach));
+    c.NJT = noj ? 1 : (int)((P.n[1] + (tj - 2 * edge) - 1) / (tj - 2 * edge));
     // what the tiles cover against what the grid holds (rows recomputed by the neighbouring tile, lanes beyond the row)
     const double used = ((double)P.n[2] / ((double)c.NKT * (double)tk)) * (noj ? 1.0 : (double)P.n[1] / ((double)c.NJT * (double)tj));
-    if (!force && !pin_bx && used < (reach == 2 ? 0.6 : 0.75)) continue;
-    const size_t row_bytes = (size_t)(tk + 2 * (16 / size_of(dt))) * size_of(dt);
+    if (!force && !pin_bx && used < ((reach == 2 || nst == 3) ? 0.6 : 0.75)) continue;
+    // (a row cut into tiles has no halo columns in LDS -- codegen.hpp: gen_dense_t2 -- and one 1-KiB piece in front of slot 0)
+    const size_t row_bytes = (size_t)(tk + (c.ktiled ? 0 : 2 * (16 / size_of(dt)))) * size_of(dt);
     const size_t slot = ((size_t)(tj + (noj ? 0 : 2 * reach)) * row_bytes + 1023) / 1024 * 1024;
     c.dense_in_slots = 2;  // (the plane requested a whole step ahead)
     c.dense_lag = lag1;
     size_t lds = 0;
-    if (reach == 1 && lag1 == 0 && lag2 == 0) {
+    if (reach == 1 && nst == 2 && !lagged) {
       // two input slots and two between the operators where four slots fit; three slots: ONE between the operators,
       // written at the very end of a step behind a second barrier
       const long long fit = (long long)(160 * 1024 / slot);
       if (fit < 3) continue;
       c.dense_mid_slots = fit >= 4 ? 2 : 1;
-      lds = (size_t)(c.dense_in_slots + c.dense_mid_slots) * slot;
+      lds = (size_t)(c.dense_in_slots + c.dense_mid_slots) * slot + (c.ktiled ? 1024 : 0);
     } else {
       // the input ring keeps the planes the first operator's late terms read; between the operators: the slot being
       // written, the plane published a step ago and the ones the second operator reads late -- TJ rows each, no halo
       // rows (dense3d.h: SF_MID_HALO 0)
       c.dense_mid_slots = 2 + lag2;
-      lds = (size_t)(c.dense_in_slots + lag1) * slot + (size_t)c.dense_mid_slots * ((size_t)tj * row_bytes) +
-            (size_t)(noj ? 0 : reach) * row_bytes + 16;
+      lds = (size_t)(c.dense_in_slots + lag1) * slot + (size_t)(c.dense_mid_slots + (nst == 3 ? 2 + lag3 : 0)) * ((size_t)tj * row_bytes) +
+            (size_t)(noj ? 0 : reach) * row_bytes + 32 + (c.ktiled ? 1024 : 0);
       if (lds > 160 * 1024) continue;
     }
     c.lds_bytes = lds;
@@ -647,7 +663,7 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     c.nt = (int)pl.opt.get("k1.nt", field_bytes >= 256.0 * 1024 * 1024 ? 1 : 0);
     StarKernelSource g;
     try {
-      g = gen_dense_t2(P, k1, k2, c);
+      g = gen_dense_t2(P, kernels, c);
     } catch (const Error&) {
       return out;  // (not a pair this form takes)
     }
@@ -776,7 +792,7 @@ static void describe_step(std::ostringstream& desc, const sf_plan& pl, const Ste
   desc << "  launch " << ck.name << ": ";
   for (int k : st.kernels) desc << P.kernels[k].name << " ";
   if (st.star)
-    desc << (st.compact ? "[compact windows " + std::to_string(st.cfg.nwin) + " T=" : st.dense ? std::string("[dense T=") : st.wide ? std::string("[wide star T=") : std::string("[star T=")) << ((st.dense && st.cfg.dense_t2) ? 2 : st.cfg.T) << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
+    desc << (st.compact ? "[compact windows " + std::to_string(st.cfg.nwin) + " T=" : st.dense ? std::string("[dense T=") : st.wide ? std::string("[wide star T=") : std::string("[star T=")) << ((st.dense && st.cfg.dense_t2) ? (int)st.kernels.size() : st.cfg.T) << " block " << st.cfg.BX << "x" << st.cfg.BY << " rows/thread "
          << st.cfg.RJ << " tiles " << st.cfg.NJT << "x" << st.cfg.NKT << " chunk "
          << star_chunk_length(pl, st.cfg, dt, (int)pl.n_local) << " lds " << star_lds_bytes(st.cfg, dt)
          << " B]";
@@ -833,7 +849,7 @@ static const OptionSpec kOptions[] = {
     {"compact", 0, 1, "kernel family switch: fused groups over {-1,0,1}^3, kernels/compact3d.h (default 1)"},
     {"wide", 0, 1, "kernel family switch: fused radius-2 star groups, kernels/wstar3d.h (default 1)"},
     {"dense", 0, 1, "kernel family switch: dense neighbourhoods and plain sums, kernels/dense3d.h (default 1)"},
-    {"dense.t2", 0, 2, "two plain sums per dense launch (radius-1 boxes; float32 3-D sums of few terms within two points): 0 never, 1 where a tile fits the grid (default), 2 wherever one compiles"},
+    {"dense.t2", 0, 3, "two plain sums per dense launch (radius-1 boxes; float32 3-D sums of few terms within two points): 0 never, 1 where a tile fits the grid (default), 2 wherever one compiles, 3 as 2 and chains of radius-1 sums in any order of their terms -- stars too -- up to three per launch"},
     {"generic_only", 0, 1, "every operator on the generic kernel, one per launch"},
     {"k1.bx", 0, 1024, "pin the tile shape, 3-D: lanes per row (with k1.by and k1.rj)"},
     {"k1.by", 0, 64, "pin the tile shape, 3-D: thread rows"},
@@ -1137,6 +1153,13 @@ void build_plan(sf_plan& pl) {
   if (P.n[1] == 1) fuse_default = 4;
   else if (P.kernels[0].dt == DT::F64) fuse_default = 3;
   const int fuse = (int)std::max<long long>(1, pl.opt.get("fuse", fuse_default));
+  // Two (or three) consecutive plain sums in one launch of the dense kernel's fused streaming form (select_dense_t2):
+  // operators k0, k0 + 1 (, k0 + 2) qualify pairwise, every field between them is a temporary with one reader.
+  // `need_reach`: 0, or what the group must reach per operator.
+  const long long t2mode = pl.opt.get("dense", 1) != 0 ? pl.opt.get("dense.t2", 1) : 0;
+  std::function<bool(Step&, int, bool, int, int)> stream_group;
+  // (dense.t2=3: up to three per launch unless fuse= says two)
+  const int stream_depth = t2mode >= 3 ? (int)std::max<long long>(2, std::min<long long>(3, pl.opt.get("fuse", 3))) : 2;
   const bool generic_only = pl.opt.get("generic_only", 0) != 0;
   // (any row length: the vector width follows it, rank_star_cfgs)
   const bool star_ok_dims = (P.nd >= 2) && P.n[0] > 1;
@@ -1239,6 +1262,32 @@ void build_plan(sf_plan& pl) {
   // ---- group kernels into launches
   std::map<std::string, StarChoice> star_memo;
   std::set<int> star_first;  // operators whose longer compact group did not come out: the star path after all
+  stream_group = [&](Step& st, int k0, bool any_order, int max_ops, int need_reach) {
+    if (t2mode == 0 || generic_only) return false;
+    int n = 1;
+    while (n < max_ops && k0 + n < K) {
+      int reach = 1;
+      const Kernel& prev = P.kernels[k0 + n - 1];
+      if (!dense_t2_eligible(P, prev, P.kernels[k0 + n], &reach, any_order) || (need_reach != 0 && reach != need_reach)) break;
+      if (P.field(prev.name).role != Role::Temp || consumers[prev.name] != 1) break;
+      ++n;
+    }
+    for (; n >= 2; --n) {
+      std::vector<int> group;
+      for (int i = 0; i < n; ++i) group.push_back(k0 + i);
+      StarChoice choice = select_dense_t2(pl, star_memo, group, P.kernels[k0].dt);
+      if (!choice.ok) continue;
+      st.star = true;
+      st.dense = true;
+      st.kernels = group;
+      st.cfg = choice.cfg;
+      st.ck = choice.ck;
+      st.alts = choice.alts;
+      st.sig = choice.sig;
+      return true;
+    }
+    return false;
+  };
   for (int k = 0; k < K;) {
     Step st;
     StarShape shape;
@@ -1267,24 +1316,13 @@ void build_plan(sf_plan& pl) {
     const bool wide = !generic_only && star_ok_dims && pl.opt.get("wide", 1) != 0 && wide_eligible(P, P.kernels[k]);
     // ... unless the operator and the next one are plain sums of few terms (the generator's crosses): the dense kernel's
     // fused streaming form (round 5: no register windows, no lanes recomputed beyond the tile's rim; select_dense_t2)
-    bool wide_pair = false;
     // (float32, three dimensions: the radius-2 cross 512^3 runs 249 us per launch of two against 303 on the wide-star
     //  kernel; float64 524-598 against 424 -- profiles/r05_cross2_fused.log)
-    if (wide && P.n[1] > 1 && P.kernels[k].dt == DT::F32 && pl.opt.get("dense.t2", 1) != 0 && pl.opt.get("dense", 1) != 0 &&
-        k + 1 < K && pl.opt.get("fuse", 2) >= 2 && dense_t2_eligible(P, P.kernels[k], P.kernels[k + 1]) &&
-        P.field(P.kernels[k].name).role == Role::Temp && consumers[P.kernels[k].name] == 1) {
-      StarChoice choice = select_dense_t2(pl, star_memo, k, k + 1, P.kernels[k].dt);
-      if (choice.ok) {
-        st.star = true;
-        st.dense = true;
-        st.kernels = {k, k + 1};
-        st.cfg = choice.cfg;
-        st.ck = choice.ck;
-        st.alts = choice.alts;
-        st.sig = choice.sig;
-        wide_pair = true;
-      }
-    }
+    bool wide_pair = wide && P.n[1] > 1 && P.kernels[k].dt == DT::F32 && pl.opt.get("fuse", 2) >= 2 && stream_group(st, k, false, 2, 0);
+    // dense.t2=3: chains of radius-1 star sums too, up to three per launch (jacobi3d 512^3: 294-299 us per launch of three
+    // against 205 per two on the star kernel, profiles/r05_c3_streaming.log -- not the default)
+    if (!wide && star && t2mode >= 3 && P.n[1] > 1 && P.kernels[k].dt == DT::F32)
+      wide_pair = stream_group(st, k, true, stream_depth, 0);
     if (wide_pair) {
       // (planned above)
     } else if (wide) {
@@ -1412,22 +1450,8 @@ void build_plan(sf_plan& pl) {
                      (cshape.extra.empty() || whole_domain);
       // two plain radius-1 sums (the generator's 27-point boxes): the dense kernel's fused streaming form where the pair
       // qualifies and a tile shape fits the grid (dense.t2, select_dense_t2); else the compact kernel
-      bool dense_pair = false;
-      if (compact && cshape.extra.empty() && pl.opt.get("dense.t2", 1) != 0 && pl.opt.get("dense", 1) != 0 && k + 1 < K &&
-          fuse >= 2 && dense_t2_eligible(P, P.kernels[k], P.kernels[k + 1], nullptr, pl.opt.get("star", 1) == 0) &&
-          P.field(P.kernels[k].name).role == Role::Temp && consumers[P.kernels[k].name] == 1) {
-        StarChoice choice = select_dense_t2(pl, star_memo, k, k + 1, P.kernels[k].dt);
-        if (choice.ok) {
-          st.star = true;
-          st.dense = true;
-          st.kernels = {k, k + 1};
-          st.cfg = choice.cfg;
-          st.ck = choice.ck;
-          st.alts = choice.alts;
-          st.sig = choice.sig;
-          dense_pair = true;
-        }
-      }
+      const bool dense_pair = compact && cshape.extra.empty() && fuse >= 2 &&
+                              stream_group(st, k, t2mode >= 3, (P.kernels[k].dt == DT::F32 && P.n[1] > 1) ? stream_depth : 2, 0);
       if (dense_pair) {
         // (planned above)
       } else if (compact) {
@@ -1513,22 +1537,8 @@ void build_plan(sf_plan& pl) {
       }
       // plain sums of few terms within two points (not stars: those are planned above), float32, three dimensions: two
       // per launch in the dense kernel's fused streaming form
-      int pair_reach = 0;
-      if (!st.star && st.kernels.size() == 1 && !generic_only && star_ok_dims && P.n[1] > 1 && P.kernels[k].dt == DT::F32 &&
-          pl.opt.get("dense.t2", 1) != 0 && pl.opt.get("dense", 1) != 0 && k + 1 < K && fuse >= 2 &&
-          dense_t2_eligible(P, P.kernels[k], P.kernels[k + 1], &pair_reach) && pair_reach == 2 &&
-          P.field(P.kernels[k].name).role == Role::Temp && consumers[P.kernels[k].name] == 1) {
-        StarChoice choice = select_dense_t2(pl, star_memo, k, k + 1, P.kernels[k].dt);
-        if (choice.ok) {
-          st.star = true;
-          st.dense = true;
-          st.kernels = {k, k + 1};
-          st.cfg = choice.cfg;
-          st.ck = choice.ck;
-          st.alts = choice.alts;
-          st.sig = choice.sig;
-        }
-      }
+      if (!st.star && st.kernels.size() == 1 && !generic_only && star_ok_dims && P.n[1] > 1 && P.kernels[k].dt == DT::F32 && fuse >= 2)
+        stream_group(st, k, false, 2, 2);
       // dense neighbourhoods of radius 2 (the generator's box of extent 2): one operator per launch, LDS tiles
       const bool dense_r3 = dense_r3_eligible(P, P.kernels[k]);
       if (!st.star && st.kernels.size() == 1 && !generic_only && star_ok_dims && pl.opt.get("dense", 1) != 0 &&
@@ -1685,7 +1695,7 @@ void build_plan(sf_plan& pl) {
     if (st.star) {
       if (star_lds_bytes(st.cfg, dt) > 160 * 1024)
         throw Error(SF_ERR_INVALID, "star kernel: tile needs more than 160 KiB of LDS");
-      StarKernelSource g = (st.dense && st.cfg.dense_t2) ? gen_dense_t2(P, st.kernels[0], st.kernels[1], st.cfg)
+      StarKernelSource g = (st.dense && st.cfg.dense_t2) ? gen_dense_t2(P, st.kernels, st.cfg)
                            : st.dense  ? gen_dense(P, st.kernels[0], st.cfg)
                            : st.wide ? gen_wide(P, st.kernels, st.cfg)
                            : st.compact ? gen_compact(P, st.kernels, st.cfg) : gen_star(P, st.kernels, st.cfg);

@@ -457,7 +457,7 @@ def test_radius_two_crosses_pair_up_in_the_fused_dense_form(tmp_path):
         text, src = plan.describe(), plan.kernel_source(0)
         assert "2 launches" in text and "sf_dense3d_f32_t2_" in text and "block 34x15 rows/thread 2 tiles 20x4" in text, text
         for macro in ("#define SF_RS 2\n", "#define SF_MID_HALO 0\n", "#define SF_LAG 2\n", "#define SF_LAG2 2\n", "#define SF_IN_SLOTS 4\n",
-                      "#define SF_MID_SLOTS 4\n", "#define SF_ACCS 5\n", "#define SFD_DLAST 2\n"):
+                      "#define SF_MID_SLOTS 4\n", "#define SF_ACCS 5\n", "#define SFD_DLAST 2\n", "#define SF_RCL 0\n"):
             assert macro in src, macro
         res = plan.kernel_resources()[plan.kernel_names()[0]]
         assert res["spills"] == 0 and res["scratch"] == 0 and res["vgprs"] <= 128 and res["lds"] <= 160 * 1024, res
@@ -468,3 +468,27 @@ def test_radius_two_crosses_pair_up_in_the_fused_dense_form(tmp_path):
         sfir = lower(sf.KernelChainGraph(programs.write_program(other, str(tmp_path / "other.json"))))
         with backend.Plan(sfir) as plan:
             assert "[wide star" in plan.describe() and "_t2_" not in plan.describe().replace("wstar3d_f64_t2", "").replace("wstar2d_f32_t2", ""), plan.describe()
+
+
+def test_three_radius_one_sums_per_launch_is_an_option_not_the_default(tmp_path):
+    """dense.t2=3 (round 5): chains of radius-1 plain sums in any order of their terms -- the benchmark's jacobi3d, a star --
+    up to three per launch of the dense kernel's fused streaming form: a second ring between the second and the third
+    operator (SF_NST 3), every ring keeping the plane the in-plane terms read late (the text lists i-1, i+1 first).
+    Measured on jacobi3d 512^3 at 294-299 us per launch of three against 205 per two on the star kernel
+    (profiles/r05_c3_streaming.log): 3-4 % per operator, inside the spread between boxes -- the default plan stays the star
+    kernel's, two per launch."""
+    sfir = lower(sf.KernelChainGraph(programs.write_program(programs.jacobi3d((512, 512, 512), 7), str(tmp_path / "c3.json"))))
+    with backend.Plan(sfir) as plan:
+        assert "4 launches" in plan.describe() and plan.describe().count("[star T=2") == 3 and "[dense" not in plan.describe()
+    with backend.Plan(sfir, options={"dense.t2": 3, "fuse": 3}) as plan:
+        text, src = plan.describe(), plan.kernel_source(0)
+        assert "3 launches" in text and text.count("sf_dense3d_f32_t3_") == 2 and "[dense T=3 block 34x15 rows/thread 2" in text, text
+        assert "[star T=1" in text  # (the seventh operator)
+        for macro in ("#define SF_NST 3\n", "#define SF_MID_HALO 0\n", "#define SF_LAG 1\n", "#define SF_LAG2 1\n", "#define SF_LAG3 1\n",
+                      "#define SF_IN_SLOTS 3\n", "#define SF_MID_SLOTS 3\n", "#define SF_ACCS 3\n", "#define SF_R 3\n", "#define SF_RCL 0\n"):
+            assert macro in src, macro
+        assert "struct sf_dense3 {" in src
+        res = plan.kernel_resources()[plan.kernel_names()[0]]
+        assert res["spills"] == 0 and res["scratch"] == 0 and res["lds"] <= 160 * 1024, res
+    with backend.Plan(sfir, options={"dense.t2": 3, "fuse": 2}) as plan:
+        assert "sf_dense3d_f32_t2_" in plan.describe() and "_t3_" not in plan.describe(), plan.describe()

@@ -1201,10 +1201,10 @@ def test_nonzero_boundary_constants_under_lds_dma(tmp_path, dims, extent, bc):
 
 
 @pytest.mark.parametrize("shape,extent,world", [("cross", 3, 2), ("cross", 3, 3), ("box", 3, 2), ("box", 2, 3), ("cross", 2, 2),
-                                                ("cross", 2, 3)])
+                                                ("cross", 2, 3), ("cross", 1, 2), ("cross", 1, 3)])
 def test_streaming_dense_launches_under_slab_decomposition(tmp_path, shape, extent, world):
     """The streaming dense forms on in-process slabs: a launch reaches `extent` planes across a slab boundary (the fused
-    pair of radius-2 crosses: four), the planes requested by LDS-DMA include ghost planes, and planes outside the GLOBAL
+    pair of radius-2 crosses: four; three radius-1 crosses per launch: three), the planes requested by LDS-DMA include ghost planes, and planes outside the GLOBAL
     domain (not the slab) are the ones that hold the boundary constant."""
     from stencilflow_amd.distributed import LocalExchanger, SlabRunner, run_lockstep
     from stencilflow_amd.lowering import lower
@@ -1212,11 +1212,13 @@ def test_streaming_dense_launches_under_slab_decomposition(tmp_path, shape, exte
     prog, x, chain = _synth_case(tmp_path, "float32", dims, extent, shape, {"type": "constant", "value": 0.5}, stages=3, seed=43)
     sfir = lower(chain)
     exch = LocalExchanger(world)
-    runners = [SlabRunner(sfir, dims, r, world, exchanger=exch.for_rank(r), groups_per_exchange=1,
-                          options={"dense.t2": 2} if extent == 2 and shape == "cross" else None) for r in range(world)]
+    options = {"dense.t2": 2} if extent == 2 and shape == "cross" else {"dense.t2": 3, "fuse": 3} if extent == 1 else None
+    runners = [SlabRunner(sfir, dims, r, world, exchanger=exch.for_rank(r), groups_per_exchange=1, options=options) for r in range(world)]
     assert all("[dense" in r.plan.describe() for r in runners), runners[0].plan.describe()
     if extent == 2 and shape == "cross":
         assert all("#define SF_RS 2\n" in r.plan.kernel_source(0) for r in runners)
+    if extent == 1:  # (three operators per launch: the launch reaches three planes across a slab boundary)
+        assert all("#define SF_NST 3\n" in r.plan.kernel_source(0) for r in runners)
     for r in runners:
         r.upload([x[r.lo:r.hi]])
     run_lockstep(runners)
@@ -1277,6 +1279,35 @@ def test_radius_two_crosses_two_per_streaming_dense_launch(tmp_path, dims, bc, s
         assert "#define SF_RS 2\n" in src and "#define SF_LAG 2\n" in src and "#define SF_LAG2 2\n" in src and "offen lds" in src
         if pins:
             assert "block %dx%d rows/thread %d" % (pins["k1.bx"], pins["k1.by"], pins["k1.rj"]) in plan.describe(), plan.describe()
+        plan.run([x], [got], 1)
+    want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("shape,dims,bc,stages,pins", [
+    ("cross", (14, 37, 72), {"type": "constant", "value": 0}, 3, {}),
+    ("cross", (9, 30, 136), {"type": "constant", "value": 0.5}, 6, {}),                         # float literal: double-typed sums
+    ("cross", (20, 33, 520), {"type": "constant", "value": -1}, 4, {}),                         # five k-tiles; the fourth operator alone
+    ("cross", (7, 5, 8), {"type": "constant", "value": 2}, 3, {}),                              # the whole grid inside a halo
+    ("box", (12, 40, 264), {"type": "constant", "value": 0.25}, 3, {}),                         # three 27-point sums
+    ("box", (33, 64, 512), {"type": "constant", "value": 1}, 5, {}),                            # three and two
+    ("cross", (12, 64, 512), {"type": "constant", "value": 0}, 3, {"k1.bx": 34, "k1.by": 30, "k1.rj": 1}),  # 1020 threads
+    ("cross", (70, 41, 136), {"type": "constant", "value": 0.5}, 6, {"k1.bx": 32, "k1.by": 8, "k1.rj": 2}),  # chunks of planes
+])
+def test_three_radius_one_sums_per_streaming_dense_launch(tmp_path, shape, dims, bc, stages, pins):
+    """dense.t2=3, fuse=3: three radius-1 plain sums per launch of the dense kernel's fused streaming form -- the generator's
+    crosses of extent 1 (the benchmark's operator: i-1, i+1, then the in-plane terms, which join their plane a step late) and
+    its 27-point boxes; the third operator reads a second LDS ring, tiles overlap by two rows, a row cut into tiles has
+    no halo columns in LDS.  Bit for bit the oracle's results."""
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    prog, x, chain = _synth_case(tmp_path, "float32", dims, 1, shape, bc, stages=stages, seed=47)
+    got = np.zeros(dims, np.float32)
+    with Plan(lower(chain), options=dict(pins, **{"dense.t2": 3, "fuse": 3})) as plan:
+        src = plan.kernel_source(0)
+        assert "sf_dense3d_f32_t3_" in plan.describe() and "[point]" not in plan.describe(), plan.describe()
+        assert "#define SF_NST 3\n" in src and "struct sf_dense3 {" in src and "offen lds" in src
+        assert ("#define SF_LAG 1\n" in src) == (shape == "cross")
         plan.run([x], [got], 1)
     want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
     assert np.array_equal(got, want, equal_nan=True)

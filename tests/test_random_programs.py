@@ -564,6 +564,22 @@ def test_hip_matches_oracle_on_fused_pairs_of_plain_sums(seed, tmp_path):
             assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 3, 4, 5, 8])
+def test_hip_matches_oracle_on_plain_sums_three_per_launch(seed, tmp_path):
+    """The same chains under dense.t2=3, fuse=3: up to three operators per launch, sums in random order included (they
+    end a fused group otherwise)."""
+    prog, ins, chain = _box_sum_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain), options={"dense.t2": 3, "fuse": 3}) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]]) for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
+
+
 def _sparse_sum_case(seed, tmp_path):
     import tests.random_programs as rp
     prog = rp.sparse_sum_program(seed)

@@ -33,7 +33,7 @@ WORKLOADS = {
     "cross2": ("float32", (512, 512, 512), 2, 4, "cross"),
     "cross2_f64": ("float64", (512, 512, 512), 2, 4, "cross"),
     "cross3": ("float32", (512, 512, 512), 3, 2, "cross"),
-    "jacobi3d": ("float32", (512, 512, 512), 1, 8, "jacobi3d"),  # (the benchmark's operator: programs.jacobi3d)
+    "jacobi3d": ("float32", (512, 512, 512), 1, 6, "jacobi3d"),  # (the benchmark's operator: programs.jacobi3d)
 }
 
 

@@ -13,13 +13,15 @@ for g in $gens; do
 done
 [ "$part" = slab ] || SF_HIP_OPTIONS="dense.t2=2" timeout -k 10 $((secs + 60)) python tools/star_fuzz.py --generator box_sum --seeds 100000 --first $first --seconds $secs > gpurun_out/${tag}_fuzz_box_sum_forced.log 2>&1
 echo "fuzz box_sum (dense.t2=2) rc=$? $(tail -1 gpurun_out/${tag}_fuzz_box_sum_forced.log)"
+[ "$part" = slab ] || SF_HIP_OPTIONS="dense.t2=3" timeout -k 10 $((secs + 60)) python tools/star_fuzz.py --generator box_sum --seeds 100000 --first $first --seconds $secs > gpurun_out/${tag}_fuzz_box_sum_three.log 2>&1
+echo "fuzz box_sum (dense.t2=3, three per launch) rc=$? $(tail -1 gpurun_out/${tag}_fuzz_box_sum_three.log)"
 [ "$part" = slab ] || SF_HIP_OPTIONS="dense.t2=2" timeout -k 10 $((secs + 60)) python tools/star_fuzz.py --generator sparse_sum --seeds 100000 --first $first --seconds $secs > gpurun_out/${tag}_fuzz_sparse_sum_forced.log 2>&1
 echo "fuzz sparse_sum (dense.t2=2) rc=$? $(tail -1 gpurun_out/${tag}_fuzz_sparse_sum_forced.log)"
 [ "$part" = undivided ] && exit 0
 slabs="mixed star wide compact dense box_sum sparse_sum dag"
 [ -n "${4:-}" ] && slabs=$(for g in $4; do case $g in dense_sum|copy) ;; *) echo $g;; esac; done)
 for g in $slabs; do
-  opt=""; { [ $g = box_sum ] || [ $g = sparse_sum ]; } && opt="dense.t2=2"
+  opt=""; [ $g = sparse_sum ] && opt="dense.t2=2"; [ $g = box_sum ] && opt="dense.t2=3"
   SF_HIP_OPTIONS="$opt" timeout -k 10 $((secs + 60)) python tools/slab_fuzz.py --generator $g --seeds 100000 --first $first --seconds $secs > gpurun_out/${tag}_fuzz_slab_$g.log 2>&1
   echo "slab fuzz $g rc=$? $(tail -1 gpurun_out/${tag}_fuzz_slab_$g.log)"
 done
