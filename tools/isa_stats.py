@@ -109,7 +109,8 @@ def updates_per_iteration(name, mac):
     elif name.startswith("sf_dense"):
         unroll, t = (mac.get("SF_ACCS", 5) if mac.get("SF_DENSE_STREAM", 0) else 6), 1  # (the streaming form rotates its accumulator sets)
         if mac.get("SF_DENSE_T2", 0):
-            unroll, t = 3, 2  # (two fused operators, three accumulator sets each)
+            # (two or three fused operators, 2 RS + 1 accumulator sets each: the step loop is unrolled by that many)
+            unroll, t = mac.get("SF_ACCS", 3), mac.get("SF_NST", 2)
         vk = mac.get("SF_VK", 4)
     else:
         return None
