@@ -225,7 +225,7 @@ def test_oracle_reproduces_the_reference_simulator_on_radius_2_stars(golden_dir,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", WIDE)
-@pytest.mark.parametrize("options", [None, {"fuse": 1}, {"generic_only": 1}, {"k1.bx": 64, "k1.by": 2, "k1.rj": 4}])
+@pytest.mark.parametrize("options", [None, {"fuse": 1}, {"generic_only": 1}, {"k1.bx": 64, "k1.by": 2, "k1.rj": 4, "dense.t2": 0}])
 def test_hip_against_the_reference_simulator_on_radius_2_stars(golden_dir, tmp_path, name, options):
     """The HIP path on the same vectors: the fused wide-star kernel (two operators per launch for
     the chain), one operator per launch, the generic kernel, and a pinned tile with thread rows
