@@ -644,7 +644,7 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
     if (reach == 1 && nst == 2 && !lagged) {
       // two input slots and two between the operators where four slots fit; three slots: ONE between the operators,
       // written at the very end of a step behind a second barrier
-      const long long fit = (long long)(160 * 1024 / slot);
+      const long long fit = (long long)((160 * 1024 - (c.ktiled ? 1024 : 0)) / slot);
       if (fit < 3) continue;
       c.dense_mid_slots = fit >= 4 ? 2 : 1;
       lds = (size_t)(c.dense_in_slots + c.dense_mid_slots) * slot + (c.ktiled ? 1024 : 0);
