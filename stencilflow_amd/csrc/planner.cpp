@@ -580,11 +580,12 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
   //  kernel two deep and 1.6e5 three deep)
   static const Shape shapes3d_f64[] = {{256, 3, 3}, {256, 4, 2}, {128, 8, 2}, {128, 4, 4}, {64, 8, 2}};
   static const Shape shapes2d[] = {{64, 1, 1}, {128, 1, 1}, {256, 1, 1}};
-  // reach two: two rows per thread; rows of 34 threads -- 136 columns, 128 of them kept: a row of 512 is four tiles --
-  // or of 32; the shape that keeps most of what it computes on this grid is tried first
-  static const Shape shapes3d_reach2[] = {{34, 15, 2}, {34, 16, 2}, {32, 16, 2}, {34, 12, 2}, {32, 14, 2}, {32, 12, 2}, {32, 8, 2}, {32, 6, 2}};
+  // reach two: rows of 34 threads -- 136 columns, 128 of them kept: a row of 512 is four tiles -- or of 32; the shape that
+  // keeps most of what it computes on this grid is tried first, among equals one row per thread (radius-2 cross 512^3,
+  // 30-row tiles: 34x30 threads x 1 row 226.6 us per launch, 34x15 x 2 rows 236.6 on the same box, profiles/r05_cross2_fused.log)
+  static const Shape shapes3d_reach2[] = {{34, 30, 1}, {34, 15, 2}, {34, 16, 2}, {32, 16, 2}, {34, 12, 2}, {32, 14, 2}, {32, 12, 2}, {32, 8, 2}, {32, 6, 2}};
   // radius-1 sums whose terms are not ordered by plane, and three operators per launch
-  static const Shape shapes3d_lagged[] = {{34, 15, 3}, {34, 15, 2}, {34, 16, 2}, {34, 12, 3}, {34, 12, 2}, {32, 16, 2}, {32, 12, 2}, {32, 8, 2}};
+  static const Shape shapes3d_lagged[] = {{34, 15, 3}, {34, 30, 1}, {34, 15, 2}, {34, 16, 2}, {34, 12, 3}, {34, 12, 2}, {32, 16, 2}, {32, 12, 2}, {32, 8, 2}};
   // dense.t2: 0 never, 1 (default) where a tile shape wastes at most a quarter of its lanes and rows on this grid,
   // 2 wherever a shape compiles (tests, fuzz campaigns on small grids)
   const bool force = pl.opt.get("dense.t2", 1) >= 2;

@@ -449,13 +449,13 @@ def test_radius_two_crosses_pair_up_in_the_fused_dense_form(tmp_path):
     kernel's fused streaming form since round 5 -- each operator reaches two planes (SF_RS 2), its eight in-plane terms
     join their output plane two steps after their own plane arrived (SF_LAG / SF_LAG2 2: four input slots, four slots of
     TJ rows between the operators), rows of 34 threads so that a row of 512 is four tiles of 128 kept columns (a block
-    of 510 threads: its last wave requests no pieces).  float64, 2-D and dense.t2=0 keep the wide-star kernel
+    of 1020 threads, one row each: its last wave has four lanes off and requests no pieces).  float64, 2-D and dense.t2=0 keep the wide-star kernel
     (profiles/r05_cross2_fused.log: 249 against 303 us per launch in float32, 524 against 424 in float64)."""
     cross, _ = programs.synthesize("float32", 4, 0.0, 512, 512, 512, 2, 2, 2)
     sfir = lower(sf.KernelChainGraph(programs.write_program(cross, str(tmp_path / "cross.json"))))
     with backend.Plan(sfir) as plan:
         text, src = plan.describe(), plan.kernel_source(0)
-        assert "2 launches" in text and "sf_dense3d_f32_t2_" in text and "block 34x15 rows/thread 2 tiles 20x4" in text, text
+        assert "2 launches" in text and "sf_dense3d_f32_t2_" in text and "block 34x30 rows/thread 1 tiles 20x4" in text, text
         for macro in ("#define SF_RS 2\n", "#define SF_MID_HALO 0\n", "#define SF_LAG 2\n", "#define SF_LAG2 2\n", "#define SF_IN_SLOTS 4\n",
                       "#define SF_MID_SLOTS 4\n", "#define SF_ACCS 5\n", "#define SFD_DLAST 2\n", "#define SF_RCL 0\n"):
             assert macro in src, macro
@@ -482,7 +482,7 @@ def test_three_radius_one_sums_per_launch_is_an_option_not_the_default(tmp_path)
         assert "4 launches" in plan.describe() and plan.describe().count("[star T=2") == 3 and "[dense" not in plan.describe()
     with backend.Plan(sfir, options={"dense.t2": 3, "fuse": 3}) as plan:
         text, src = plan.describe(), plan.kernel_source(0)
-        assert "3 launches" in text and text.count("sf_dense3d_f32_t3_") == 2 and "[dense T=3 block 34x15 rows/thread 2" in text, text
+        assert "3 launches" in text and text.count("sf_dense3d_f32_t3_") == 2 and "[dense T=3 block 34x30 rows/thread 1" in text, text
         assert "[star T=1" in text  # (the seventh operator)
         for macro in ("#define SF_NST 3\n", "#define SF_MID_HALO 0\n", "#define SF_LAG 1\n", "#define SF_LAG2 1\n", "#define SF_LAG3 1\n",
                       "#define SF_IN_SLOTS 3\n", "#define SF_MID_SLOTS 3\n", "#define SF_ACCS 3\n", "#define SF_R 3\n", "#define SF_RCL 0\n"):
