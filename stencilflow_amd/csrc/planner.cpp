@@ -850,7 +850,7 @@ static const OptionSpec kOptions[] = {
     {"compact", 0, 1, "kernel family switch: fused groups over {-1,0,1}^3, kernels/compact3d.h (default 1)"},
     {"wide", 0, 1, "kernel family switch: fused radius-2 star groups, kernels/wstar3d.h (default 1)"},
     {"dense", 0, 1, "kernel family switch: dense neighbourhoods and plain sums, kernels/dense3d.h (default 1)"},
-    {"dense.t2", 0, 3, "two plain sums per dense launch (radius-1 boxes; float32 3-D sums of few terms within two points): 0 never, 1 where a tile fits the grid (default), 2 wherever one compiles, 3 as 2 and chains of radius-1 sums in any order of their terms -- stars too -- up to three per launch"},
+    {"dense.t2", 0, 3, "two plain sums per dense launch (radius-1 boxes; float32 3-D sums of few terms within two points): 0 never, 1 where a tile fits the grid (default; chains of radius-1 star sums three per launch), 2 wherever one compiles, 3 as 2 and radius-1 sums in any order of their terms, stars too, two or three per launch"},
     {"generic_only", 0, 1, "every operator on the generic kernel, one per launch"},
     {"k1.bx", 0, 1024, "pin the tile shape, 3-D: lanes per row (with k1.by and k1.rj)"},
     {"k1.by", 0, 64, "pin the tile shape, 3-D: thread rows"},
@@ -1158,7 +1158,10 @@ void build_plan(sf_plan& pl) {
   // operators k0, k0 + 1 (, k0 + 2) qualify pairwise, every field between them is a temporary with one reader.
   // `need_reach`: 0, or what the group must reach per operator.
   const long long t2mode = pl.opt.get("dense", 1) != 0 ? pl.opt.get("dense.t2", 1) : 0;
-  std::function<bool(Step&, int, bool, int, int)> stream_group;
+  std::function<bool(Step&, int, bool, int, int, int)> stream_group_n;
+  auto stream_group = [&](Step& st, int k0, bool any_order, int max_ops, int need_reach, int min_ops = 2) {
+    return stream_group_n(st, k0, any_order, max_ops, need_reach, min_ops);
+  };
   // (dense.t2=3: up to three per launch unless fuse= says two)
   const int stream_depth = t2mode >= 3 ? (int)std::max<long long>(2, std::min<long long>(3, pl.opt.get("fuse", 3))) : 2;
   const bool generic_only = pl.opt.get("generic_only", 0) != 0;
@@ -1263,7 +1266,7 @@ void build_plan(sf_plan& pl) {
   // ---- group kernels into launches
   std::map<std::string, StarChoice> star_memo;
   std::set<int> star_first;  // operators whose longer compact group did not come out: the star path after all
-  stream_group = [&](Step& st, int k0, bool any_order, int max_ops, int need_reach) {
+  stream_group_n = [&](Step& st, int k0, bool any_order, int max_ops, int need_reach, int min_ops) {
     if (t2mode == 0 || generic_only) return false;
     int n = 1;
     while (n < max_ops && k0 + n < K) {
@@ -1273,7 +1276,7 @@ void build_plan(sf_plan& pl) {
       if (P.field(prev.name).role != Role::Temp || consumers[prev.name] != 1) break;
       ++n;
     }
-    for (; n >= 2; --n) {
+    for (; n >= min_ops; --n) {
       std::vector<int> group;
       for (int i = 0; i < n; ++i) group.push_back(k0 + i);
       StarChoice choice = select_dense_t2(pl, star_memo, group, P.kernels[k0].dt);
@@ -1320,10 +1323,26 @@ void build_plan(sf_plan& pl) {
     // (float32, three dimensions: the radius-2 cross 512^3 runs 249 us per launch of two against 303 on the wide-star
     //  kernel; float64 524-598 against 424 -- profiles/r05_cross2_fused.log)
     bool wide_pair = wide && P.n[1] > 1 && P.kernels[k].dt == DT::F32 && pl.opt.get("fuse", 2) >= 2 && stream_group(st, k, false, 2, 0);
-    // dense.t2=3: chains of radius-1 star sums too, up to three per launch (jacobi3d 512^3: 294-299 us per launch of three
-    // against 205 per two on the star kernel, profiles/r05_c3_streaming.log -- not the default)
-    if (!wide && star && t2mode >= 3 && P.n[1] > 1 && P.kernels[k].dt == DT::F32)
-      wide_pair = stream_group(st, k, true, stream_depth, 0);
+    // Chains of radius-1 star sums (the benchmark's jacobi3d), float32, three dimensions: THREE per launch of the same
+    // form where a tile shape fits the grid -- 91.0 against 97.9 us per operator at 512^3 on one box (1.47 against
+    // 1.37e6 Mcells/s), ahead on every grid tried from 128^3 to 512x256x1024 (profiles/r05_c3_streaming.log); pairs, and
+    // plans whose depth or tile shape the caller chose (fuse=, k1.bx ...), stay on the star kernel.  dense.t2=3: pairs
+    // too, on any grid.
+    const bool caller_tuned = pl.opt.kv.count("fuse") || pl.opt.kv.count("k1.bx") || pl.opt.kv.count("k1.by") || pl.opt.kv.count("k1.rj") ||
+                              pl.opt.kv.count("k1.vk");
+    if (!wide && star && P.n[1] > 1 && P.kernels[k].dt == DT::F32 && !star_first.count(k)) {
+      if (t2mode >= 3) {
+        wide_pair = stream_group(st, k, true, stream_depth, 0);
+      } else if (t2mode >= 1 && !caller_tuned) {
+        // (a launch of three costs about 1.5 launches of two, a lone operator as much as two: three now unless that leaves
+        //  one operator over -- a chain of four is two pairs)
+        int left = 1;
+        while (left < 5 && k + left < K && dense_t2_eligible(P, P.kernels[k + left - 1], P.kernels[k + left], nullptr, true) &&
+               P.field(P.kernels[k + left - 1].name).role == Role::Temp && consumers[P.kernels[k + left - 1].name] == 1)
+          ++left;
+        if (left >= 3 && left != 4) wide_pair = stream_group(st, k, true, 3, 0, 3);
+      }
+    }
     if (wide_pair) {
       // (planned above)
     } else if (wide) {

@@ -124,8 +124,10 @@ def test_committed_traffic_records_cover_the_bench_kernels():
         table = json.load(f)
     families = {v.get("family", k.rsplit("_", 1)[0]): v for k, v in table.items()}
     field = 512 ** 3 * 4
-    for fam, lo, hi in (("sf_star3d_f32_t2", 2 * field, 2.2 * field), ("slab2", 2 * field, 2.2 * field),
-                        ("slab4", 2 * field, 2.2 * field), ("slab8", 2 * field, 2.2 * field),
+    # (the benchmark's chain runs three operators per launch of the dense kernel's fused form since round 5: tiles of
+    #  34-thread rows re-read their halos, 1.13 x the field once in and once out)
+    for fam, lo, hi in (("sf_dense3d_f32_t3", 2 * field, 2.4 * field), ("sf_star3d_f32_t2", 2 * field, 2.2 * field),
+                        ("slab2", 2 * field, 2.4 * field), ("slab4", 2 * field, 2.4 * field), ("slab8", 2 * field, 2.4 * field),
                         ("sf_star3d_f64_t3", 4 * field, 4.6 * field), ("sf_star2d_f32_t4", 2 * 4096 ** 2 * 4, 2.6 * 4096 ** 2 * 4)):
         assert fam in families, (fam, sorted(families))
         assert lo <= families[fam]["hbm_bytes_per_launch"] <= hi, (fam, families[fam]["hbm_bytes_per_launch"])

@@ -470,25 +470,37 @@ def test_radius_two_crosses_pair_up_in_the_fused_dense_form(tmp_path):
             assert "[wide star" in plan.describe() and "_t2_" not in plan.describe().replace("wstar3d_f64_t2", "").replace("wstar2d_f32_t2", ""), plan.describe()
 
 
-def test_three_radius_one_sums_per_launch_is_an_option_not_the_default(tmp_path):
-    """dense.t2=3 (round 5): chains of radius-1 plain sums in any order of their terms -- the benchmark's jacobi3d, a star --
-    up to three per launch of the dense kernel's fused streaming form: a second ring between the second and the third
-    operator (SF_NST 3), every ring keeping the plane the in-plane terms read late (the text lists i-1, i+1 first).
-    Measured on jacobi3d 512^3 at 294-299 us per launch of three against 205 per two on the star kernel
-    (profiles/r05_c3_streaming.log): 3-4 % per operator, inside the spread between boxes -- the default plan stays the star
-    kernel's, two per launch."""
-    sfir = lower(sf.KernelChainGraph(programs.write_program(programs.jacobi3d((512, 512, 512), 7), str(tmp_path / "c3.json"))))
-    with backend.Plan(sfir) as plan:
-        assert "4 launches" in plan.describe() and plan.describe().count("[star T=2") == 3 and "[dense" not in plan.describe()
-    with backend.Plan(sfir, options={"dense.t2": 3, "fuse": 3}) as plan:
+def test_the_benchmark_chain_runs_three_operators_per_streaming_launch(tmp_path):
+    """Round 5: chains of radius-1 plain sums in any order of their terms -- the benchmark's jacobi3d, a star -- run THREE
+    per launch of the dense kernel's fused streaming form where a tile shape fits the grid: a second ring between the second
+    and the third operator (SF_NST 3), every ring keeping the plane the in-plane terms read late (the text lists i-1, i+1
+    first), rows of 34 threads, one row per thread.  jacobi3d 512^3: 91.0 against 97.9 us per operator on one box (1.47
+    against 1.37e6 Mcells/s), ahead on every grid tried (profiles/r05_c3_streaming.log).  A launch of three costs about 1.5
+    launches of two and a lone operator as much as two: a chain of four is two pairs on the star kernel, seven are 3 + 2 + 2;
+    plans whose depth or tile the caller chose (fuse=, k1.bx ...) and dense.t2=0 keep the star kernel; small grids too."""
+    def plan_of(stages, options=None, dims=(512, 512, 512)):
+        sfir = lower(sf.KernelChainGraph(programs.write_program(programs.jacobi3d(dims, stages), str(tmp_path / "c3.json"))))
+        return backend.Plan(sfir, options=options)
+    with plan_of(7) as plan:
         text, src = plan.describe(), plan.kernel_source(0)
-        assert "3 launches" in text and text.count("sf_dense3d_f32_t3_") == 2 and "[dense T=3 block 34x30 rows/thread 1" in text, text
-        assert "[star T=1" in text  # (the seventh operator)
+        assert "3 launches" in text and text.count("sf_dense3d_f32_t3_") == 1 and "[dense T=3 block 34x30 rows/thread 1" in text, text
+        assert text.count("[star T=2") == 2
         for macro in ("#define SF_NST 3\n", "#define SF_MID_HALO 0\n", "#define SF_LAG 1\n", "#define SF_LAG2 1\n", "#define SF_LAG3 1\n",
                       "#define SF_IN_SLOTS 3\n", "#define SF_MID_SLOTS 3\n", "#define SF_ACCS 3\n", "#define SF_R 3\n", "#define SF_RCL 0\n"):
             assert macro in src, macro
         assert "struct sf_dense3 {" in src
         res = plan.kernel_resources()[plan.kernel_names()[0]]
-        assert res["spills"] == 0 and res["scratch"] == 0 and res["lds"] <= 160 * 1024, res
-    with backend.Plan(sfir, options={"dense.t2": 3, "fuse": 2}) as plan:
+        assert res["spills"] == 0 and res["scratch"] == 0 and res["vgprs"] <= 128 and res["lds"] <= 160 * 1024, res
+    with plan_of(1000) as plan:  # (the benchmark: 332 launches of three, the last four operators two by two)
+        names = [plan.kernel_names()[plan.step_kernel(st)] for st in range(plan.num_steps)]
+        assert plan.num_launches == 334 and sum(n.startswith("sf_dense3d_f32_t3_") for n in names) == 332, plan.describe()[:300]
+        assert [n.split("_")[1] for n in names[-2:]] == ["star3d", "star3d"]
+    with plan_of(4) as plan:
+        assert plan.describe().count("[star T=2") == 2 and "[dense" not in plan.describe()
+    for options in ({"dense.t2": 0}, {"fuse": 2}, {"fuse": 3}, {"k1.bx": 128, "k1.by": 4, "k1.rj": 5}):
+        with plan_of(6, options) as plan:
+            assert "[star T=" in plan.describe() and "[dense" not in plan.describe(), (options, plan.describe())
+    with plan_of(6, None, (24, 40, 64)) as plan:  # (a grid no tile shape fits)
+        assert "[star T=2" in plan.describe() and "[dense" not in plan.describe()
+    with plan_of(6, {"dense.t2": 3, "fuse": 2}) as plan:
         assert "sf_dense3d_f32_t2_" in plan.describe() and "_t3_" not in plan.describe(), plan.describe()

@@ -788,8 +788,16 @@ def test_full_benchmark_configuration_bit_exact():
         chain = sf.KernelChainGraph(path)
     got = np.zeros((n, n, n), np.float32)
     with Plan(lower(chain)) as plan:
-        assert "star T=2" in plan.describe() and plan.num_launches == stages // 2
+        # (round 5: 332 launches of three operators in the dense kernel's fused streaming form, the last four
+        #  operators two by two on the star kernel -- the plan `python bench.py` times)
+        assert "[dense T=3 block 34x30 rows/thread 1" in plan.describe() and plan.num_launches == 334, plan.describe()[:400]
         plan.run([x], [got], 1)
+    # ... and the star kernel's plan of rounds 1-4, two operators per launch, which dense.t2=0 still selects
+    got2 = np.zeros((n, n, n), np.float32)
+    with Plan(lower(chain), options={"dense.t2": 0}) as plan:
+        assert "star T=2" in plan.describe() and plan.num_launches == stages // 2
+        plan.run([x], [got2], 1)
+    assert np.array_equal(got, got2)
     ref = c_oracle.CompiledReference(programs.jacobi3d((n, n, n), block))
     ref.threads = _oracle_threads()
     want = x
@@ -1066,7 +1074,9 @@ def test_full_c4_grid_eight_slabs_bit_exact():
     for v in views:
         v.reserved_cus = 32
     runners = [SlabRunner(sfir, shape, r, world, exchanger=views[r]) for r in range(world)]
-    assert runners[0].is_chain and runners[0].halo == 8 and runners[3].n_local == 512
+    # (four launches per exchange; a launch is three operators since round 5 -- two before: halos of 8 planes)
+    assert runners[0].is_chain and runners[0].halo == 12 and runners[3].n_local == 512
+    assert "[dense T=3" in runners[0].plan.describe()
     for r in runners:
         r.upload([c4_input(r.lo, r.hi)])
     run_lockstep(runners)

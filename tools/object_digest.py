@@ -40,9 +40,10 @@ def cases():
     from stencilflow_amd import programs
     syn = programs.synthesize
     return {
-        "c3": (programs.jacobi3d((512, 512, 512), 8), None),
+        "c3": (programs.jacobi3d((512, 512, 512), 8), "dense.t2=0"),
+        "c3_fused": (programs.jacobi3d((512, 512, 512), 9), None),
         "c3_t1": (programs.jacobi3d((512, 512, 512), 3), "fuse=1"),
-        "c3_slab": (programs.jacobi3d((512, 512, 512), 8), "slab=0:512:16:4096"),
+        "c3_slab": (programs.jacobi3d((512, 512, 512), 8), "slab=0:512:16:4096;dense.t2=0"),
         "c2": (programs.jacobi2d((4096, 4096), 8), "fuse=4"),
         "c5": (programs.diffusion_advection_laplacian((512, 512, 512)), "fuse=3"),
         "generic": (programs.jacobi3d((64, 64, 64), 2), "generic_only=1"),
