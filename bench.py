@@ -15,6 +15,9 @@ touches a GPU), relays rank 0's line and fails unless N ranks really took part
 bin/run_distributed_program.py:98-100,283-299).  Rank 0 prints ONE JSON line
 (contract: task description).
 
+The chain's plan since round 5: 332 launches of THREE operators each (kernels/dense3d.h, fused streaming form) and the
+last four operators two by two on the star kernel; `roofline` is about the former's launches (`roofline.scope`).
+
 `roofline` describes the dominant kernel (on rank 0 for N > 1: per GPU):
   achieved / frac   HBM bytes the kernel's launches move / their duration (HIP
                     events on the plan's stream), against the 8 TB/s peak; the bytes
@@ -27,7 +30,9 @@ bin/run_distributed_program.py:98-100,283-299).  Rank 0 prints ONE JSON line
                     of a launch.  A launch fuses `fused_operators` operators, so
                     this figure counts bytes that never travel and may exceed the
                     peak: it is the chain's speed-up over unfused sweeps, not a
-                    bandwidth.
+                    bandwidth.  (The more operators a launch fuses, the fewer bytes it
+                    moves per update: `frac` falls while `value` rises -- the launch of
+                    three sits at 0.55 where the launch of two sat at 0.69.)
 At N = 1 the line also carries `cpu_baseline` (the oracle's C/OpenMP port on the
 host cores) and `other_configs`: BASELINE.json's configs[1] (jacobi2d 4096^2) and
 configs[4] (the fused f64 chain), timed the same way for a few steps each, plus two
