@@ -243,9 +243,17 @@ class ShmExchanger:
         try:
             if create:
                 os.ftruncate(fd, size)
+            elif os.fstat(fd).st_size < size:
+                # (a mapping beyond the end of the owner's file would be pinned page by page until the device faults on it)
+                raise RuntimeError("shared-memory halo transport: the outbox {} holds {} bytes, this rank expects {}".format(
+                    path, os.fstat(fd).st_size, size))
             mm = mmap.mmap(fd, size)
         finally:
             os.close(fd)
+        if create:
+            # every page exists before anybody pins it: the neighbours register this file while the owner does, and a
+            # page of a fresh tmpfs file is allocated on first touch
+            mm[:] = bytes(size)
         addr = self._ct.addressof(self._ct.c_char.from_buffer(mm))
         dev = self._ct.c_void_p()
         self._check(self._lib.sf_host_register(self._ct.c_void_p(addr), size, self._ct.byref(dev)))
