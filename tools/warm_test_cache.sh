@@ -24,4 +24,7 @@ for name, stages in (("c3", 1000), ("c2", 1000), ("c5", 300), ("box", 16), ("wid
     _, sfir = bench.lower_program(wl["prog"])
     Plan(sfir).close()
 PY
+# ... and what the CPU suite compiles (it passes here; 8 minutes from a cold cache, 2 from a warm one)
+timeout 2400 python -m pytest tests -q -m "not gpu" -n $n -p no:cacheprovider > /tmp/warm_test_cache_cpu.log 2>&1
+tail -1 /tmp/warm_test_cache_cpu.log
 echo "$(ls .sf_cache | wc -l) code objects, $(du -sh .sf_cache | cut -f1)"
