@@ -18,12 +18,9 @@
 //   thread = SF_RJ consecutive rows x SF_VK consecutive k (one 16-byte vector
 //            per row); for every stage boundary a window of three planes
 //            (q-1, q, q+1) lives in registers.
-//   Input planes (SF_PREFETCH2): 0 = the plane for the next step is loaded into
-//   the window slot stage 1 has just freed; 1 = it is loaded into staging
-//   registers a step earlier and copied into the freed slot (a load has two
-//   steps to land); 2 = the input window has FOUR slots rotating with period 4
-//   (the step loop is unrolled by 4), so the plane after next is loaded straight
-//   into the slot freed now: two steps to land, no copy.
+//   Input planes: the plane for the next step is loaded into the window slot stage 1 has just freed, or (SF_RING4:
+//   3-D float32 chains and every 2-D program) the input window has FOUR slots rotating with period 4 -- the step loop is
+//   unrolled by 4 -- so the plane after next is loaded straight into the slot freed now: two steps to land, no copy.
 //   Per step one new input plane is read from HBM (coalesced 16 B/lane);
 //   i-neighbours come from the register window, j-neighbours from registers
 //   (inner rows) or LDS (first/last row of the adjacent thread row),
@@ -33,21 +30,15 @@
 //   with compile-time slot indices, so no register is ever copied -- the slot
 //   that held plane q-1 receives plane q+2.
 //
-// Step order (SF_REVERSE)
-//   0  stage 1 first, then stages 2..T, each consuming what the previous one
-//      produced in the same step; stage S produces plane p-S.  Default in 3-D.
-//   1  the storing stage T first, stage 1 last: every stage reads only planes
-//      finished in earlier steps (stage S produces plane p-(2S-1)), so the
-//      stages of one step are independent of each other.  Default in 2-D, where
-//      a block is a lone wave.
-//   2  as 1, with the input plane staged in `pf` and moved into the window at
-//      the start of the step.
+// Step order
+//   3-D: stage 1 first, then stages 2..T, each consuming what the previous one produced in the same step; stage S
+//   produces plane p-S.
+//   2-D (a block is a lone wave; chains only): the storing stage T first, stage 1 last -- every stage reads only planes
+//   finished in earlier steps (stage S produces plane p-(2S-1)), so the stages of one step are independent of each other.
 //
 // Macros from codegen: SF_T SF_VK SF_RJ SF_BX SF_BY SF_HK SF_KTILED SF_NOJ
-//   SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_LDS_DB SF_ROW_FENCE SF_OPAQUE SF_REVERSE
-//   SF_PREFETCH2 SF_PFD SF_SPREAD_LOADS SF_DPP SF_NT SF_TILE_ORDER SF_NAUX SF_KERNEL_NAME;
-//   diagnostic builds: SF_STAMP (cycle stamps), SF_EXPERIMENT (timing-only
-//   variants with parts removed -- results invalid);
+//   SF_N0G SF_N1 SF_N2 SF_NJT SF_NKT SF_ROW_FENCE SF_OPAQUE SF_RING4 SF_AUX_AHEAD SF_NT SF_KERNEL_NAME
+//   [SF_NS SF_NW SF_NOUT: DAG groups; SF_AUX_PASS];
 //   typedef sf_t, struct sf_scalars, struct sf_auxptrs,
 //   template<int S> struct sf_stage {bc(), bc_zero, bc_copy, load_aux(), apply()}.
 
@@ -103,8 +94,7 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 
 
 // window slots per stage and period of the phase rotation
-// (SF_PREFETCH2 3: a FIVE-slot input ring, two planes in flight -- a load has three steps to land; the step
-// loop is unrolled by five.  SF_RING4 names the ring forms, SF_INFLIGHT the planes in flight beside the window.)
+// (SF_RING4: the four-slot input ring; SF_INFLIGHT the planes in flight beside the window)
 #define SF_INFLIGHT (SF_RING4 ? 1 : 0)
 #define SF_SLOTS (3 + SF_INFLIGHT)
 
@@ -126,10 +116,10 @@ typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 #define SF_ROWS_ELEMS (SF_NW * SF_BY * 2 * SF_TKH)
 #endif
 #define SF_USE_LDS (!(SF_NOJ && SF_WPR == 1))
-// (SF_DPP 4: one virtual wave below and one above every row hold the boundary
+// (one virtual wave below and one above every row hold the boundary
 // constant, so a wave reads its neighbours' edge columns without testing whether
 // they exist)
-#define SF_VWAVES (4 == 4 && SF_WPR > 1)
+#define SF_VWAVES (SF_WPR > 1)
 #define SF_EDGE_WAVES (SF_VWAVES ? SF_WPR + 2 : SF_WPR)
 #define SF_EDGE_ELEMS (SF_NW * SF_BY * SF_RJ * SF_EDGE_WAVES * 2)
 #define SF_IMAGE_ELEMS (SF_ROWS_ELEMS + SF_EDGE_ELEMS)
@@ -278,7 +268,6 @@ __device__ __forceinline__ void sf_buf_store(const V v, const __amdgpu_buffer_rs
 // Is row r of input plane p inside the global domain (and inside what this chunk reads)?
 __device__ __forceinline__ bool sf_row_ok(const sf_ctx& cx, const int p, const int r) {
   const bool plane_in = (p + cx.goff >= 0) && (p + cx.goff < SF_N0G);
-  // SF_EXPERIMENT 5: timing-only build without the input loads (invalid results)
   return plane_in && ((cx.jmask >> r) & 1u) && cx.kvec_in;
 }
 
@@ -570,7 +559,7 @@ __device__ __forceinline__ void sf_stages_from(sf_state& st, const sf_t* lds, co
   }
 }
 
-// stages S, S-1, ..., 2 (SF_REVERSE order, chains only: the storing stage first)
+// stages S, S-1, ..., 2 (2-D chains: the storing stage first)
 template <int S, int PH>
 __device__ __forceinline__ void sf_later_stages_desc(sf_state& st, const sf_t* lds,
                                                      const sf_scalars& sc, const sf_outptrs& outs,
@@ -687,8 +676,8 @@ extern "C" __global__ void __launch_bounds__(SF_BX* SF_BY)
 #pragma unroll
   for (int i = 1; i < SF_NOUT; ++i) outs.p[i] = static_cast<sf_t*>(more.p[i - 1]);
 #endif
-  // SF_LDS_DB: two exchange images used alternately -> one barrier per step
-  __shared__ sf_t lds_all[(1 ? 2 : 1) * SF_IMAGE_ELEMS];
+  // two exchange images used alternately -> one barrier per step
+  __shared__ sf_t lds_all[2 * SF_IMAGE_ELEMS];
 #if SF_AUX_PASS
   __shared__ sf_aux_passed lds_aux[2 * SF_RJ * SF_BX * SF_BY];
 #endif
