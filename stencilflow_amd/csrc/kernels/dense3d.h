@@ -430,9 +430,10 @@ template <int PH>
 __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, const sf_scalars& sc, const sf_ctx& cx,
                                            const int p, const int p_begin, const int p_end, const int slot, const int mw,
                                            const int mw2, sf_dense::acc_t (&acc1)[SF_ACCS][SF_RJ][SF_VK],
-                                           sf_dense2::acc_t (&acc2)[SF_ACCS][SF_RJ][SF_VK]
+                                           sf_dense2::acc_t (&acc2)[SF_ACCS][SF_RJ][SF_VK], sf_dense::acc_t (&carry1)[SF_RJ][SF_VK],
+                                           sf_dense2::acc_t (&carry2)[SF_RJ][SF_VK]
 #if SF_NST == 3
-                                           , sf_dense3::acc_t (&acc3)[SF_ACCS][SF_RJ][SF_VK]
+                                           , sf_dense3::acc_t (&acc3)[SF_ACCS][SF_RJ][SF_VK], sf_dense3::acc_t (&carry3)[SF_RJ][SF_VK]
 #endif
 ) {
   sf_wait_plane<(SF_AHEAD - 1) * SF_NDMIN + SF_AHEAD * SF_RJ>(p - p_begin < SF_AHEAD);
@@ -450,7 +451,7 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
 #pragma unroll
     for (int l = 0; l <= SF_LAG2; ++l)
       tb2[l] = lds + SF_MID0 + (SF_MID_SLOTS == 1 ? 0 : (mw + SF_MID_SLOTS - 1 - l) % SF_MID_SLOTS) * SF_MID_STRIDE + mid_tb;
-    sf_dense2::template accumulate<PH2>(tb2, acc2);
+    sf_dense2::template accumulate<PH2>(tb2, acc2, carry2);
     sf_pin(acc2);
     sf_t rows[SF_RJ][SF_VK];
     sf_dense2::finish(sc, acc2[(PH2 - SFD2_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
@@ -463,7 +464,7 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
     const sf_t* tb3[SF_LAG3 + 1];
 #pragma unroll
     for (int l = 0; l <= SF_LAG3; ++l) tb3[l] = lds + SF_MIDB0 + ((mw2 + SF_MID2_SLOTS - 1 - l) % SF_MID2_SLOTS) * SF_MID_STRIDE + mid_tb;
-    sf_dense3::template accumulate<PH3>(tb3, acc3);
+    sf_dense3::template accumulate<PH3>(tb3, acc3, carry3);
     sf_pin(acc3);
     sf_t rows3[SF_RJ][SF_VK];
     sf_dense3::finish(sc, acc3[(PH3 - SFD3_DLAST + 2 * SF_ACCS) % SF_ACCS], rows3);
@@ -479,7 +480,7 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
   const sf_t* tb1[SF_LAG + 1];
 #pragma unroll
   for (int l = 0; l <= SF_LAG; ++l) tb1[l] = lds + ((slot + SF_IN_SLOTS - l) % SF_IN_SLOTS) * SF_SLOT_STRIDE + cx.tb;
-  sf_dense::template accumulate<PH>(tb1, acc1);
+  sf_dense::template accumulate<PH>(tb1, acc1, carry1);
   sf_pin(acc1);
   sf_t mid[SF_RJ][SF_VK];
   sf_dense::finish(sc, acc1[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], mid);
@@ -594,6 +595,22 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
 #endif
   sf_dense::acc_t acc1[SF_ACCS][SF_RJ][SF_VK];
   sf_dense2::acc_t acc2[SF_ACCS][SF_RJ][SF_VK];
+  // (the arriving plane's values at the thread's own points, kept for the step that reads them again: codegen)
+  sf_dense::acc_t carry1[SF_RJ][SF_VK];
+  sf_dense2::acc_t carry2[SF_RJ][SF_VK];
+#if SF_NST == 3
+  sf_dense3::acc_t carry3[SF_RJ][SF_VK];
+#endif
+#pragma unroll
+  for (int r = 0; r < SF_RJ; ++r)
+#pragma unroll
+    for (int v = 0; v < SF_VK; ++v) {
+      carry1[r][v] = (sf_dense::acc_t)0;
+      carry2[r][v] = (sf_dense2::acc_t)0;
+#if SF_NST == 3
+      carry3[r][v] = (sf_dense3::acc_t)0;
+#endif
+    }
 #pragma unroll
   for (int a = 0; a < SF_ACCS; ++a)
 #pragma unroll
@@ -611,11 +628,11 @@ extern "C" __global__ void __launch_bounds__(SF_THREADS, 2)
   // output plane q leaves at step q + SFD_DLAST + 1 + SFD2_DLAST (+ 1 + SFD3_DLAST); input planes up to ce + R - 1 are read
 #if SF_NST == 3
   const int p_stop = cx.ce + SFD_DLAST + 1 + SFD2_DLAST + 1 + SFD3_DLAST;
-#define SF_ACCS_ARGS acc1, acc2, acc3
+#define SF_ACCS_ARGS acc1, acc2, carry1, carry2, acc3, carry3
 #define SF_M2(n) ((mw2 + (n)) % SF_MID2_SLOTS)
 #else
   const int p_stop = cx.ce + SFD_DLAST + 1 + SFD2_DLAST;
-#define SF_ACCS_ARGS acc1, acc2
+#define SF_ACCS_ARGS acc1, acc2, carry1, carry2
 #define SF_M2(n) 0
 #endif
   int slot = 0, mw = 0, mw2 = 0;  // the input plane's slot; the slots operator 1's and operator 2's planes go to

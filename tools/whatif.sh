@@ -6,7 +6,7 @@
 # usage: bash tools/whatif.sh <dir under results/whatif> <workload of tools/dense_probe.py> "<plan options>" [clock]
 export SF_HIP_CACHE_DIR=off SF_HIP_SELF_CHECK=0 TMPDIR=/tmp
 dir=$1; wl=$2; opts=${3:-}; mode=${4:-time}
-for v in asis ahead2 ahead3 nobar nolds nodma nostore nomem valu; do
+for v in asis carry ahead2 ahead3 nobar nolds nodma nostore nomem valu; do
   [ -d results/whatif/$dir/$v ] || continue
   if [ "$mode" = clock ]; then
     out=gpurun_out/whatif_clock_${dir}_$v

@@ -6,7 +6,7 @@ SF_HIP_OBJECT_DIR=<out>/<variant> SF_HIP_SELF_CHECK=0 makes the library launch t
 (csrc/codecache.cpp: intern_kernel) -- e.g. under tools/dense_probe.py --no-check.  This replaces round 4's
 `debug.whatif` plan option: no wrong-result build is reachable through sf_plan_create any more.
 usage: whatif_objects.py WORKLOAD "PLAN OPTIONS" OUT_DIR [variant ...]
-  variants: asis nobar nolds nodma nostore nomem (= nodma + nostore) valu (= everything but the arithmetic) ahead2"""
+  variants: asis nobar nolds nodma nostore nomem (= nodma + nostore) valu (= everything but the arithmetic) ahead2 carry"""
 import os
 import re
 import subprocess
@@ -32,6 +32,11 @@ def edit(text, variant):
             continue
         elif part in ("ahead2", "ahead3"):  # (more input slots: planes requested two / three steps ahead -- the results stay right)
             text = re.sub(r"#define SF_IN_SLOTS (\d+)", lambda m: "#define SF_IN_SLOTS %d" % (int(m.group(1)) + int(part[-1]) - 1), text)
+        elif part == "carry":
+            # what keeping the converted own columns of a plane for the step that reads its centre row again would save
+            # (radius-1 crosses in the fused forms: the middle four of the six values of segment g1_<centre row>)
+            text = text.replace("typedef float sf_t;", "typedef float sf_t;\nstatic __device__ __forceinline__ double sf_fake_d() { double v; asm volatile(\"\" : \"=v\"(v)); return v; }\n", 1)
+            text = re.sub(r"\(double\)g1_3\[[1-4]\]", "sf_fake_d()", text)
         elif part == "nobar":
             text = text.replace("\\n\\ts_barrier", "").replace('asm volatile("s_barrier" ::: "memory");', "")
         elif part == "nolds":
