@@ -451,7 +451,7 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
 #pragma unroll
     for (int l = 0; l <= SF_LAG2; ++l)
       tb2[l] = lds + SF_MID0 + (SF_MID_SLOTS == 1 ? 0 : (mw + SF_MID_SLOTS - 1 - l) % SF_MID_SLOTS) * SF_MID_STRIDE + mid_tb;
-    sf_dense2::template accumulate<PH2>(tb2, acc2, carry2);
+    sf_dense2::template accumulate<PH2>(tb2, sc, acc2, carry2);
     sf_pin(acc2);
     sf_t rows[SF_RJ][SF_VK];
     sf_dense2::finish(sc, acc2[(PH2 - SFD2_DLAST + 2 * SF_ACCS) % SF_ACCS], rows);
@@ -464,7 +464,7 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
     const sf_t* tb3[SF_LAG3 + 1];
 #pragma unroll
     for (int l = 0; l <= SF_LAG3; ++l) tb3[l] = lds + SF_MIDB0 + ((mw2 + SF_MID2_SLOTS - 1 - l) % SF_MID2_SLOTS) * SF_MID_STRIDE + mid_tb;
-    sf_dense3::template accumulate<PH3>(tb3, acc3, carry3);
+    sf_dense3::template accumulate<PH3>(tb3, sc, acc3, carry3);
     sf_pin(acc3);
     sf_t rows3[SF_RJ][SF_VK];
     sf_dense3::finish(sc, acc3[(PH3 - SFD3_DLAST + 2 * SF_ACCS) % SF_ACCS], rows3);
@@ -480,7 +480,7 @@ __device__ __forceinline__ void sf_step_t2(sf_t* lds, sf_t* __restrict__ out, co
   const sf_t* tb1[SF_LAG + 1];
 #pragma unroll
   for (int l = 0; l <= SF_LAG; ++l) tb1[l] = lds + ((slot + SF_IN_SLOTS - l) % SF_IN_SLOTS) * SF_SLOT_STRIDE + cx.tb;
-  sf_dense::template accumulate<PH>(tb1, acc1, carry1);
+  sf_dense::template accumulate<PH>(tb1, sc, acc1, carry1);
   sf_pin(acc1);
   sf_t mid[SF_RJ][SF_VK];
   sf_dense::finish(sc, acc1[(PH - SFD_DLAST + 2 * SF_ACCS) % SF_ACCS], mid);

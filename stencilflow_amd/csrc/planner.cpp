@@ -561,7 +561,7 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
   std::vector<int> lags;
   for (int s = 0; s < nst; ++s) {
     int rs = 1;
-    if (s + 1 < nst && !dense_t2_eligible(P, P.kernels[kernels[s]], P.kernels[kernels[s + 1]], &rs, true)) return out;
+    if (s + 1 < nst && !dense_t2_eligible(P, P.kernels[kernels[s]], P.kernels[kernels[s + 1]], &rs, true, true)) return out;
     reach = std::max(reach, rs);
     DenseSum sum;
     dense_sum_form(P, P.kernels[kernels[s]], &sum);
@@ -1158,9 +1158,10 @@ void build_plan(sf_plan& pl) {
   // operators k0, k0 + 1 (, k0 + 2) qualify pairwise, every field between them is a temporary with one reader.
   // `need_reach`: 0, or what the group must reach per operator.
   const long long t2mode = pl.opt.get("dense", 1) != 0 ? pl.opt.get("dense.t2", 1) : 0;
-  std::function<bool(Step&, int, bool, int, int, int)> stream_group_n;
-  auto stream_group = [&](Step& st, int k0, bool any_order, int max_ops, int need_reach, int min_ops = 2) {
-    return stream_group_n(st, k0, any_order, max_ops, need_reach, min_ops);
+  std::function<bool(Step&, int, int, int, int, int)> stream_group_n;
+  // (`how`: 1 = the terms in any order, 2 = a factor per term allowed too -- what the star and wide-star branches pass)
+  auto stream_group = [&](Step& st, int k0, int how, int max_ops, int need_reach, int min_ops = 2) {
+    return stream_group_n(st, k0, how, max_ops, need_reach, min_ops);
   };
   // (dense.t2=3: up to three per launch unless fuse= says two)
   const int stream_depth = t2mode >= 3 ? (int)std::max<long long>(2, std::min<long long>(3, pl.opt.get("fuse", 3))) : 2;
@@ -1266,13 +1267,14 @@ void build_plan(sf_plan& pl) {
   // ---- group kernels into launches
   std::map<std::string, StarChoice> star_memo;
   std::set<int> star_first;  // operators whose longer compact group did not come out: the star path after all
-  stream_group_n = [&](Step& st, int k0, bool any_order, int max_ops, int need_reach, int min_ops) {
+  stream_group_n = [&](Step& st, int k0, int how, int max_ops, int need_reach, int min_ops) {
+    const bool any_order = (how & 1) != 0, weighted = (how & 2) != 0;
     if (t2mode == 0 || generic_only) return false;
     int n = 1;
     while (n < max_ops && k0 + n < K) {
       int reach = 1;
       const Kernel& prev = P.kernels[k0 + n - 1];
-      if (!dense_t2_eligible(P, prev, P.kernels[k0 + n], &reach, any_order) || (need_reach != 0 && reach != need_reach)) break;
+      if (!dense_t2_eligible(P, prev, P.kernels[k0 + n], &reach, any_order, weighted) || (need_reach != 0 && reach != need_reach)) break;
       if (P.field(prev.name).role != Role::Temp || consumers[prev.name] != 1) break;
       ++n;
     }
@@ -1322,7 +1324,7 @@ void build_plan(sf_plan& pl) {
     // fused streaming form (round 5: no register windows, no lanes recomputed beyond the tile's rim; select_dense_t2)
     // (float32, three dimensions: the radius-2 cross 512^3 runs 249 us per launch of two against 303 on the wide-star
     //  kernel; float64 524-598 against 424 -- profiles/r05_cross2_fused.log)
-    bool wide_pair = wide && P.n[1] > 1 && P.kernels[k].dt == DT::F32 && pl.opt.get("fuse", 2) >= 2 && stream_group(st, k, false, 2, 0);
+    bool wide_pair = wide && P.n[1] > 1 && P.kernels[k].dt == DT::F32 && pl.opt.get("fuse", 2) >= 2 && stream_group(st, k, 2, 2, 0);
     // Chains of radius-1 star sums (the benchmark's jacobi3d), float32, three dimensions: THREE per launch of the same
     // form where a tile shape fits the grid -- 91.0 against 97.9 us per operator at 512^3 on one box (1.47 against
     // 1.37e6 Mcells/s), ahead on every grid tried from 128^3 to 512x256x1024 (profiles/r05_c3_streaming.log); pairs, and
@@ -1332,15 +1334,15 @@ void build_plan(sf_plan& pl) {
                               pl.opt.kv.count("k1.vk");
     if (!wide && star && P.n[1] > 1 && P.kernels[k].dt == DT::F32 && !star_first.count(k)) {
       if (t2mode >= 3) {
-        wide_pair = stream_group(st, k, true, stream_depth, 0);
+        wide_pair = stream_group(st, k, 3, stream_depth, 0);
       } else if (t2mode >= 1 && !caller_tuned) {
         // (a launch of three costs about 1.5 launches of two, a lone operator as much as two: three now unless that leaves
         //  one operator over -- a chain of four is two pairs)
         int left = 1;
-        while (left < 5 && k + left < K && dense_t2_eligible(P, P.kernels[k + left - 1], P.kernels[k + left], nullptr, true) &&
+        while (left < 5 && k + left < K && dense_t2_eligible(P, P.kernels[k + left - 1], P.kernels[k + left], nullptr, true, true) &&
                P.field(P.kernels[k + left - 1].name).role == Role::Temp && consumers[P.kernels[k + left - 1].name] == 1)
           ++left;
-        if (left >= 3 && left != 4) wide_pair = stream_group(st, k, true, 3, 0, 3);
+        if (left >= 3 && left != 4) wide_pair = stream_group(st, k, 3, 3, 0, 3);
       }
     }
     if (wide_pair) {
@@ -1471,7 +1473,7 @@ void build_plan(sf_plan& pl) {
       // two plain radius-1 sums (the generator's 27-point boxes): the dense kernel's fused streaming form where the pair
       // qualifies and a tile shape fits the grid (dense.t2, select_dense_t2); else the compact kernel
       const bool dense_pair = compact && cshape.extra.empty() && fuse >= 2 &&
-                              stream_group(st, k, t2mode >= 3, (P.kernels[k].dt == DT::F32 && P.n[1] > 1) ? stream_depth : 2, 0);
+                              stream_group(st, k, t2mode >= 3 ? 1 : 0, (P.kernels[k].dt == DT::F32 && P.n[1] > 1) ? stream_depth : 2, 0);
       if (dense_pair) {
         // (planned above)
       } else if (compact) {
@@ -1558,7 +1560,7 @@ void build_plan(sf_plan& pl) {
       // plain sums of few terms within two points (not stars: those are planned above), float32, three dimensions: two
       // per launch in the dense kernel's fused streaming form
       if (!st.star && st.kernels.size() == 1 && !generic_only && star_ok_dims && P.n[1] > 1 && P.kernels[k].dt == DT::F32 && fuse >= 2)
-        stream_group(st, k, false, 2, 2);
+        stream_group(st, k, 0, 2, 2);
       // dense neighbourhoods of radius 2 (the generator's box of extent 2): one operator per launch, LDS tiles
       const bool dense_r3 = dense_r3_eligible(P, P.kernels[k]);
       if (!st.star && st.kernels.size() == 1 && !generic_only && star_ok_dims && pl.opt.get("dense", 1) != 0 &&

@@ -737,6 +737,63 @@ def sparse_sum_program(seed):
     return prog
 
 
+def weighted_cross_program(seed):
+    """Chains of 2-6 star operators, each ONE left-associated sum of products `factor * a[...]` / `a[...] * factor` / plain
+    accesses over a cross of radius 1 or 2 (the generator's `diffusion` shapes: a scalar per term, the centre first -- or
+    anywhere, or absent), factors literals or scalars of the program, the terms in the generator's order or shuffled;
+    constant boundaries.  What the dense kernel's fused streaming forms take with a factor per term since round 5 (three
+    per launch at radius 1, two at radius 2; dense.t2=3 forces the forms onto small grids)."""
+    rng = np.random.default_rng(456_000 + seed)
+    nd = 3 if rng.random() < 0.9 else 2
+    its = ["i", "j", "k"][3 - nd:]
+    if nd == 3:
+        dims = [int(rng.integers(4, 26)), int(rng.integers(3, 60)), 4 * int(rng.integers(2, 140))]
+    else:
+        dims = [int(rng.integers(5, 140)), 4 * int(rng.integers(2, 300))]
+    dtype = "float32" if rng.random() < 0.85 else "float64"
+    prog = {"inputs": {"a": {"data": "constant:1.0", "data_type": dtype}}, "outputs": [],
+            "dimensions": dims, "program": {}}
+    for name in ("s0", "s1"):
+        prog["inputs"][name] = {"data": float(np.round(rng.uniform(-0.5, 0.5), 3)), "data_type": dtype, "input_dims": []}
+    stages = int(rng.integers(2, 7))
+    radius = 1 if rng.random() < 0.5 else 2
+    prev = "a"
+    for s in range(stages):
+        name = "b%d" % s
+        if rng.random() < 0.15:
+            radius = 3 - radius  # (a change of radius ends a fused group)
+        offs = [tuple(d if a == ax else 0 for a in range(nd)) for ax in range(nd) for d in range(-radius, radius + 1) if d]
+        if rng.random() < 0.4:
+            offs = [offs[int(t)] for t in rng.permutation(len(offs))]
+        if rng.random() < 0.7:
+            offs.insert(0 if rng.random() < 0.6 else int(rng.integers(0, len(offs) + 1)), (0, ) * nd)
+        terms = []
+        weights = rng.random() < 0.85  # (now and then an operator without factors: a plain sum in the chain)
+        for off in offs:
+            acc = "%s[%s]" % (prev, ",".join(it if o == 0 else "%s%+d" % (it, o) for it, o in zip(its, off)))
+            kind = rng.random()
+            if not weights or kind < 0.15:
+                terms.append(acc)
+            else:
+                factor = ("s0" if kind < 0.45 else "s1" if kind < 0.6 else repr(float(np.round(rng.uniform(0.05, 0.4), 6))))
+                terms.append("%s * %s" % (factor, acc) if rng.random() < 0.8 else "%s * %s" % (acc, factor))
+        expr = " + ".join(terms)
+        kind = rng.random()
+        if kind < 0.5:
+            bc = {"type": "constant", "value": int(rng.integers(-1, 3))}
+        else:
+            bc = {"type": "constant", "value": float(rng.choice(EXACT))}
+        prog["program"][name] = {"computation_string": "%s = %s" % (name, expr),
+                                 "boundary_conditions": {prev: bc}, "data_type": dtype}
+        prev = name
+    prog["outputs"].append(prev)
+    text = " ".join(k["computation_string"] for k in prog["program"].values())
+    for name in ("s0", "s1"):
+        if name + " *" not in text and "* " + name not in text:
+            del prog["inputs"][name]
+    return prog
+
+
 # --- random chains of COMPACT operators (kernels/compact3d.h): any subset of the 27
 # offsets {-1,0,1}^3 of the previous stage, optionally a second full input field read
 # through such offsets, scalar / literal coefficients, int / float / shrink boundaries,

@@ -463,6 +463,11 @@ def test_radius_two_crosses_pair_up_in_the_fused_dense_form(tmp_path):
         assert res["spills"] == 0 and res["scratch"] == 0 and res["vgprs"] <= 128 and res["lds"] <= 160 * 1024, res
     with backend.Plan(sfir, options={"dense.t2": 0}) as plan:
         assert "[wide star T=2" in plan.describe()
+    # (sums with a factor per term too: the generator's `diffusion` shape at extent 2, 182.8 -> 144.7 us per operator)
+    weighted, _ = programs.synthesize("float32", 4, 0.0, 512, 512, 512, 2, 2, 2, stencil_shape="diffusion")
+    with backend.Plan(lower(sf.KernelChainGraph(programs.write_program(weighted, str(tmp_path / "diffusion.json"))))) as plan:
+        assert "2 launches" in plan.describe() and "sf_dense3d_f32_t2_" in plan.describe(), plan.describe()
+        assert " * (float)g" in plan.kernel_source(0)
     for dtype, dims in (("float64", (512, 512, 512)), ("float32", (4096, 4096, 0))):
         other, _ = programs.synthesize(dtype, 4, 0.0, *dims, 2, 2, 2 if dims[2] else 0)
         sfir = lower(sf.KernelChainGraph(programs.write_program(other, str(tmp_path / "other.json"))))

@@ -1323,6 +1323,33 @@ def test_three_radius_one_sums_per_streaming_dense_launch(tmp_path, shape, dims,
     assert np.array_equal(got, want, equal_nan=True)
 
 
+@pytest.mark.parametrize("extent,dims,dtype,bc,stages,options", [
+    (1, (14, 37, 72), "float32", {"type": "constant", "value": 0}, 3, {"dense.t2": 3}),
+    (1, (9, 30, 136), "float32", {"type": "constant", "value": 0.5}, 6, {"dense.t2": 3}),        # float literal: double-typed sums of float products
+    (1, (20, 33, 520), "float32", {"type": "constant", "value": -1}, 4, {"dense.t2": 3}),
+    (2, (14, 37, 72), "float32", {"type": "constant", "value": 0}, 2, {"dense.t2": 2}),
+    (2, (9, 30, 136), "float32", {"type": "constant", "value": 0.5}, 4, {"dense.t2": 2}),
+    (2, (31, 70, 264), "float32", {"type": "constant", "value": 0.25}, 3, {"dense.t2": 2}),       # the odd one out: wide-star kernel
+])
+def test_weighted_star_sums_in_the_fused_streaming_forms(tmp_path, extent, dims, dtype, bc, stages, options):
+    """The generator's `diffusion` shapes (bin/synthesize.py: every term of the cross times a scalar of its own, the centre
+    first) in the dense kernel's fused streaming forms: a product is formed in the common type of its factor and its
+    operand and then converted to the sum's, term by term in the order of the text; three per launch at extent 1, two at
+    extent 2.  512^3 float32 (profiles/r05_diffusion_fused.log): 98.7 -> 85.4 us per operator at extent 1 (star kernel
+    before), 182.8 -> 144.7 at extent 2 (wide-star kernel before).  Bit for bit the oracle's results."""
+    from stencilflow_amd.backend import Plan
+    from stencilflow_amd.lowering import lower
+    prog, x, chain = _synth_case(tmp_path, dtype, dims, extent, "diffusion", bc, stages=stages, seed=48)
+    got = np.zeros(dims, dtype)
+    with Plan(lower(chain), options=options) as plan:
+        src = plan.kernel_source(0)
+        assert ("sf_dense3d_f32_t3_" if extent == 1 else "sf_dense3d_f32_t2_") in plan.describe() and "[point]" not in plan.describe(), plan.describe()
+        assert "offen lds" in src and " * (float)g" in src  # (a factor per term)
+        plan.run(_plan_inputs(plan, prog, x), [got], 1)
+    want = npo.run_reference(prog, inputs={"a": x})[prog["outputs"][0]]
+    assert np.array_equal(got, want, equal_nan=True)
+
+
 def test_full_size_radius_three_cross_bit_exact():
     """The generator's radius-3 cross at the benchmark's 512^3 (bench.py's `cross3` workload): all 134 million results
     of a two-operator chain against the C oracle -- the tile, chunk and ring shapes the planner picks at full size."""

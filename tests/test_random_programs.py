@@ -580,6 +580,51 @@ def test_hip_matches_oracle_on_plain_sums_three_per_launch(seed, tmp_path):
             assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
 
 
+def _weighted_cross_case(seed, tmp_path):
+    import tests.random_programs as rp
+    prog = rp.weighted_cross_program(seed)
+    rng = np.random.default_rng(seed + 7)
+    p = npo.load_program(prog)
+    ins = {}
+    for name, desc in p["inputs"].items():
+        dims = npo._input_dims(p, name)
+        ins[name] = (rng.uniform(-1, 1, npo._dims_shape(p, dims)).astype(npo._NP[desc["data_type"]])
+                     if dims else desc["data"])
+    path = programs.write_program(prog, str(tmp_path / "p.json"))
+    return prog, ins, sf.KernelChainGraph(path)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 5])
+def test_weighted_crosses_take_the_fused_streaming_forms(seed, tmp_path):
+    """Chains of crosses of radius 1 or 2 with a factor per term -- literal or scalar, before or after the access, the
+    generator's `diffusion` order or shuffled (tests/random_programs.py: weighted_cross_program): the oracles agree, and
+    under dense.t2=3 consecutive float32 3-D operators share a launch of the dense kernel's fused form whose functors
+    multiply term by term (CPU: hipRTC only)."""
+    prog, ins, chain = _weighted_cross_case(seed, tmp_path)
+    a = npo.run_reference(prog, inputs=ins)
+    b = c_oracle.CompiledReference(prog).run(inputs=ins)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (seed, k)
+    with Plan(lower(chain), options={"dense.t2": 3}) as plan:
+        text = plan.describe()
+        fused = [i for i, n in enumerate(plan.kernel_names()) if n.startswith("sf_dense") and ("_t2_" in n or "_t3_" in n) and n in text]
+        assert fused and any(" * (" in plan.kernel_source(i) for i in fused), text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(0, 8)))
+def test_hip_matches_oracle_on_fused_weighted_crosses(seed, tmp_path):
+    prog, ins, chain = _weighted_cross_case(seed, tmp_path)
+    want = npo.run_reference(prog, inputs=ins)
+    with Plan(lower(chain), options={"dense.t2": 3}) as plan:
+        if plan.scalar_names:
+            plan.set_scalars([ins[n] for n in plan.scalar_names])
+        outs = [np.zeros(prog["dimensions"], dtype=npo._NP[prog["program"][n]["data_type"]]) for n in plan.output_names]
+        plan.run([np.ascontiguousarray(ins[n]) for n in plan.input_names], outs, 1)
+        for n, got in zip(plan.output_names, outs):
+            assert np.array_equal(got, want[n], equal_nan=True), (seed, n, plan.describe()[:600])
+
+
 def _sparse_sum_case(seed, tmp_path):
     import tests.random_programs as rp
     prog = rp.sparse_sum_program(seed)

@@ -33,7 +33,9 @@ WORKLOADS = {
     "cross2": ("float32", (512, 512, 512), 2, 4, "cross"),
     "cross2_f64": ("float64", (512, 512, 512), 2, 4, "cross"),
     "cross3": ("float32", (512, 512, 512), 3, 2, "cross"),
-    "jacobi3d": ("float32", (512, 512, 512), 1, 6, "jacobi3d"),  # (the benchmark's operator: programs.jacobi3d)
+    "jacobi3d": ("float32", (512, 512, 512), 1, 6, "jacobi3d"),
+    "diffusion1": ("float32", (512, 512, 512), 1, 6, "diffusion"),  # (a factor per term: scalars of the program)
+    "diffusion2": ("float32", (512, 512, 512), 2, 4, "diffusion"),  # (the benchmark's operator: programs.jacobi3d)
 }
 
 
@@ -65,10 +67,15 @@ def main():
     x = np.random.default_rng(5).uniform(-1, 1, shape).astype(dtype)
     with tempfile.TemporaryDirectory() as tmp:
         sfir = lower(sf.KernelChainGraph(programs.write_program(prog, os.path.join(tmp, "p.json"))))
+    def set_scalars(plan):
+        if plan.scalar_names:
+            plan.set_scalars([float(str(prog["inputs"][n]["data"]).split(":")[-1]) for n in plan.scalar_names])
+
     want = None
     if not args.no_check:
         want = np.zeros(shape, x.dtype)
         with Plan(sfir, options="generic_only=1") as plan:
+            set_scalars(plan)
             plan.run([x], [want], 1)
     for variant in args.variants.split("|"):
         try:
@@ -77,6 +84,7 @@ def main():
             print(json.dumps({"variant": variant, "error": str(exc)[:300]}), flush=True)
             continue
         got = np.zeros(shape, x.dtype)
+        set_scalars(plan)
         plan.run([x], [got], 1)
         plan.upload([x])
         plan.execute(2)

@@ -6,7 +6,7 @@ ranks in this process on one GPU (LocalExchanger copies the halos) and compares
 the stitched result bit for bit with the oracle.  Lower-dimensional inputs are
 replicated or sliced per rank as the slab runner expects.
 
-usage: slab_fuzz.py [--seeds 100] [--first 0] [--generator mixed|star|wide|compact|dense|box_sum|sparse_sum] [--copy] [--seconds S]"""
+usage: slab_fuzz.py [--seeds 100] [--first 0] [--generator mixed|star|wide|compact|dense|box_sum|sparse_sum|weighted_cross] [--copy] [--seconds S]"""
 import argparse
 import json
 import os
@@ -65,7 +65,7 @@ def run_seed(seed, tmp, generator="mixed", copy=False, seconds_per_case=None):
     split = "i" if len(dims) == 3 else "j"  # iterator of the outermost axis
     exch = LocalExchanger(world)
     fuse = int(rng.integers(1, 4))
-    if generator in ("wide", "dense", "box_sum", "sparse_sum"):
+    if generator in ("wide", "dense", "box_sum", "sparse_sum", "weighted_cross"):
         groups = min(groups, 2)  # (reach 2 per operator: deeper halos than the slabs are tall)
     early = bool(seed % 2)  # exchange started a launch ahead (SlabRunner early_exchange)
     label = {"seed": seed, "world": world, "groups": groups, "overlap": overlap, "dims": dims, "fuse": fuse,
@@ -115,7 +115,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
-    ap.add_argument("--generator", choices=["mixed", "star", "wide", "compact", "dense", "box_sum", "sparse_sum", "dag"], default="mixed",
+    ap.add_argument("--generator", choices=["mixed", "star", "wide", "compact", "dense", "box_sum", "sparse_sum", "weighted_cross", "dag"], default="mixed",
                     help="mixed = star chains and random DAGs (the default); the others: tests/random_programs.py")
     ap.add_argument("--copy", action="store_true", help="`copy` boundaries; reference: undivided run on the generic kernel")
     ap.add_argument("--seconds", type=float, default=0, help="stop after this many seconds (0: all seeds)")

@@ -30,7 +30,7 @@ from stencilflow_amd.backend import Plan  # noqa: E402
 from stencilflow_amd.lowering import lower  # noqa: E402
 from oracle import numpy_oracle as npo  # noqa: E402
 
-from tests.random_programs import (box_sum_program, sparse_sum_program, compact_program, dag_program, dense_program, dense_sum_program, star_program,  # noqa: E402
+from tests.random_programs import (box_sum_program, sparse_sum_program, weighted_cross_program, compact_program, dag_program, dense_program, dense_sum_program, star_program,  # noqa: E402
                                    wide_program, with_copy_boundaries)
 
 
@@ -40,14 +40,14 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--options", default="")
     ap.add_argument("--dump", type=int, default=-1, help="print the program of one seed and exit")
-    ap.add_argument("--generator", choices=["star", "wide", "dense", "dense_sum", "box_sum", "sparse_sum", "compact", "copy", "dag"], default="star")
+    ap.add_argument("--generator", choices=["star", "wide", "dense", "dense_sum", "box_sum", "sparse_sum", "weighted_cross", "compact", "copy", "dag"], default="star")
     ap.add_argument("--seconds", type=float, default=0, help="stop after this many seconds (0: run all seeds)")
     ap.add_argument("--copy", action="store_true",
                     help="turn a share of the boundary conditions into `copy`; reference: the generic kernel")
     args = ap.parse_args()
     if args.generator == "copy":
         args.generator, args.copy = "star", True
-    plain = {"wide": wide_program, "dense": dense_program, "dense_sum": dense_sum_program, "box_sum": box_sum_program, "sparse_sum": sparse_sum_program, "compact": compact_program,
+    plain = {"wide": wide_program, "dense": dense_program, "dense_sum": dense_sum_program, "box_sum": box_sum_program, "sparse_sum": sparse_sum_program, "weighted_cross": weighted_cross_program, "compact": compact_program,
              "dag": dag_program}.get(args.generator, star_program)
     make = (lambda seed: with_copy_boundaries(plain(seed), seed)) if args.copy else plain
     if args.dump >= 0:
