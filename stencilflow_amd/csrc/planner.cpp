@@ -546,8 +546,9 @@ static StarChoice select_dense(sf_plan& pl, std::map<std::string, StarChoice>& m
 }
 
 // Two plain sums in one streaming dense launch (kernels/dense3d.h: SF_DENSE_T2, codegen.hpp: gen_dense_t2): radius-1
-// boxes, or (round 5) radius-2 sums of few terms -- the generator's crosses.  Tiles overlap by what ONE operator reaches
-// in rows (and, when a row is cut, four columns) on either side.
+// boxes, or (round 5) radius-2 sums of few terms -- the generator's crosses --, or THREE radius-1 sums (the benchmark's
+// chain), with a factor per term where the caller allows it.  Tiles overlap by what all operators but the first reach in
+// rows (and, when a row is cut, four columns) on either side.
 static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>& memo, const std::vector<int>& kernels, DT dt) {
   const Program& P = pl.P;
   const bool noj = P.n[1] == 1;
@@ -676,13 +677,13 @@ static StarChoice select_dense_t2(sf_plan& pl, std::map<std::string, StarChoice>
       ck = intern_kernel(pl, prefix, g.source, slp_flags(false));
     } catch (const Error& e) {
       if (e.status != SF_ERR_COMPILE) throw;
-      report_rejected_candidate(pl, "dense (two fused)", std::to_string(sh.bx) + "x" + std::to_string(sh.by) + "x" + std::to_string(sh.rj), e);
+      report_rejected_candidate(pl, nst == 3 ? "dense (three fused)" : "dense (two fused)", std::to_string(sh.bx) + "x" + std::to_string(sh.by) + "x" + std::to_string(sh.rj), e);
       continue;
     }
     const CompiledKernel& k = pl.kernels[ck];
     if (pl.opt.get("debug", 0) != 0)
-      std::fprintf(stderr, "[sf_hip] dense candidate block %dx%d rows/thread %d (two plain sums fused, planes streamed): vgpr %d agpr %d spill %d scratch %d lds %d\n",
-                   sh.bx, sh.by, sh.rj, k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
+      std::fprintf(stderr, "[sf_hip] dense candidate block %dx%d rows/thread %d (%d plain sums fused, planes streamed): vgpr %d agpr %d spill %d scratch %d lds %d\n",
+                   sh.bx, sh.by, sh.rj, nst, k.vgprs, k.agprs, k.spills, k.scratch, k.lds);
     if (!kernel_unsafe(k) && (!kernel_slow(k) || (pin_bx != 0 && pl.opt.get("allow_spills", 0) != 0))) {
       out.ok = true;
       out.cfg = c;
